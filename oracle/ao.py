@@ -1,0 +1,121 @@
+"""Oracle: periodic AO collocation on a grid (numpy).  TEST INFRASTRUCTURE ONLY.
+
+Follows pyscf/pbc/gto/eval_gto.py:31-165 (driver, image list, Bloch phases) and the native code it
+calls: pyscf/lib/pbc/grid_ao.c:301-429 (per-shell image loop; an image contributes to a block of
+grid points when the block's minimum distance to the atom image is below the shell's rcut),
+pyscf/lib/gto/deriv1.c:31-58 (radial contraction  fac * sum_p c_p exp(-a_p r^2)) and :71-165
+(Cartesian angular factors).  The l>=2 Cartesian->real-spherical step lives in libcint (not in the
+tree); its d coefficients are pinned by pyscf/pbc/dft/test/test_numint.py:77-96 (see
+tests/test_oracle_pins.py).
+
+Two truncation rules are provided:
+  rule='blk56'  the reference's: blocks of 56 consecutive grid points share one include/skip decision
+                (grid_ao_drv.h:34 BLKSIZE, grid_ao.c:152-176,381).  Used to pin against the reference.
+  rule='point'  per grid point: an image contributes iff |r - R - T| < rcut(shell).  Independent of
+                grid ordering; this is the rule the HIP kernel implements.  The two differ by terms
+                below the cell precision (tests/test_oracle_pins.py bounds the difference).
+"""
+import numpy as np
+
+ATOM_OF, ANG_OF, NPRIM_OF, NCTR_OF, PTR_EXP, PTR_COEFF, BAS_SLOTS = 0, 1, 2, 3, 5, 6, 8
+PTR_COORD, ATM_SLOTS = 1, 6
+BLKSIZE = 56
+
+FAC_S = 0.282094791773878143   # pyscf/gto/mole.py:171-174 (CINTcommon_fac_sp)
+FAC_P = 0.488602511902919921
+# real solid harmonics l=2 in libcint order (xy, yz, z2, xz, x2-y2) on Cartesian (xx,xy,xz,yy,yz,zz)
+D_XY = 1.0925484305920792
+D_Z2_ZZ = 0.6307831305050401
+D_Z2_XXYY = 0.31539156525252005
+D_X2Y2 = 0.5462742152960396
+
+
+def ao_loc(bas):
+    dims = (bas[:, ANG_OF] * 2 + 1) * bas[:, NCTR_OF]
+    return np.append(0, np.cumsum(dims)).astype(np.int64)
+
+
+def _angular(l, dx, dy, dz):
+    """Real-spherical angular polynomials x^a y^b z^c combos (without radial part), list of arrays."""
+    if l == 0:
+        return [np.ones_like(dx)]
+    if l == 1:
+        return [dx, dy, dz]
+    if l == 2:
+        return [D_XY * dx * dy, D_XY * dy * dz,
+                D_Z2_ZZ * dz * dz - D_Z2_XXYY * (dx * dx + dy * dy),
+                D_XY * dx * dz, D_X2Y2 * (dx * dx - dy * dy)]
+    raise NotImplementedError('l > 2: libcint cart2sph coefficients are not pinned by the reference tree')
+
+
+def eval_ao(atm, bas, env, coords, Ls, rcut, kpts=None, rule='point'):
+    """AO values on ``coords`` (G,3).
+
+    Returns (G, nao) float64 for Γ (kpts None), else a list of (G, nao) arrays (float64 at Γ,
+    complex128 otherwise), the reference's return convention (eval_gto.py:153-165).
+    """
+    atm = np.asarray(atm).reshape(-1, ATM_SLOTS)
+    bas = np.asarray(bas).reshape(-1, BAS_SLOTS)
+    coords = np.asarray(coords, dtype=float)
+    G = coords.shape[0]
+    loc = ao_loc(bas)
+    nao = loc[-1]
+    gamma_only = kpts is None
+    kpts_lst = np.zeros((1, 3)) if gamma_only else np.reshape(kpts, (-1, 3))
+    nk = len(kpts_lst)
+    expLk = np.exp(1j * np.dot(Ls, kpts_lst.T))            # (nimg, nk)
+    all_gamma = bool(np.all(np.abs(kpts_lst).sum(axis=1) < 1e-9))
+    out = np.zeros((nk, nao, G), dtype=np.float64 if all_gamma else np.complex128)
+    rcut = np.asarray(rcut, dtype=float)
+    natm = len(atm)
+    nblk = (G + BLKSIZE - 1) // BLKSIZE
+    shells_of = [np.where(bas[:, ATOM_OF] == ia)[0] for ia in range(natm)]
+    for ia in range(natm):
+        shl = shells_of[ia]
+        if len(shl) == 0:
+            continue
+        ri = env[atm[ia, PTR_COORD]:atm[ia, PTR_COORD] + 3]
+        rc_max = rcut[shl].max()
+        for iL, L in enumerate(Ls):
+            d = coords - (ri + L)
+            rr = np.einsum('gx,gx->g', d, d)
+            if rule == 'blk56':
+                pad = np.full(nblk * BLKSIZE, np.inf)
+                pad[:G] = rr
+                dmin_blk = np.sqrt(pad.reshape(nblk, BLKSIZE).min(axis=1))
+                if not (dmin_blk < rc_max).any():
+                    continue
+            else:
+                if not (rr < rc_max * rc_max).any():
+                    continue
+            for ib in shl:
+                l, npr, nc = bas[ib, ANG_OF], bas[ib, NPRIM_OF], bas[ib, NCTR_OF]
+                if rule == 'blk56':
+                    m = np.repeat(dmin_blk < rcut[ib], BLKSIZE)[:G]
+                else:
+                    m = rr < rcut[ib] * rcut[ib]
+                idx = np.nonzero(m)[0]
+                if idx.size == 0:
+                    continue
+                es = env[bas[ib, PTR_EXP]:bas[ib, PTR_EXP] + npr]
+                cs = env[bas[ib, PTR_COEFF]:bas[ib, PTR_COEFF] + npr * nc].reshape(nc, npr)
+                fac = FAC_S if l == 0 else (FAC_P if l == 1 else 1.0)
+                e = np.exp(-np.outer(es, rr[idx])) * fac            # (nprim, n)
+                rad = cs.dot(e)                                       # (nctr, n)
+                ang = _angular(l, d[idx, 0], d[idx, 1], d[idx, 2])
+                deg = 2 * l + 1
+                for k in range(nc):
+                    for mm in range(deg):
+                        val = rad[k] * ang[mm]
+                        row = loc[ib] + k * deg + mm
+                        for kk in range(nk):
+                            out[kk, row, idx] += val if all_gamma else val * expLk[iL, kk]
+    res = []
+    for k in range(nk):
+        v = out[k]
+        if not all_gamma and abs(kpts_lst[k]).sum() < 1e-9:
+            v = v.real
+        res.append(np.ascontiguousarray(v.T))
+    if gamma_only or np.shape(kpts) == (3,):
+        return res[0]
+    return res

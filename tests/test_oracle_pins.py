@@ -1,0 +1,90 @@
+"""Pin the CPU oracle (and the host-side cell tables it is fed) against the reference's own
+known-answer constants.  No GPU, no pyscf."""
+import numpy as np
+import pytest
+from pyscf_isdf_amd import gto
+from oracle import ao as oao, pbc_tools as tools, fftdf
+import cells
+
+
+def _aoR(cell, rule='blk56', kpts=None):
+    coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    return oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpts=kpts, rule=rule), coords
+
+
+def test_gto_norm_known_value():
+    # pyscf/gto/mole.py:143-144
+    assert abs(gto.gto_norm(0, 1) - 2.5264751109842591) < 1e-13
+
+
+def test_eval_ao_dshell_pin():
+    # pyscf/pbc/dft/test/test_numint.py:96  fp(ao) = -0.54069672246407219 (places=8)
+    cell = cells.cell_c2_ccpvdz()
+    ao, _ = _aoR(cell)
+    assert ao.shape == (21 ** 3, 28)
+    assert abs(tools.fp(ao) - (-0.54069672246407219)) < 1e-8
+
+
+def test_truncation_rules_agree_within_precision():
+    cell = cells.cell_he_c()
+    a56, _ = _aoR(cell, 'blk56')
+    apt, _ = _aoR(cell, 'point')
+    assert abs(a56 - apt).max() < 1e-8       # cell.precision
+    assert abs(a56 - apt).max() > 0           # they are different rules
+
+
+@pytest.fixture(scope='module')
+def hec():
+    cell = cells.cell_he_c()
+    ao, coords = _aoR(cell)
+    return cell, ao, coords
+
+
+def test_fftdf_get_jk_identity_dm_pin(hec):
+    # pyscf/pbc/df/test/test_fft.py:641-645
+    cell, ao, _ = hec
+    dm = np.eye(cell.nao_nr())
+    vj = fftdf.get_j(ao, dm, cell.lattice_vectors(), cell.mesh)
+    vk = fftdf.get_k(ao, dm, cell.lattice_vectors(), cell.mesh)
+    assert abs(tools.fp(vj) - 3.7955873127283377) < 1e-8
+    assert abs(tools.fp(vk) - 4.290076429522121) < 1e-8
+
+
+def test_fftdf_ao_eri_pin(hec):
+    # pyscf/pbc/df/test/test_fft.py:692-695
+    cell, ao, _ = hec
+    eri = fftdf.get_ao_eri_s4(ao, cell.lattice_vectors(), cell.mesh)
+    assert abs(tools.fp(eri) - 0.80425358275734926) < 1e-8
+
+
+def test_fftdf_get_k_kpts_band_pin():
+    # pyscf/pbc/df/test/test_fft.py:555-557,663-676: 4 random k-points, 2 band k-points, MO-tagged DMs
+    cell = cells.cell_he_c()
+    np.random.seed(1)
+    kpts = np.random.random((4, 3))
+    kpts[3] = kpts[0] - kpts[1] + kpts[2]
+    np.random.seed(1)
+    kpts_band = np.random.random((2, 3))
+    nao = cell.nao_nr()
+    nk = 4
+    mo_coeff = np.random.random((nk, nao, nao))
+    mo_occ = np.array(np.random.random((nk, nao)) > .6, dtype=np.double)
+    dms = np.einsum('kpi,ki,kqi->kpq', mo_coeff, mo_occ, mo_coeff)
+    ao_k, coords = _aoR(cell, kpts=kpts)
+    ao_b, _ = _aoR(cell, kpts=kpts_band)
+    vj, vk = fftdf.get_jk_kpts(ao_k, dms, cell.lattice_vectors(), cell.mesh, coords, kpts,
+                               ao_band=ao_b, kpts_band=kpts_band, mo_coeff=mo_coeff, mo_occ=mo_occ)
+    assert abs(tools.fp(vk) - (10.239828255099447 + 2.1190549216896182j)) < 1e-8
+
+
+def test_fft_roundtrip_and_numpy_convention():
+    # pyscf/pbc/tools/test/test_pbc.py:185-217: fft == numpy.fft.fftn, ifft == numpy.fft.ifftn
+    rng = np.random.default_rng(0)
+    mesh = (5, 6, 7)
+    f = rng.standard_normal((3, 5 * 6 * 7))
+    g = tools.fft(f, mesh)
+    ref = np.fft.fftn(f.reshape(3, *mesh), axes=(1, 2, 3)).reshape(3, -1)
+    assert abs(g - ref).max() < 1e-12
+    assert abs(tools.ifft(g, mesh) - f).max() < 1e-13
