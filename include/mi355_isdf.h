@@ -1,0 +1,136 @@
+/*
+ * mi355_isdf.h — C ABI of libmi355_isdf.so: the MI355X (gfx950) ISDF hot path for PySCF's
+ * periodic density-fitting layer.
+ *
+ * Boundary style follows the reference's ctypes convention (SURVEY.md 8b "inner boundary"):
+ * plain C, raw pointers + explicit sizes, caller-owned buffers, nothing returned by allocation
+ * (pyscf/pbc/gto/eval_gto.py:140-151, pyscf/lib/numpy_helper.py:849-860, pyscf/pbc/tools/pbc.py:66-88).
+ * Two deliberate differences: every entry point returns an int status (0 = ok; the message is
+ * available from isdf_last_error), and data pointers named d_* are DEVICE pointers (HBM) so that
+ * the stages chain without leaving the GPU.  Pointers without the d_ prefix are host pointers to
+ * small tables.  All work is enqueued on the stream set with isdf_set_stream (default: the null
+ * stream); calls are asynchronous with respect to the host unless stated otherwise.
+ *
+ * Layouts (double precision throughout, Γ point):
+ *   ao      (nao, ld)   AO-major, grid index contiguous  — phi_mu(r_g) = ao[mu*ld + g]
+ *                       (the transpose of the reference's (G, nao) eval_ao return, eval_gto.py:153-161)
+ *   coords  (3, ngrids) SoA x|y|z                         (the reference passes F-ordered (G,3), eval_gto.py:130)
+ *   theta   (P, ldt)    one interpolation vector per row, grid index contiguous (FFT batch layout)
+ *   W       (P, ldw)    row-major
+ *   dm, vj, vk (nset, nao, nao) row-major
+ *   grid order: C order over (x,y,z) with fftfreq wrap-around, pyscf/pbc/gto/cell.py:874-898
+ */
+#ifndef MI355_ISDF_H
+#define MI355_ISDF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct isdf_ctx* isdf_handle;
+
+#define ISDF_OK 0
+#define ISDF_ERR_ARG 1      /* bad argument / unsupported shape */
+#define ISDF_ERR_HIP 2      /* HIP runtime error */
+#define ISDF_ERR_LIB 3      /* rocBLAS / rocSOLVER / hipFFT error */
+#define ISDF_ERR_NUM 4      /* numerical failure (e.g. Cholesky breakdown) */
+
+/* ABI version of this header (bumped on any signature change). */
+int isdf_abi_version(void);
+
+/* Create/destroy a context bound to one GPU (one context per process/rank).
+ * Replaces nothing in the reference (its native code is stateless); holds the hipFFT plans,
+ * the rocBLAS/rocSOLVER handles and reusable workspace. */
+int isdf_create(int device_id, isdf_handle* out);
+int isdf_destroy(isdf_handle h);
+int isdf_set_stream(isdf_handle h, void* hip_stream);
+const char* isdf_last_error(isdf_handle h);
+/* Bytes of device workspace currently held by the context. */
+int64_t isdf_workspace_bytes(isdf_handle h);
+/* Release cached workspace and FFT plans (keeps the context usable). */
+int isdf_release_workspace(isdf_handle h);
+
+/* S1. Periodic AO collocation, Γ point, real spherical GTOs, l <= 2.
+ * Replaces PBCGTOval_sph_deriv0 (pyscf/lib/pbc/grid_ao.c:524-534, driver :439-486, per-shell image
+ * loop :301-429; radial/angular parts pyscf/lib/gto/deriv1.c:31-165) as called from
+ * pyscf/pbc/gto/eval_gto.py:140-151.  atm/bas/env are the libcint tables (pyscf/gto/mole.py:59-89),
+ * Ls the translation list (eval_gto.py:132-136), rcut the per-shell cutoff (eval_gto.py:169-186).
+ * Truncation rule: image T contributes to grid point r iff |r - R_atom - T| < rcut[shell]
+ * (per point; the reference decides per block of 56 points — see oracle/ao.py). */
+int isdf_eval_ao(isdf_handle h,
+                 const int32_t* atm, int natm, const int32_t* bas, int nbas,
+                 const double* env, int nenv,
+                 const double* Ls, int nimgs, const double* rcut,
+                 const double* d_coords, int64_t ngrids,
+                 double* d_ao, int64_t ld);
+
+/* Copy columns: d_dst[mu*ld_dst + i] = d_src[mu*ld_src + d_idx[i]], i < n  (block-major regrouping
+ * of the grid for local selection; also picks phi at interpolation points). */
+int isdf_gather_cols(isdf_handle h, const double* d_src, int nrow, int64_t ld_src,
+                     const int64_t* d_idx, int64_t n, double* d_dst, int64_t ld_dst);
+
+/* S2. Interpolation-point selection: pivoted Cholesky of the implicit pair-density Gram matrix
+ * A(r,r') = (sum_mu ao[mu,r] ao[mu,r'])^2, independently for nblk column blocks
+ * [blk_off[b], blk_off[b+1]) of d_ao, nip[b] pivots each (stops early when the largest residual
+ * diagonal <= tol; tol < 0 means m_b * eps * max diag).  Pivot rule: the reference's
+ * pivoted_cholesky_python (pyscf/lib/scipy_helper.py:71-110) with a deterministic tie rule —
+ * the lowest index whose residual >= (1 - tie_rtol) * max is taken (tie_rtol = 0: plain argmax).
+ * Outputs: d_piv (nblk, kmax) int64 column indices LOCAL to each block, d_L (kmax, ldL) the
+ * Cholesky rows (row j of block b in columns blk_off[b]..), rank[b] (host) pivots actually taken.
+ * kmax = max_b nip[b].  Synchronises the stream before returning (rank is a host output). */
+int isdf_select_ip(isdf_handle h, const double* d_ao, int nao, int64_t ld,
+                   int nblk, const int64_t* blk_off, const int32_t* nip,
+                   double tol, double tie_rtol,
+                   double* d_L, int64_t ldL, int64_t* d_piv, int32_t* rank);
+
+/* S3a. Fit from the selection's own factor (single block): Theta = T^-1 L in place, with
+ * T[t,s] = L[t, piv[s]] upper triangular.  Equals the least-squares fit A_PP^-1 A_P. */
+int isdf_fit_from_chol(isdf_handle h, double* d_L, int k, int64_t m, int64_t ldL,
+                       const int64_t* d_piv);
+
+/* S3b. Global least-squares fit for an arbitrary interpolation-point set d_ip (grid indices):
+ * Theta = [(aoP aoP^T)^2]^-1 (aoP ao)^2 by Cholesky.  Also returns
+ * d_aoP (P, nao) = phi at the interpolation points.  Returns ISDF_ERR_NUM if A_PP is not
+ * numerically positive definite. */
+int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, int64_t ld,
+                    const int64_t* d_ip, int P, double* d_theta, int64_t ldt, double* d_aoP);
+
+/* S4+S5. Coulomb convolution and W:  for rows p in [row0, row0+nrows):
+ *   V_p = ifft( coulG * fft(theta_p) ).real,   W[p, q] = (vol/G) * sum_g V_p[g] theta_q[g],  q < P.
+ * FFT conventions of pyscf/pbc/tools/pbc.py:149-211 (forward unscaled, inverse 1/G), Coulomb kernel
+ * 4 pi/|G|^2 with G=0 -> 0 (pbc.py:352-356) on the fftfreq-ordered mesh (cell.py:552-587),
+ * normalisation of pyscf/pbc/df/fft_ao2mo.py:154-184.  a = lattice vectors (3,3 row-major, Bohr).
+ * d_W rows [row0, row0+nrows) are written (row-major, ldw >= P).  batch = rows per FFT batch. */
+int isdf_coulomb_W(isdf_handle h, const double* d_theta, int P, int64_t ldt,
+                   const int32_t mesh[3], const double a[9],
+                   int row0, int nrows, int batch, double* d_W, int64_t ldw);
+
+/* S6. J exactly as pyscf/pbc/df/fft_jk.py:63-107 (Γ, real dm):
+ *   rho = sum_mn dm_mn ao_m ao_n;  v = (vol/G) ifft(coulG fft rho).real;  vj = ao (v .* ao)^T.
+ * Grid columns [g0, g0+ng) only are contracted when ng < ngrids (grid-sharded partial sums:
+ * the density/potential FFT still uses the full grid, so ng<ngrids requires d_vR_in/out staging —
+ * see isdf_rho / isdf_vj_from_vR). */
+int isdf_get_j(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, int64_t ld,
+               const int32_t mesh[3], const double a[9],
+               const double* d_dm, int nset, double* d_vj);
+/* The three pieces of S6 separately (for grid-sharded multi-GPU runs). */
+int isdf_rho(isdf_handle h, const double* d_ao, int nao, int64_t ng, int64_t ld,
+             const double* d_dm, int nset, double* d_rho, int64_t ldrho);
+int isdf_coulomb_potential(isdf_handle h, double* d_rho_inout, int nset, int64_t ldrho,
+                           const int32_t mesh[3], const double a[9]);
+int isdf_vj_from_vR(isdf_handle h, const double* d_ao, int nao, int64_t ng, int64_t ld,
+                    const double* d_vR, int nset, int64_t ldv, double* d_vj);
+
+/* S7. K from the interpolation factorisation:
+ *   vk = aoP^T [ (aoP dm aoP^T) .* W ] aoP   for rows [row0,row0+nrows) of the Hadamard matrix
+ * (row-sharded partial sums for multi-GPU; pass row0=0,nrows=P for the whole thing). */
+int isdf_get_k(isdf_handle h, const double* d_aoP, int P, int nao,
+               const double* d_W, int64_t ldw, int row0, int nrows,
+               const double* d_dm, int nset, double* d_vk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

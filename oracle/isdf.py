@@ -1,0 +1,200 @@
+"""Oracle: the ISDF stages on the CPU (numpy).  TEST INFRASTRUCTURE ONLY.
+
+The mounted reference holds no ISDF code, so this file IS the specification
+the HIP kernels are checked against; conventions are anchored to the reference where it has them:
+
+* pivot rule / stopping tolerance: pyscf/lib/scipy_helper.py:71-110 (argmax of the residual diagonal,
+  L[k,k] = sqrt(D[k]), D -= L[:,k]^2, tol = n*eps*max(diag) when tol < 0);
+* grid order, weights w = vol/G: pyscf/pbc/gto/cell.py:874-898, pyscf/pbc/dft/gen_grid.py:88-96;
+* FFT / Coulomb kernel: pyscf/pbc/tools/pbc.py:149-211,230-420 (see oracle/pbc_tools.py);
+* normalisation of W: pyscf/pbc/df/fft_ao2mo.py:154-184, (ij|kl) = sum_r [ifft(fft(rho_ij) coulG vol/G)].real rho_kl;
+* J exactly as pyscf/pbc/df/fft_jk.py:63-107; output shapes as pyscf/pbc/df/df_jk.py:1426-1444.
+
+Layout: ``aoT`` is (nao, m) — AO-major, grid index contiguous (the device layout).
+
+Interpolation points are chosen by pivoted Cholesky of the pair-density Gram matrix
+A(r,r') = (sum_mu phi_mu(r) phi_mu(r'))^2, which is never formed: its diagonal is
+(sum_mu phi_mu(r)^2)^2 and column p is (aoT^T aoT[:,p])^2.  The Cholesky rows L (k, m) double as the
+fit: with T = L[:, piv] (upper triangular), the least-squares interpolation vectors
+Theta = A_PP^-1 A_P equal T^-1 L.
+
+Tie rule: exact argmax is not reproducible across CPU/GPU arithmetic on symmetric crystals, where
+symmetry-equivalent grid points tie to the last bit.  ``tie_rtol`` picks the LOWEST grid index whose
+residual is within (1 - tie_rtol) of the maximum; tie_rtol = 0 is the reference rule.
+"""
+import numpy as np
+import scipy.linalg
+from . import pbc_tools as tools
+
+TIE_RTOL = 1e-10
+
+
+def select_ip(aoT, k, tol=-1.0, tie_rtol=TIE_RTOL):
+    """Pivoted Cholesky of the implicit Gram matrix.  Returns (piv[int64 rank], L[rank, m])."""
+    aoT = np.asarray(aoT, dtype=float)
+    nao, m = aoT.shape
+    k = min(k, m)
+    d = np.einsum('ig,ig->g', aoT, aoT) ** 2
+    if tol < 0:
+        tol = m * np.finfo(float).eps * d.max()
+    L = np.zeros((k, m))
+    piv = np.zeros(k, dtype=np.int64)
+    alive = np.ones(m, dtype=bool)
+    rank = 0
+    for j in range(k):
+        dmax = d.max()
+        if dmax <= tol:
+            break
+        p = int(np.argmax(d >= dmax * (1.0 - tie_rtol)))
+        piv[j] = p
+        col = aoT.T.dot(aoT[:, p]) ** 2
+        if j:
+            col -= L[:j].T.dot(L[:j, p])
+        dp = np.sqrt(d[p])
+        row = col / dp
+        row[~alive] = 0.0          # residual rows of earlier pivots are exactly zero
+        row[p] = dp
+        L[j] = row
+        d -= row * row
+        alive[p] = False
+        d[~alive] = -1.0           # never selectable again
+        rank += 1
+    return piv[:rank], L[:rank]
+
+
+def fit_theta(L, piv):
+    """Theta (k, m) = T^-1 L with T = L[:, piv] upper triangular."""
+    T = np.triu(L[:, piv])
+    return scipy.linalg.solve_triangular(T, L, lower=False)
+
+
+def fit_theta_normal_equations(aoT, piv):
+    """The textbook fit  (phi_P phi_P^T)^2 Theta = (phi_P phi^T)^2  (SURVEY 7.1-3), for cross-checks."""
+    aoP = aoT[:, piv]
+    A = aoP.T.dot(aoP) ** 2
+    B = aoP.T.dot(aoT) ** 2
+    return np.linalg.lstsq(A, B, rcond=None)[0]
+
+
+def coulomb_V(theta, a, mesh):
+    """V_P = ifft(coulG * fft(Theta_P)).real, rows over P (k, G)."""
+    coulG = tools.get_coulG(a, mesh)
+    return tools.ifft(tools.fft(theta, mesh) * coulG, mesh).real
+
+
+def build_W(theta, a, mesh):
+    G = theta.shape[1]
+    w = abs(np.linalg.det(a)) / G
+    V = coulomb_V(theta, a, mesh)
+    return w * V.dot(theta.T)
+
+
+# ---- global (dense) ISDF ---------------------------------------------------------------------
+def build_global(aoT, a, mesh, nip, tie_rtol=TIE_RTOL):
+    piv, L = select_ip(aoT, nip, tie_rtol=tie_rtol)
+    theta = fit_theta(L, piv)
+    W = build_W(theta, a, mesh)
+    return dict(ip=piv, theta=theta, W=W, aoP=np.ascontiguousarray(aoT[:, piv].T))
+
+
+# ---- block-local ISDF ------------------------------------------------------------------------
+def partition_by_atom(coords, atom_coords, a, tie_atol=1e-9):
+    """Voronoi partition of grid points by nearest atom under the minimum-image convention.
+    Ties (|d - dmin| <= tie_atol) go to the lowest atom index.  Returns owner[G] (int32)."""
+    Ts = np.array([[i, j, k] for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1)], dtype=float).dot(a)
+    G = len(coords)
+    dmin = np.full(G, np.inf)
+    owner = np.zeros(G, dtype=np.int32)
+    for ia, R in enumerate(atom_coords):
+        da = np.full(G, np.inf)
+        for T in Ts:
+            d = coords - (R + T)
+            da = np.minimum(da, np.einsum('gx,gx->g', d, d))
+        da = np.sqrt(da)
+        better = da < dmin - tie_atol
+        owner[better] = ia
+        dmin = np.where(better, da, dmin)
+    return owner
+
+
+def build_local(aoT, a, mesh, owner, nip_per_block, tie_rtol=TIE_RTOL):
+    """Block-local ISDF.  ``owner[g]`` = block id of grid point g; ``nip_per_block[b]`` = points to pick.
+
+    Returns ip (global grid indices, block-major), blocks (list of dicts with idx, theta_b, ip_local),
+    W (P,P) and aoP (P, nao).  Theta is block-sparse: Theta[P in b, idx_b] = theta_b, zero elsewhere.
+    """
+    nblk = len(nip_per_block)
+    G = aoT.shape[1]
+    blocks, ips = [], []
+    for b in range(nblk):
+        idx = np.nonzero(owner == b)[0]
+        piv, L = select_ip(aoT[:, idx], nip_per_block[b], tie_rtol=tie_rtol)
+        th = fit_theta(L, piv)
+        blocks.append(dict(idx=idx, theta=th, ip_local=piv))
+        ips.append(idx[piv])
+    ip = np.concatenate(ips)
+    P = len(ip)
+    w = abs(np.linalg.det(a)) / G
+    W = np.zeros((P, P))
+    coulG = tools.get_coulG(a, mesh)
+    r0 = 0
+    for b in range(nblk):
+        kb = len(blocks[b]['ip_local'])
+        dense = np.zeros((kb, G))
+        dense[:, blocks[b]['idx']] = blocks[b]['theta']
+        V = tools.ifft(tools.fft(dense, mesh) * coulG, mesh).real
+        c0 = 0
+        for b2 in range(nblk):
+            kb2 = len(blocks[b2]['ip_local'])
+            W[r0:r0 + kb, c0:c0 + kb2] = w * V[:, blocks[b2]['idx']].dot(blocks[b2]['theta'].T)
+            c0 += kb2
+        r0 += kb
+    return dict(ip=ip, blocks=blocks, W=W, aoP=np.ascontiguousarray(aoT[:, ip].T))
+
+
+def theta_dense_from_blocks(blocks, G):
+    P = sum(len(b['ip_local']) for b in blocks)
+    th = np.zeros((P, G))
+    r0 = 0
+    for b in blocks:
+        kb = len(b['ip_local'])
+        th[r0:r0 + kb][:, b['idx']] = b['theta']
+        r0 += kb
+    return th
+
+
+# ---- J / K -------------------------------------------------------------------------------------
+def get_j(aoT, dm, a, mesh):
+    """Exact J (FFTDF formula) in the (nao, G) layout."""
+    dms = np.asarray(dm, dtype=float)
+    shape = dms.shape
+    dms = dms.reshape(-1, shape[-2], shape[-1])
+    G = aoT.shape[1]
+    w = abs(np.linalg.det(a)) / G
+    coulG = tools.get_coulG(a, mesh)
+    vj = np.empty_like(dms)
+    for i, d in enumerate(dms):
+        rho = np.einsum('ig,ig->g', d.dot(aoT), aoT)
+        vR = tools.ifft(coulG * tools.fft(rho, mesh), mesh).real * w
+        vj[i] = (aoT * vR).dot(aoT.T)
+    return vj.reshape(shape)
+
+
+def get_k(aoP, W, dm):
+    """K_mn = sum_PQ phi_m(r_P) [ (phi_P D phi_P^T)_PQ W_PQ ] phi_n(r_Q);  aoP is (P, nao)."""
+    dms = np.asarray(dm, dtype=float)
+    shape = dms.shape
+    dms = dms.reshape(-1, shape[-2], shape[-1])
+    vk = np.empty_like(dms)
+    for i, d in enumerate(dms):
+        M = aoP.dot(d).dot(aoP.T) * W
+        vk[i] = aoP.T.dot(M).dot(aoP)
+    return vk.reshape(shape)
+
+
+def isdf_eri_s4(aoP, W):
+    """(ij|kl) ~ sum_PQ phi_iP phi_jP W_PQ phi_kQ phi_lQ, packed s4 like fftdf.get_ao_eri_s4."""
+    nao = aoP.shape[1]
+    i, j = np.tril_indices(nao)
+    X = aoP[:, i] * aoP[:, j]            # (P, npair)
+    return X.T.dot(W).dot(X)

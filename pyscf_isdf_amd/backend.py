@@ -1,0 +1,137 @@
+"""Device backend: the stage functions of include/mi355_isdf.h on torch-owned HBM buffers.
+
+torch is plumbing here (device memory, streams, torch.distributed); all arithmetic happens inside
+libmi355_isdf.so.  The method set below is the contract between the host driver
+(pyscf_isdf_amd/isdf.py) and a backend; tests exercise the host driver's sharding logic on CPU by
+passing a checker backend with the same methods (tests/oracle_backend.py) — the product never does.
+"""
+import ctypes
+import numpy as np
+import torch
+from . import lib as _lib
+
+_vp = ctypes.c_void_p
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+class HipBackend:
+    name = 'hip-gfx950'
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise _lib.IsdfError('no GPU visible to torch; the ISDF path has no CPU fallback')
+        self.device = torch.device('cuda', device)
+        torch.cuda.set_device(self.device)
+        self.handle = _lib.Handle(device)
+
+    # ---- memory -------------------------------------------------------------------------------
+    def empty(self, shape, dtype=torch.float64):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype=torch.float64):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def to_device(self, a, dtype=None):
+        t = torch.as_tensor(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device)
+
+    def to_host(self, t):
+        return t.detach().cpu().numpy()
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    def release_workspace(self):
+        self.handle.call('isdf_release_workspace')
+
+    def _stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self.handle.call('isdf_set_stream', _vp(s))
+
+    @staticmethod
+    def _p(t):
+        assert t.is_contiguous() or t.stride(-1) == 1
+        return _vp(t.data_ptr())
+
+    # ---- stages -------------------------------------------------------------------------------
+    def eval_ao(self, atm, bas, env, Ls, rcut, coords_soa, ao):
+        """ao (nao, ld) <- collocation on coords_soa (3, G)."""
+        self._stream()
+        atm = np.ascontiguousarray(atm, dtype=np.int32)
+        bas = np.ascontiguousarray(bas, dtype=np.int32)
+        env = np.ascontiguousarray(env, dtype=np.float64)
+        Ls = np.ascontiguousarray(Ls, dtype=np.float64)
+        rcut = np.ascontiguousarray(rcut, dtype=np.float64)
+        G = coords_soa.shape[1]
+        assert coords_soa.is_contiguous() and ao.stride(1) == 1 and ao.shape[1] >= G
+        self.handle.call('isdf_eval_ao', _np_ptr(atm), len(atm), _np_ptr(bas), len(bas), _np_ptr(env), len(env),
+                         _np_ptr(Ls), len(Ls), _np_ptr(rcut), self._p(coords_soa), G, self._p(ao), ao.stride(0))
+
+    def gather_cols(self, src, idx, dst):
+        self._stream()
+        assert idx.dtype == torch.int64 and src.stride(1) == 1 and dst.stride(1) == 1
+        self.handle.call('isdf_gather_cols', self._p(src), src.shape[0], src.stride(0), self._p(idx), idx.numel(),
+                         self._p(dst), dst.stride(0))
+
+    def select_ip(self, ao, blk_off, nip, tol, tie_rtol, L, piv):
+        """Returns rank (np.int32[nblk]); fills L (kmax, ldL) and piv (nblk, kmax) int64 (local indices)."""
+        self._stream()
+        blk_off = np.ascontiguousarray(blk_off, dtype=np.int64)
+        nip = np.ascontiguousarray(nip, dtype=np.int32)
+        rank = np.zeros(len(nip), dtype=np.int32)
+        assert piv.dtype == torch.int64 and piv.is_contiguous() and ao.stride(1) == 1 and L.stride(1) == 1
+        self.handle.call('isdf_select_ip', self._p(ao), ao.shape[0], ao.stride(0), len(nip), _np_ptr(blk_off),
+                         _np_ptr(nip), float(tol), float(tie_rtol), self._p(L), L.stride(0), self._p(piv), _np_ptr(rank))
+        return rank
+
+    def fit_from_chol(self, L, k, m, piv):
+        self._stream()
+        self.handle.call('isdf_fit_from_chol', self._p(L), int(k), int(m), L.stride(0), self._p(piv))
+
+    def fit_global(self, ao, ngrids, ip, theta, aoP):
+        self._stream()
+        assert ip.dtype == torch.int64 and aoP.is_contiguous()
+        self.handle.call('isdf_fit_global', self._p(ao), ao.shape[0], int(ngrids), ao.stride(0), self._p(ip),
+                         ip.numel(), self._p(theta), theta.stride(0), self._p(aoP))
+
+    def coulomb_W(self, theta, mesh, a, row0, nrows, batch, W):
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self.handle.call('isdf_coulomb_W', self._p(theta), theta.shape[0], theta.stride(0), _np_ptr(mesh), _np_ptr(a),
+                         int(row0), int(nrows), int(batch), self._p(W), W.stride(0))
+
+    def get_j(self, ao, ngrids, mesh, a, dm, vj):
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert dm.is_contiguous() and vj.is_contiguous()
+        self.handle.call('isdf_get_j', self._p(ao), ao.shape[0], int(ngrids), ao.stride(0), _np_ptr(mesh), _np_ptr(a),
+                         self._p(dm), dm.shape[0], self._p(vj))
+
+    def rho(self, ao, ng, dm, rho):
+        self._stream()
+        self.handle.call('isdf_rho', self._p(ao), ao.shape[0], int(ng), ao.stride(0), self._p(dm), dm.shape[0],
+                         self._p(rho), rho.stride(0))
+
+    def coulomb_potential(self, rho, mesh, a):
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self.handle.call('isdf_coulomb_potential', self._p(rho), rho.shape[0], rho.stride(0), _np_ptr(mesh), _np_ptr(a))
+
+    def vj_from_vR(self, ao, ng, vR, vj):
+        self._stream()
+        self.handle.call('isdf_vj_from_vR', self._p(ao), ao.shape[0], int(ng), ao.stride(0), self._p(vR), vR.shape[0],
+                         vR.stride(0), self._p(vj))
+
+    def get_k(self, aoP, W, row0, nrows, dm, vk):
+        self._stream()
+        assert aoP.is_contiguous() and dm.is_contiguous() and vk.is_contiguous()
+        self.handle.call('isdf_get_k', self._p(aoP), aoP.shape[0], aoP.shape[1], self._p(W), W.stride(0), int(row0),
+                         int(nrows), self._p(dm), dm.shape[0], self._p(vk))

@@ -1,0 +1,75 @@
+// Internal shared definitions for libmi355_isdf.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+#include <hipfft/hipfft.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/mi355_isdf.h"
+
+struct FftPlan {
+  hipfftHandle fwd = 0, bwd = 0;
+  size_t work_bytes = 0;
+};
+
+struct isdf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  rocblas_handle blas = nullptr;
+  std::string err;
+  // cached FFT plans keyed by (n0,n1,n2,batch)
+  std::map<std::vector<int>, FftPlan> plans;
+  // named workspace buffers (grow-only until isdf_release_workspace)
+  std::map<std::string, std::pair<void*, size_t>> ws;
+  int num_cu = 256;
+};
+
+int isdf_fail(isdf_handle h, int code, const char* fmt, ...);
+void* isdf_ws(isdf_handle h, const char* name, size_t bytes);   // nullptr on failure (error set)
+int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out);
+
+#define HIP_TRY(h, expr)                                                                    \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return isdf_fail(h, ISDF_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr,        \
+                       hipGetErrorString(e_));                                              \
+  } while (0)
+#define BLAS_TRY(h, expr)                                                                   \
+  do {                                                                                      \
+    rocblas_status s_ = (expr);                                                             \
+    if (s_ != rocblas_status_success)                                                       \
+      return isdf_fail(h, ISDF_ERR_LIB, "%s:%d %s -> rocblas status %d", __FILE__, __LINE__, \
+                       #expr, (int)s_);                                                     \
+  } while (0)
+#define FFT_TRY(h, expr)                                                                    \
+  do {                                                                                      \
+    hipfftResult r_ = (expr);                                                               \
+    if (r_ != HIPFFT_SUCCESS)                                                               \
+      return isdf_fail(h, ISDF_ERR_LIB, "%s:%d %s -> hipfft result %d", __FILE__, __LINE__,  \
+                       #expr, (int)r_);                                                     \
+  } while (0)
+#define KERNEL_CHECK(h) HIP_TRY(h, hipGetLastError())
+#define ARG_CHECK(h, cond)                                                                  \
+  do {                                                                                      \
+    if (!(cond)) return isdf_fail(h, ISDF_ERR_ARG, "%s:%d argument check failed: %s",       \
+                                  __FILE__, __LINE__, #cond);                               \
+  } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- dense FP64 helpers implemented in gemm_f64.hip -------------------------------------------
+// C (M x N row-major, ldc) = alpha * A (M x K row-major, lda) * B(N x K row-major, ldb)^T + beta * C
+// "NT with K contiguous in both operands": the shape of W = V Theta^T and of J = ao (v.ao)^T.
+int gemm_nt_f64(isdf_handle h, int M, int N, int64_t K, double alpha, const double* A, int64_t lda,
+                const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+// Row-major wrappers over rocBLAS for the well-shaped products.
+// C (M x N, ldc) = alpha * op(A) * op(B) + beta * C, all row-major; opA/opB 'N' or 'T'.
+int gemm_rm(isdf_handle h, char opA, char opB, int64_t M, int64_t N, int64_t K, double alpha,
+            const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+            int64_t ldc);

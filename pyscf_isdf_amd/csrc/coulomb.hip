@@ -1,0 +1,149 @@
+// S4+S5: FFT-based Coulomb convolution of the interpolation vectors and W = (vol/G) V Theta^T.
+//
+// Per batch of rows: batched real-to-complex 3-D FFT (hipFFT D2Z) -> multiply the half spectrum by
+// coulG/G (fused scaling: the reference's ifft carries the 1/G, pyscf/pbc/tools/pbc.py:182-211) ->
+// complex-to-real inverse (Z2D) -> contraction with Theta on the matrix cores (gemm_nt_f64).
+// coulG = 4 pi / |G|^2, G = 0 -> 0 (pbc.py:352-356); G vectors in fftfreq order (cell.py:552-587).
+// The table is symmetrised (see coulG_half_kernel) so that the real-to-complex / complex-to-real pair
+// reproduces the reference's complex transform + .real exactly, also on even, non-orthogonal meshes.
+#include "common.h"
+
+namespace {
+
+// |G|^2 of mesh index (ix,iy,iz) with numpy.fft.fftfreq(n, 1/n) frequencies: 0..(n-1)/2, -(n/2)..-1
+struct Recip { double b[9]; };
+__device__ inline double g2_of(int ix, int iy, int iz, int n0, int n1, int n2, const Recip& r) {
+  const double fx = (ix < (n0 + 1) / 2) ? ix : ix - n0;
+  const double fy = (iy < (n1 + 1) / 2) ? iy : iy - n1;
+  const double fz = (iz < (n2 + 1) / 2) ? iz : iz - n2;
+  const double gx = fx * r.b[0] + fy * r.b[3] + fz * r.b[6];
+  const double gy = fx * r.b[1] + fy * r.b[4] + fz * r.b[7];
+  const double gz = fx * r.b[2] + fy * r.b[5] + fz * r.b[8];
+  return gx * gx + gy * gy + gz * gz;
+}
+
+// Half-spectrum table (n0, n1, n2/2+1) of the kernel the reference effectively applies:
+// Re[ifft(c * fft(rho))] for real rho equals ifft(c_sym * fft(rho)) with
+// c_sym(G) = (c(idx) + c(mirror idx)) / 2.  On even meshes the Nyquist index keeps frequency -n/2
+// in both idx and its mirror, so c is not inversion symmetric there for non-orthogonal lattices;
+// symmetrising makes the real-to-complex / complex-to-real pair reproduce the reference exactly.
+__global__ void coulG_half_kernel(double* __restrict__ out, int n0, int n1, int n2, Recip r,
+                                  double scale) {
+  const int n2h = n2 / 2 + 1;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tot = (int64_t)n0 * n1 * n2h;
+  if (idx >= tot) return;
+  const int iz = (int)(idx % n2h);
+  const int iy = (int)((idx / n2h) % n1);
+  const int ix = (int)(idx / ((int64_t)n2h * n1));
+  if (ix == 0 && iy == 0 && iz == 0) { out[idx] = 0.0; return; }
+  const double fourpi = 4.0 * 3.14159265358979323846;
+  const double c1 = fourpi / g2_of(ix, iy, iz, n0, n1, n2, r);
+  const double c2 = fourpi / g2_of((n0 - ix) % n0, (n1 - iy) % n1, (n2 - iz) % n2, n0, n1, n2, r);
+  out[idx] = scale * 0.5 * (c1 + c2);
+}
+
+__global__ void mul_half_kernel(double2* __restrict__ z, const double* __restrict__ cg, int64_t gc,
+                                int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const double c = cg[i % gc];
+    double2 v = z[i];
+    v.x *= c;
+    v.y *= c;
+    z[i] = v;
+  }
+}
+
+}  // namespace
+
+// Build (or fetch) the scaled half-spectrum Coulomb table for this mesh/lattice.
+static int get_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9], double extra_scale,
+                          double** out) {
+  const int64_t gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
+  const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  double* cg = (double*)isdf_ws(h, "coulG_half", sizeof(double) * gc);
+  if (!cg) return ISDF_ERR_HIP;
+  // b = 2 pi inv(a^T): rows b_i (pyscf/pbc/gto/cell.py:1571-1591)
+  const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) +
+                     a[2] * (a[3] * a[7] - a[4] * a[6]);
+  if (det == 0.0) return isdf_fail(h, ISDF_ERR_ARG, "singular lattice");
+  const double tp = 2.0 * 3.14159265358979323846 / det;
+  // b_0 = 2pi (a1 x a2)/det, b_1 = 2pi (a2 x a0)/det, b_2 = 2pi (a0 x a1)/det
+  const double b[9] = {tp * (a[4] * a[8] - a[5] * a[7]), tp * (a[5] * a[6] - a[3] * a[8]), tp * (a[3] * a[7] - a[4] * a[6]),
+                       tp * (a[7] * a[2] - a[8] * a[1]), tp * (a[8] * a[0] - a[6] * a[2]), tp * (a[6] * a[1] - a[7] * a[0]),
+                       tp * (a[1] * a[5] - a[2] * a[4]), tp * (a[2] * a[3] - a[0] * a[5]), tp * (a[0] * a[4] - a[1] * a[3])};
+  Recip rr;
+  for (int i = 0; i < 9; ++i) rr.b[i] = b[i];
+  hipLaunchKernelGGL(coulG_half_kernel, dim3((unsigned)cdiv(gc, 256)), dim3(256), 0, h->stream, cg, mesh[0],
+                     mesh[1], mesh[2], rr, extra_scale / (double)G);
+  KERNEL_CHECK(h);
+  *out = cg;
+  return ISDF_OK;
+}
+
+// In-place Coulomb convolution of nb real fields (rows of length G, contiguous): the FFT buffer
+// `zbuf` must hold nb * gc complex numbers.
+static int convolve_rows(isdf_handle h, const double* d_in, double* d_out, int nb, const int32_t mesh[3],
+                         const double* cg, double2* zbuf) {
+  const int64_t gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
+  FftPlan* plan = nullptr;
+  int rc = isdf_get_plan(h, mesh, nb, &plan);
+  if (rc) return rc;
+  FFT_TRY(h, hipfftExecD2Z(plan->fwd, (hipfftDoubleReal*)d_in, (hipfftDoubleComplex*)zbuf));
+  const int64_t total = gc * nb;
+  const unsigned nblocks = (unsigned)std::min<int64_t>(cdiv(total, 256), (int64_t)h->num_cu * 16);
+  hipLaunchKernelGGL(mul_half_kernel, dim3(nblocks), dim3(256), 0, h->stream, zbuf, cg, gc, total);
+  KERNEL_CHECK(h);
+  FFT_TRY(h, hipfftExecZ2D(plan->bwd, (hipfftDoubleComplex*)zbuf, (hipfftDoubleReal*)d_out));
+  return ISDF_OK;
+}
+
+extern "C" int isdf_coulomb_W(isdf_handle h, const double* d_theta, int P, int64_t ldt,
+                              const int32_t mesh[3], const double a[9], int row0, int nrows,
+                              int batch, double* d_W, int64_t ldw) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_theta && mesh && a && d_W && P > 0 && batch > 0 && ldw >= P);
+  ARG_CHECK(h, row0 >= 0 && nrows >= 0 && row0 + nrows <= P);
+  const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  const int64_t gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
+  ARG_CHECK(h, ldt == G);   // FFT batches read the rows in place
+  if (nrows == 0) return ISDF_OK;
+  if (batch > nrows) batch = nrows;
+  double* cg = nullptr;
+  int rc = get_coulG_half(h, mesh, a, 1.0, &cg);
+  if (rc) return rc;
+  double* V = (double*)isdf_ws(h, "coul_V", sizeof(double) * (size_t)batch * G);
+  double2* Z = (double2*)isdf_ws(h, "coul_Z", sizeof(double2) * (size_t)batch * gc);
+  if (!V || !Z) return ISDF_ERR_HIP;
+  const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) +
+                     a[2] * (a[3] * a[7] - a[4] * a[6]);
+  const double w = fabs(det) / (double)G;
+  for (int r = row0; r < row0 + nrows; r += batch) {
+    const int nb = std::min(batch, row0 + nrows - r);
+    rc = convolve_rows(h, d_theta + (int64_t)r * ldt, V, nb, mesh, cg, Z);
+    if (rc) return rc;
+    // W[r:r+nb, :] = w * V (nb x G) * Theta^T (G x P)
+    rc = gemm_nt_f64(h, nb, P, G, w, V, G, d_theta, ldt, 0.0, d_W + (int64_t)r * ldw, ldw);
+    if (rc) return rc;
+  }
+  return ISDF_OK;
+}
+
+extern "C" int isdf_coulomb_potential(isdf_handle h, double* d_rho, int nset, int64_t ldrho,
+                                      const int32_t mesh[3], const double a[9]) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_rho && mesh && a && nset > 0);
+  const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  const int64_t gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
+  ARG_CHECK(h, ldrho == G);
+  const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) +
+                     a[2] * (a[3] * a[7] - a[4] * a[6]);
+  double* cg = nullptr;
+  int rc = get_coulG_half(h, mesh, a, fabs(det) / (double)G, &cg);   // weight vol/G folded in
+  if (rc) return rc;
+  double2* Z = (double2*)isdf_ws(h, "coul_Z", sizeof(double2) * (size_t)nset * gc);
+  if (!Z) return ISDF_ERR_HIP;
+  return convolve_rows(h, d_rho, d_rho, nset, mesh, cg, Z);
+}

@@ -1,0 +1,251 @@
+// S1: periodic AO collocation on gfx950 (Γ point, real spherical GTOs, l <= 2).
+//
+// One workgroup = 256 consecutive grid points x one atom.  The workgroup first culls the lattice
+// translations against the bounding box of its points (LDS list), then every lane walks only the
+// surviving images for each shell of the atom, accumulating the shell's AO values in registers,
+// and writes them AO-major so that the 64 lanes of a wave store 512 contiguous bytes per AO row.
+// Arithmetic follows pyscf/lib/gto/deriv1.c:31-58 (fac * sum_p c_p exp(-a_p r^2)) and :71-165
+// (Cartesian monomials), with libcint's real-spherical d combination; truncation is per point
+// (|r - R - T| < rcut[shell]) — see include/mi355_isdf.h.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int NCMAX = 4;     // contractions per shell kept in registers
+
+struct AtomDev {
+  double x, y, z, rcut_max;
+  int sh0, sh1;
+};
+struct ShellDev {
+  int l, nprim, nctr, pexp, pcoef, ao0;
+  double rcut2;
+};
+
+constexpr double FAC_S = 0.282094791773878143;
+constexpr double FAC_P = 0.488602511902919921;
+constexpr double D_XY = 1.0925484305920792;
+constexpr double D_Z2_ZZ = 0.6307831305050401;
+constexpr double D_Z2_XXYY = 0.31539156525252005;
+constexpr double D_X2Y2 = 0.5462742152960396;
+
+__device__ inline double wave_min(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <int L>
+__device__ inline void shell_eval(const ShellDev sh, const double* __restrict__ env,
+                                  const double* __restrict__ Ls, const int* __restrict__ img_list,
+                                  int nlist, double px, double py, double pz, double ax, double ay,
+                                  double az, bool valid, double* __restrict__ ao, int64_t ld,
+                                  int64_t g) {
+  constexpr int DEG = 2 * L + 1;
+  double acc[NCMAX][DEG];
+#pragma unroll
+  for (int c = 0; c < NCMAX; ++c)
+#pragma unroll
+    for (int m = 0; m < DEG; ++m) acc[c][m] = 0.0;
+  const double fac = (L == 0) ? FAC_S : (L == 1 ? FAC_P : 1.0);
+  const double* __restrict__ es = env + sh.pexp;
+  const double* __restrict__ cs = env + sh.pcoef;
+  for (int i = 0; i < nlist; ++i) {
+    const int iL = img_list[i];
+    const double dx = px - (ax + Ls[3 * iL + 0]);
+    const double dy = py - (ay + Ls[3 * iL + 1]);
+    const double dz = pz - (az + Ls[3 * iL + 2]);
+    const double rr = dx * dx + dy * dy + dz * dz;
+    if (rr < sh.rcut2) {
+      double rad[NCMAX];
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c) rad[c] = 0.0;
+      for (int p = 0; p < sh.nprim; ++p) {
+        const double e = exp(-es[p] * rr) * fac;
+#pragma unroll
+        for (int c = 0; c < NCMAX; ++c)
+          if (c < sh.nctr) rad[c] += cs[c * sh.nprim + p] * e;
+      }
+      double ang[DEG];
+      if (L == 0) {
+        ang[0] = 1.0;
+      } else if (L == 1) {
+        ang[0] = dx; ang[1] = dy; ang[2] = dz;
+      } else {
+        ang[0] = D_XY * dx * dy;
+        ang[1] = D_XY * dy * dz;
+        ang[2] = D_Z2_ZZ * dz * dz - D_Z2_XXYY * (dx * dx + dy * dy);
+        ang[3] = D_XY * dx * dz;
+        ang[4] = D_X2Y2 * (dx * dx - dy * dy);
+      }
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c)
+#pragma unroll
+        for (int m = 0; m < DEG; ++m) acc[c][m] += rad[c] * ang[m];
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c)
+      if (c < sh.nctr) {
+#pragma unroll
+        for (int m = 0; m < DEG; ++m) ao[(int64_t)(sh.ao0 + c * DEG + m) * ld + g] = acc[c][m];
+      }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void eval_ao_kernel(
+    const AtomDev* __restrict__ atoms, const ShellDev* __restrict__ shells,
+    const double* __restrict__ env, const double* __restrict__ Ls, int nimgs,
+    const double* __restrict__ coords, int64_t ngrids, double* __restrict__ ao, int64_t ld) {
+  extern __shared__ int img_list[];      // nimgs ints
+  __shared__ double red[6][TPB / 64];
+  __shared__ int wcnt[TPB / 64];
+  const int tid = threadIdx.x;
+  const int64_t g = (int64_t)blockIdx.x * TPB + tid;
+  const bool valid = g < ngrids;
+  const int64_t gc = valid ? g : (int64_t)blockIdx.x * TPB;   // clamp to the block's first point
+  const double px = coords[gc], py = coords[ngrids + gc], pz = coords[2 * ngrids + gc];
+  const AtomDev at = atoms[blockIdx.y];
+
+  // bounding box of the workgroup's points
+  double lo[3] = {wave_min(px), wave_min(py), wave_min(pz)};
+  double hi[3] = {wave_max(px), wave_max(py), wave_max(pz)};
+  const int w = tid >> 6;
+  if ((tid & 63) == 0) {
+    for (int k = 0; k < 3; ++k) { red[k][w] = lo[k]; red[3 + k][w] = hi[k]; }
+  }
+  __syncthreads();
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = red[k][0]; hi[k] = red[3 + k][0];
+    for (int ww = 1; ww < TPB / 64; ++ww) {
+      lo[k] = fmin(lo[k], red[k][ww]);
+      hi[k] = fmax(hi[k], red[3 + k][ww]);
+    }
+  }
+  // cull images: keep T when dist(R + T, box) < rcut_max (conservative; the exact test is per
+  // point).  Ordered compaction (ballot + prefix) keeps the list in ascending image index, so the
+  // floating-point accumulation order over images is fixed and equals the oracle's.
+  const double rc2 = at.rcut_max * at.rcut_max;
+  const int lane = tid & 63;
+  int nlist = 0;
+  for (int base = 0; base < nimgs; base += TPB) {
+    const int i = base + tid;
+    bool keep = false;
+    if (i < nimgs) {
+      const double c[3] = {at.x + Ls[3 * i], at.y + Ls[3 * i + 1], at.z + Ls[3 * i + 2]};
+      double d2 = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        const double d = fmax(fmax(lo[k] - c[k], c[k] - hi[k]), 0.0);
+        d2 += d * d;
+      }
+      keep = d2 < rc2;
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) wcnt[w] = __popcll(mask);
+    __syncthreads();
+    int off = nlist;
+    for (int ww = 0; ww < w; ++ww) off += wcnt[ww];
+    if (keep) img_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    for (int ww = 0; ww < TPB / 64; ++ww) nlist += wcnt[ww];
+    __syncthreads();
+  }
+
+  for (int s = at.sh0; s < at.sh1; ++s) {
+    const ShellDev sh = shells[s];
+    switch (sh.l) {
+      case 0: shell_eval<0>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, g); break;
+      case 1: shell_eval<1>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, g); break;
+      default: shell_eval<2>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, g); break;
+    }
+  }
+}
+
+__global__ void gather_cols_kernel(const double* __restrict__ src, int64_t ld_src,
+                                   const int64_t* __restrict__ idx, int64_t n,
+                                   double* __restrict__ dst, int64_t ld_dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t row = blockIdx.y;
+  dst[row * ld_dst + i] = src[row * ld_src + idx[i]];
+}
+
+}  // namespace
+
+extern "C" int isdf_eval_ao(isdf_handle h, const int32_t* atm, int natm, const int32_t* bas, int nbas,
+                            const double* env, int nenv, const double* Ls, int nimgs,
+                            const double* rcut, const double* d_coords, int64_t ngrids,
+                            double* d_ao, int64_t ld) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, atm && bas && env && Ls && rcut && d_coords && d_ao);
+  ARG_CHECK(h, natm > 0 && nbas > 0 && nimgs > 0 && ngrids > 0 && ld >= ngrids);
+  ARG_CHECK(h, (size_t)nimgs * sizeof(int) <= 64 * 1024);
+  constexpr int ATM_SLOTS = 6, BAS_SLOTS = 8, PTR_COORD = 1;
+  constexpr int ATOM_OF = 0, ANG_OF = 1, NPRIM_OF = 2, NCTR_OF = 3, PTR_EXP = 5, PTR_COEFF = 6;
+  std::vector<AtomDev> atoms(natm);
+  std::vector<ShellDev> shells(nbas);
+  for (int ia = 0; ia < natm; ++ia) {
+    const double* r = env + atm[ia * ATM_SLOTS + PTR_COORD];
+    atoms[ia] = {r[0], r[1], r[2], 0.0, -1, -1};
+  }
+  int ao0 = 0;
+  for (int ib = 0; ib < nbas; ++ib) {
+    const int32_t* b = bas + ib * BAS_SLOTS;
+    const int ia = b[ATOM_OF];
+    ARG_CHECK(h, ia >= 0 && ia < natm);
+    if (b[ANG_OF] > 2)
+      return isdf_fail(h, ISDF_ERR_ARG, "shell %d has l=%d; only l<=2 is supported", ib, b[ANG_OF]);
+    if (b[NCTR_OF] > NCMAX)
+      return isdf_fail(h, ISDF_ERR_ARG, "shell %d has %d contractions; at most %d supported", ib,
+                       b[NCTR_OF], NCMAX);
+    ARG_CHECK(h, b[PTR_EXP] + b[NPRIM_OF] <= nenv && b[PTR_COEFF] + b[NPRIM_OF] * b[NCTR_OF] <= nenv);
+    shells[ib] = {b[ANG_OF], b[NPRIM_OF], b[NCTR_OF], b[PTR_EXP], b[PTR_COEFF], ao0, rcut[ib] * rcut[ib]};
+    ao0 += (2 * b[ANG_OF] + 1) * b[NCTR_OF];
+    AtomDev& a = atoms[ia];
+    if (a.sh0 < 0) { a.sh0 = ib; a.sh1 = ib + 1; }
+    else {
+      if (a.sh1 != ib) return isdf_fail(h, ISDF_ERR_ARG, "shells of atom %d are not contiguous in bas", ia);
+      a.sh1 = ib + 1;
+    }
+    if (rcut[ib] > a.rcut_max) a.rcut_max = rcut[ib];
+  }
+  for (auto& a : atoms) if (a.sh0 < 0) { a.sh0 = a.sh1 = 0; }
+
+  size_t b_atoms = sizeof(AtomDev) * natm, b_shells = sizeof(ShellDev) * nbas;
+  size_t b_env = sizeof(double) * nenv, b_Ls = sizeof(double) * 3 * nimgs;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  char* tab = (char*)isdf_ws(h, "ao_tables", al(b_atoms) + al(b_shells) + al(b_env) + al(b_Ls));
+  if (!tab) return ISDF_ERR_HIP;
+  AtomDev* d_atoms = (AtomDev*)tab;
+  ShellDev* d_shells = (ShellDev*)(tab + al(b_atoms));
+  double* d_env = (double*)(tab + al(b_atoms) + al(b_shells));
+  double* d_Ls = (double*)(tab + al(b_atoms) + al(b_shells) + al(b_env));
+  HIP_TRY(h, hipMemcpyAsync(d_atoms, atoms.data(), b_atoms, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d_shells, shells.data(), b_shells, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d_env, env, b_env, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d_Ls, Ls, b_Ls, hipMemcpyHostToDevice, h->stream));
+  // host vectors die at return: the copies above are from pageable memory and complete
+  // (staged) before hipMemcpyAsync returns, but be explicit:
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+
+  dim3 grid((unsigned)cdiv(ngrids, TPB), (unsigned)natm);
+  ARG_CHECK(h, natm <= 65535);
+  hipLaunchKernelGGL(eval_ao_kernel, grid, dim3(TPB), (size_t)nimgs * sizeof(int), h->stream,
+                     d_atoms, d_shells, d_env, d_Ls, nimgs, d_coords, ngrids, d_ao, ld);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_gather_cols(isdf_handle h, const double* d_src, int nrow, int64_t ld_src,
+                                const int64_t* d_idx, int64_t n, double* d_dst, int64_t ld_dst) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_src && d_idx && d_dst && nrow > 0 && n > 0 && ld_dst >= n && nrow <= 65535);
+  dim3 grid((unsigned)cdiv(n, 256), (unsigned)nrow);
+  hipLaunchKernelGGL(gather_cols_kernel, grid, dim3(256), 0, h->stream, d_src, ld_src, d_idx, n, d_dst, ld_dst);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}

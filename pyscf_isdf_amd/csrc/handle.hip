@@ -1,0 +1,127 @@
+// Context management for libmi355_isdf.so: stream, rocBLAS handle, hipFFT plan cache, workspace.
+#include "common.h"
+#include <cstdarg>
+
+int isdf_fail(isdf_handle h, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  else fprintf(stderr, "mi355_isdf: %s\n", buf);
+  return code;
+}
+
+void* isdf_ws(isdf_handle h, const char* name, size_t bytes) {
+  auto& slot = h->ws[name];
+  if (slot.second >= bytes && slot.first) return slot.first;
+  if (slot.first) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(slot.first);
+    slot.first = nullptr;
+    slot.second = 0;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+  if (e != hipSuccess) {
+    isdf_fail(h, ISDF_ERR_HIP, "workspace '%s': hipMalloc(%zu) failed: %s", name, bytes,
+              hipGetErrorString(e));
+    return nullptr;
+  }
+  slot.first = p;
+  slot.second = bytes;
+  return p;
+}
+
+int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out) {
+  std::vector<int> key = {mesh[0], mesh[1], mesh[2], batch};
+  auto it = h->plans.find(key);
+  if (it != h->plans.end()) {
+    *out = &it->second;
+    return ISDF_OK;
+  }
+  FftPlan p;
+  int dims[3] = {mesh[0], mesh[1], mesh[2]};
+  int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  int64_t Gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
+  ARG_CHECK(h, G < (int64_t)2147483647);
+  FFT_TRY(h, hipfftPlanMany(&p.fwd, 3, dims, nullptr, 1, (int)G, nullptr, 1, (int)Gc, HIPFFT_D2Z, batch));
+  FFT_TRY(h, hipfftPlanMany(&p.bwd, 3, dims, nullptr, 1, (int)Gc, nullptr, 1, (int)G, HIPFFT_Z2D, batch));
+  FFT_TRY(h, hipfftSetStream(p.fwd, h->stream));
+  FFT_TRY(h, hipfftSetStream(p.bwd, h->stream));
+  auto res = h->plans.emplace(key, p);
+  *out = &res.first->second;
+  return ISDF_OK;
+}
+
+extern "C" {
+
+int isdf_abi_version(void) { return 1; }
+
+int isdf_create(int device_id, isdf_handle* out) {
+  if (!out) return ISDF_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return isdf_fail(nullptr, ISDF_ERR_HIP, "no HIP device visible (%s)", hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev)
+    return isdf_fail(nullptr, ISDF_ERR_ARG, "device %d out of range (%d devices)", device_id, ndev);
+  isdf_ctx* h = new isdf_ctx();
+  h->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess) { delete h; return ISDF_ERR_HIP; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->num_cu = prop.multiProcessorCount;
+  if (rocblas_create_handle(&h->blas) != rocblas_status_success) {
+    delete h;
+    return isdf_fail(nullptr, ISDF_ERR_LIB, "rocblas_create_handle failed");
+  }
+  rocblas_set_pointer_mode(h->blas, rocblas_pointer_mode_host);
+  *out = h;
+  return ISDF_OK;
+}
+
+int isdf_release_workspace(isdf_handle h) {
+  if (!h) return ISDF_ERR_ARG;
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& kv : h->ws)
+    if (kv.second.first) (void)hipFree(kv.second.first);
+  h->ws.clear();
+  for (auto& kv : h->plans) {
+    if (kv.second.fwd) hipfftDestroy(kv.second.fwd);
+    if (kv.second.bwd) hipfftDestroy(kv.second.bwd);
+  }
+  h->plans.clear();
+  return ISDF_OK;
+}
+
+int isdf_destroy(isdf_handle h) {
+  if (!h) return ISDF_OK;
+  isdf_release_workspace(h);
+  if (h->blas) rocblas_destroy_handle(h->blas);
+  delete h;
+  return ISDF_OK;
+}
+
+int isdf_set_stream(isdf_handle h, void* hip_stream) {
+  if (!h) return ISDF_ERR_ARG;
+  h->stream = (hipStream_t)hip_stream;
+  BLAS_TRY(h, rocblas_set_stream(h->blas, h->stream));
+  for (auto& kv : h->plans) {
+    FFT_TRY(h, hipfftSetStream(kv.second.fwd, h->stream));
+    FFT_TRY(h, hipfftSetStream(kv.second.bwd, h->stream));
+  }
+  return ISDF_OK;
+}
+
+const char* isdf_last_error(isdf_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int64_t isdf_workspace_bytes(isdf_handle h) {
+  if (!h) return 0;
+  int64_t s = 0;
+  for (auto& kv : h->ws) s += (int64_t)kv.second.second;
+  return s;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// S6/S7: J (exact, FFTDF formula) and K (from the interpolation factorisation) on the device.
+//   J: rho_g = sum_mn dm_mn ao_mg ao_ng ;  v = (vol/G) ifft(coulG fft rho).real ; vj = ao (v .* ao)^T
+//      (pyscf/pbc/df/fft_jk.py:63-107)
+//   K: vk = aoP^T [ (aoP dm aoP^T) .* W ] aoP                       
+#include "common.h"
+
+namespace {
+
+constexpr int64_t JCHUNK = 32768;   // grid columns per pass (workspace nao * JCHUNK doubles)
+
+// rho[g] = sum_mu T[mu,g] * ao[mu,g]   (T = dm * ao for this chunk)
+__global__ void rho_reduce_kernel(const double* __restrict__ T, int64_t ldT,
+                                  const double* __restrict__ ao, int64_t ld, int nao, int64_t ng,
+                                  double* __restrict__ rho) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  double s = 0.0;
+#pragma unroll 4
+  for (int mu = 0; mu < nao; ++mu) s = fma(T[(int64_t)mu * ldT + g], ao[(int64_t)mu * ld + g], s);
+  rho[g] = s;
+}
+
+// S[mu,g] = ao[mu,g] * v[g]
+__global__ void scale_cols_kernel(const double* __restrict__ ao, int64_t ld, const double* __restrict__ v,
+                                  int64_t ng, double* __restrict__ S, int64_t ldS) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  const int64_t mu = blockIdx.y;
+  S[mu * ldS + g] = ao[mu * ld + g] * v[g];
+}
+
+__global__ void hadamard_kernel(double* __restrict__ M, int64_t ldm, const double* __restrict__ W,
+                                int64_t ldw, int64_t rows, int64_t cols) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (c >= cols) return;
+  M[r * ldm + c] *= W[r * ldw + c];
+}
+
+}  // namespace
+
+extern "C" int isdf_rho(isdf_handle h, const double* d_ao, int nao, int64_t ng, int64_t ld,
+                        const double* d_dm, int nset, double* d_rho, int64_t ldrho) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_ao && d_dm && d_rho && nao > 0 && ng > 0 && ld >= ng && nset > 0 && ldrho >= ng);
+  double* T = (double*)isdf_ws(h, "jk_T", sizeof(double) * (size_t)nao * JCHUNK);
+  if (!T) return ISDF_ERR_HIP;
+  for (int i = 0; i < nset; ++i) {
+    for (int64_t g0 = 0; g0 < ng; g0 += JCHUNK) {
+      const int64_t nc = std::min(JCHUNK, ng - g0);
+      int rc = gemm_rm(h, 'N', 'N', nao, nc, nao, 1.0, d_dm + (int64_t)i * nao * nao, nao, d_ao + g0, ld, 0.0, T, JCHUNK);
+      if (rc) return rc;
+      hipLaunchKernelGGL(rho_reduce_kernel, dim3((unsigned)cdiv(nc, 256)), dim3(256), 0, h->stream, T, JCHUNK,
+                         d_ao + g0, ld, nao, nc, d_rho + (int64_t)i * ldrho + g0);
+      KERNEL_CHECK(h);
+    }
+  }
+  return ISDF_OK;
+}
+
+extern "C" int isdf_vj_from_vR(isdf_handle h, const double* d_ao, int nao, int64_t ng, int64_t ld,
+                               const double* d_vR, int nset, int64_t ldv, double* d_vj) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_ao && d_vR && d_vj && nao > 0 && nao <= 65535 && ng > 0 && ld >= ng && nset > 0 && ldv >= ng);
+  double* S = (double*)isdf_ws(h, "jk_T", sizeof(double) * (size_t)nao * JCHUNK);
+  if (!S) return ISDF_ERR_HIP;
+  for (int i = 0; i < nset; ++i) {
+    double* vj = d_vj + (int64_t)i * nao * nao;
+    for (int64_t g0 = 0; g0 < ng; g0 += JCHUNK) {
+      const int64_t nc = std::min(JCHUNK, ng - g0);
+      hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)cdiv(nc, 256), (unsigned)nao), dim3(256), 0, h->stream,
+                         d_ao + g0, ld, d_vR + (int64_t)i * ldv + g0, nc, S, JCHUNK);
+      KERNEL_CHECK(h);
+      int rc = gemm_nt_f64(h, nao, nao, nc, 1.0, d_ao + g0, ld, S, JCHUNK, g0 == 0 ? 0.0 : 1.0, vj, nao);
+      if (rc) return rc;
+    }
+  }
+  return ISDF_OK;
+}
+
+extern "C" int isdf_get_j(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, int64_t ld,
+                          const int32_t mesh[3], const double a[9], const double* d_dm, int nset,
+                          double* d_vj) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, mesh && ngrids == (int64_t)mesh[0] * mesh[1] * mesh[2]);
+  double* rho = (double*)isdf_ws(h, "jk_rho", sizeof(double) * (size_t)nset * ngrids);
+  if (!rho) return ISDF_ERR_HIP;
+  int rc = isdf_rho(h, d_ao, nao, ngrids, ld, d_dm, nset, rho, ngrids);
+  if (rc) return rc;
+  rc = isdf_coulomb_potential(h, rho, nset, ngrids, mesh, a);
+  if (rc) return rc;
+  return isdf_vj_from_vR(h, d_ao, nao, ngrids, ld, rho, nset, ngrids, d_vj);
+}
+
+extern "C" int isdf_get_k(isdf_handle h, const double* d_aoP, int P, int nao, const double* d_W,
+                          int64_t ldw, int row0, int nrows, const double* d_dm, int nset,
+                          double* d_vk) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_aoP && d_W && d_dm && d_vk && P > 0 && nao > 0 && ldw >= P && nset > 0);
+  ARG_CHECK(h, row0 >= 0 && nrows >= 0 && row0 + nrows <= P);
+  const int RCH = 4096;   // Hadamard rows per pass
+  const int rch = std::min(RCH, std::max(nrows, 1));
+  double* X = (double*)isdf_ws(h, "k_X", sizeof(double) * (size_t)P * nao);        // aoP dm^T... (P, nao)
+  double* M = (double*)isdf_ws(h, "k_M", sizeof(double) * (size_t)rch * P);        // (rows, P)
+  double* Y = (double*)isdf_ws(h, "k_Y", sizeof(double) * (size_t)rch * nao);      // (rows, nao)
+  if (!X || !M || !Y) return ISDF_ERR_HIP;
+  for (int i = 0; i < nset; ++i) {
+    const double* dm = d_dm + (int64_t)i * nao * nao;
+    double* vk = d_vk + (int64_t)i * nao * nao;
+    // X = aoP dm^T  so that  (aoP dm aoP^T)[p,q] = sum_n (aoP dm)[p,n] aoP[q,n]; we need aoP dm:
+    int rc = gemm_rm(h, 'N', 'N', P, nao, nao, 1.0, d_aoP, nao, dm, nao, 0.0, X, nao);
+    if (rc) return rc;
+    if (nrows == 0) {
+      HIP_TRY(h, hipMemsetAsync(vk, 0, sizeof(double) * (size_t)nao * nao, h->stream));
+      continue;
+    }
+    for (int r = row0; r < row0 + nrows; r += rch) {
+      const int nr = std::min(rch, row0 + nrows - r);
+      // M = X[r:r+nr] aoP^T   (nr x P)
+      rc = gemm_rm(h, 'N', 'T', nr, P, nao, 1.0, X + (int64_t)r * nao, nao, d_aoP, nao, 0.0, M, P);
+      if (rc) return rc;
+      hipLaunchKernelGGL(hadamard_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)nr), dim3(256), 0, h->stream, M,
+                         (int64_t)P, d_W + (int64_t)r * ldw, ldw, (int64_t)nr, (int64_t)P);
+      KERNEL_CHECK(h);
+      // Y = M aoP (nr x nao);  vk += aoP[r:r+nr]^T Y
+      rc = gemm_rm(h, 'N', 'N', nr, nao, P, 1.0, M, P, d_aoP, nao, 0.0, Y, nao);
+      if (rc) return rc;
+      rc = gemm_rm(h, 'T', 'N', nao, nao, nr, 1.0, d_aoP + (int64_t)r * nao, nao, Y, nao, r == row0 ? 0.0 : 1.0, vk, nao);
+      if (rc) return rc;
+    }
+  }
+  return ISDF_OK;
+}

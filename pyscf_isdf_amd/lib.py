@@ -1,0 +1,98 @@
+"""ctypes binding of libmi355_isdf.so (include/mi355_isdf.h).
+
+Mirrors the reference's loader idiom (pyscf/lib/misc.py:91-104 ``load_library`` + raw
+``ctypes.c_void_p`` pointers, e.g. pyscf/pbc/gto/eval_gto.py:140-151).  There is no CPU fallback:
+if the shared library is missing or no GPU is visible, ``load()`` / ``Handle()`` raise.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
+ABI_VERSION = 1
+
+_lib = None
+
+c_int, c_i64, c_dbl, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/mi355_isdf.h
+SIGNATURES = {
+    'isdf_abi_version': (c_int, []),
+    'isdf_create': (c_int, [c_int, ctypes.POINTER(c_vp)]),
+    'isdf_destroy': (c_int, [c_vp]),
+    'isdf_set_stream': (c_int, [c_vp, c_vp]),
+    'isdf_last_error': (ctypes.c_char_p, [c_vp]),
+    'isdf_workspace_bytes': (c_i64, [c_vp]),
+    'isdf_release_workspace': (c_int, [c_vp]),
+    'isdf_eval_ao': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_i64]),
+    'isdf_gather_cols': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_i64]),
+    'isdf_select_ip': (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_i64, c_vp, c_vp]),
+    'isdf_fit_from_chol': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp]),
+    'isdf_fit_global': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_i64, c_vp]),
+    'isdf_coulomb_W': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64]),
+    'isdf_get_j': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_vp]),
+    'isdf_rho': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_i64]),
+    'isdf_coulomb_potential': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),
+    'isdf_vj_from_vR': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_i64, c_vp]),
+    'isdf_get_k': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]),
+}
+
+
+def load():
+    """Load the shared library (once).  torch is imported first so that the HIP runtime, rocBLAS,
+    rocSOLVER and hipFFT resolve to the single copy the process already holds."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'libmi355_isdf.so not found at %s — build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` or `make -C pyscf_isdf_amd/csrc`.  There is no CPU fallback.' % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (side effect: loads libamdhip64 & co.)
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.isdf_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError('libmi355_isdf.so ABI version %d != binding version %d' % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+class IsdfError(RuntimeError):
+    pass
+
+
+class Handle:
+    """Owns one isdf_handle (one GPU)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = c_vp()
+        rc = self.lib.isdf_create(int(device), ctypes.byref(h))
+        if rc != 0 or not h.value:
+            raise IsdfError('isdf_create(device=%d) failed with status %d (no MI355X visible?)' % (device, rc))
+        self.h = h
+        self.device = device
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self.h, *args)
+        if rc != 0:
+            msg = self.lib.isdf_last_error(self.h)
+            raise IsdfError('%s failed (status %d): %s' % (name, rc, msg.decode() if msg else ''))
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h.value:
+            self.lib.isdf_destroy(self.h)
+            self.h = c_vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,262 @@
+"""GPU parity tests: every stage of libmi355_isdf.so (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Tolerances are stated per test; FP64 throughout."""
+import numpy as np
+import pytest
+import cells
+from pyscf_isdf_amd import gto
+from oracle import ao as oao, isdf as oisdf, fftdf, pbc_tools as tools
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def be():
+    from pyscf_isdf_amd.backend import HipBackend
+    return HipBackend(0)
+
+
+def _oracle_ao(cell, coords=None):
+    if coords is None:
+        coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    ao = oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, rule='point')
+    return np.ascontiguousarray(ao.T), coords, Ls, rcut
+
+
+def _gpu_ao(be, cell, coords, Ls, rcut):
+    G = len(coords)
+    ao = be.empty((cell.nao_nr(), G))
+    be.eval_ao(cell._atm, cell._bas, cell._env, Ls, rcut, be.to_device(np.ascontiguousarray(coords.T)), ao)
+    return ao
+
+
+@pytest.mark.parametrize('mk', [cells.cell_he_c, cells.cell_he2_triclinic, cells.cell_c2_ccpvdz,
+                                lambda: cells.cell_diamond_prim('gth-dzvp', (12, 12, 12))])
+def test_eval_ao(be, mk):
+    """S1: collocation (s, p, d shells; cubic, triclinic and fcc lattices).  Tolerance 1e-12 absolute
+    (values are O(1); the only difference allowed is the last-ulp of exp)."""
+    cell = mk()
+    ref, coords, Ls, rcut = _oracle_ao(cell)
+    got = be.to_host(_gpu_ao(be, cell, coords, Ls, rcut))
+    assert got.shape == ref.shape
+    assert abs(got - ref).max() < 1e-12
+
+
+def test_eval_ao_ragged_tail_and_permuted_coords(be):
+    """Grid size not a multiple of the workgroup (9261 = 36*256 + 45) and a shuffled point order."""
+    cell = cells.cell_he_c()
+    coords = cell.get_uniform_grids()
+    perm = np.random.default_rng(3).permutation(len(coords))[:5000]
+    ref, c2, Ls, rcut = _oracle_ao(cell, coords[perm])
+    got = be.to_host(_gpu_ao(be, cell, c2, Ls, rcut))
+    assert abs(got - ref).max() < 1e-12
+
+
+def test_gather_cols(be):
+    rng = np.random.default_rng(0)
+    src = rng.standard_normal((7, 1000))
+    idx = rng.permutation(1000)[:333].astype(np.int64)
+    dst = be.empty((7, 333))
+    be.gather_cols(be.to_device(src), be.to_device(idx), dst)
+    assert np.array_equal(be.to_host(dst), src[:, idx])
+
+
+def _select_gpu(be, aoT, blk_off, nip, tie_rtol=1e-10, tol=-1.0):
+    import torch
+    kmax = int(max(nip))
+    m = aoT.shape[1]
+    L = be.zeros((kmax, m))
+    piv = be.empty((len(nip), kmax), dtype=torch.int64)
+    rank = be.select_ip(be.to_device(aoT), blk_off, nip, tol, tie_rtol, L, piv)
+    return rank, be.to_host(piv), be.to_host(L), L, piv
+
+
+def test_select_ip_global_matches_oracle(be):
+    """S2 on an asymmetric cell: identical pivot list; Cholesky rows within 1e-9 relative to max|L|."""
+    cell = cells.cell_he_c()
+    aoT = _oracle_ao(cell)[0]
+    k = 18
+    piv_ref, L_ref = oisdf.select_ip(aoT, k)
+    rank, piv, L, _, _ = _select_gpu(be, aoT, [0, aoT.shape[1]], [k])
+    assert rank[0] == len(piv_ref)
+    assert np.array_equal(piv[0, :rank[0]], piv_ref)
+    assert abs(L[:rank[0]] - L_ref).max() < 1e-9 * abs(L_ref).max()
+
+
+def test_select_ip_rank_deficient_stops(be):
+    """6 AOs -> 21 independent pair products: asking for 40 points must stop at rank 21 like
+    pivoted_cholesky_python's tolerance rule (scipy_helper.py:88-99)."""
+    cell = cells.cell_he_c()
+    aoT = _oracle_ao(cell)[0]
+    piv_ref, L_ref = oisdf.select_ip(aoT, 40)
+    rank, piv, L, _, _ = _select_gpu(be, aoT, [0, aoT.shape[1]], [40])
+    assert len(piv_ref) == 21 and rank[0] == 21
+    assert np.array_equal(piv[0, :21], piv_ref)
+
+
+def test_select_ip_blocks_match_oracle(be):
+    """Batched blocks of unequal size (incl. one smaller than a workgroup and an empty request)."""
+    rng = np.random.default_rng(5)
+    nao = 9
+    sizes = [700, 130, 1025, 64]
+    nip = [25, 10, 0, 30]
+    blk_off = np.append(0, np.cumsum(sizes))
+    aoT = rng.standard_normal((nao, blk_off[-1])) * np.exp(-rng.random(blk_off[-1]) * 3)
+    rank, piv, L, _, _ = _select_gpu(be, aoT, blk_off, nip)
+    for b in range(4):
+        pr, Lr = oisdf.select_ip(aoT[:, blk_off[b]:blk_off[b + 1]], nip[b]) if nip[b] else (np.zeros(0, int), None)
+        assert rank[b] == len(pr)
+        assert np.array_equal(piv[b, :rank[b]], pr)
+        if nip[b]:
+            got = L[:rank[b], blk_off[b]:blk_off[b + 1]]
+            assert abs(got - Lr).max() < 1e-9 * abs(Lr).max()
+
+
+def test_select_ip_tie_rule_lowest_index(be):
+    """Exactly duplicated columns tie to the last bit: the lowest index must win on every step."""
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal((5, 300))
+    aoT = np.concatenate([base, base, base], axis=1)        # columns i, i+300, i+600 identical
+    rank, piv, L, _, _ = _select_gpu(be, aoT, [0, 900], [12])
+    assert rank[0] == 12 and (piv[0, :12] < 300).all()
+    piv_ref, _ = oisdf.select_ip(aoT, 12)
+    assert np.array_equal(piv[0, :12], piv_ref)
+
+
+def test_fit_from_chol(be):
+    """S3a: Theta = T^-1 L equals the normal-equation fit and is the identity on the points."""
+    cell = cells.cell_he_c()
+    aoT = _oracle_ao(cell)[0]
+    k = 15
+    rank, piv, L, dL, dpiv = _select_gpu(be, aoT, [0, aoT.shape[1]], [k])
+    be.fit_from_chol(dL, k, aoT.shape[1], dpiv[0].contiguous())
+    theta = be.to_host(dL)
+    ref = oisdf.fit_theta(*oisdf.select_ip(aoT, k)[::-1])
+    assert abs(theta - ref).max() < 1e-9 * abs(ref).max()
+    assert abs(theta[:, piv[0]] - np.eye(k)).max() < 1e-10
+    ne = oisdf.fit_theta_normal_equations(aoT, piv[0])
+    assert abs(theta - ne).max() < 1e-6 * abs(ne).max()
+
+
+def test_fit_global(be):
+    """S3b: Cholesky fit for an arbitrary point set vs numpy lstsq (conditioning-limited: 1e-7 rel)."""
+    cell = cells.cell_he_c()
+    aoT = _oracle_ao(cell)[0]
+    G = aoT.shape[1]
+    ip = oisdf.select_ip(aoT, 14)[0]
+    ip = np.sort(ip)                                         # arbitrary order
+    theta = be.empty((14, G))
+    aoP = be.empty((14, aoT.shape[0]))
+    be.fit_global(be.to_device(aoT), G, be.to_device(ip), theta, aoP)
+    assert np.array_equal(be.to_host(aoP), aoT[:, ip].T)
+    ref = oisdf.fit_theta_normal_equations(aoT, ip)
+    assert abs(be.to_host(theta) - ref).max() < 1e-7 * abs(ref).max()
+
+
+@pytest.mark.parametrize('mk', [cells.cell_he_c, cells.cell_he2_triclinic,
+                                lambda: cells.cell_diamond_prim('gth-szv', (12, 10, 8))])
+def test_coulomb_W(be, mk):
+    """S4+S5 on odd meshes, a triclinic lattice and an even non-orthogonal mesh (Nyquist planes):
+    W vs the oracle's complex-FFT construction, 1e-10 relative to max|W|."""
+    cell = mk()
+    aoT = _oracle_ao(cell)[0]
+    G = aoT.shape[1]
+    k = min(12, cell.nao_nr() * 2)
+    piv, L = oisdf.select_ip(aoT, k)
+    theta = oisdf.fit_theta(L, piv)
+    a = cell.lattice_vectors()
+    ref = oisdf.build_W(theta, a, cell.mesh)
+    k = len(piv)
+    W = be.empty((k, k))
+    for batch in (5, k):                                     # ragged last batch and single batch
+        W.zero_()
+        be.coulomb_W(be.to_device(theta), cell.mesh, a, 0, k, batch, W)
+        assert abs(be.to_host(W) - ref).max() < 1e-10 * abs(ref).max()
+    # row range (multi-GPU sharding of P)
+    W.zero_()
+    be.coulomb_W(be.to_device(theta), cell.mesh, a, 3, 4, 3, W)
+    got = be.to_host(W)
+    assert abs(got[3:7] - ref[3:7]).max() < 1e-10 * abs(ref).max() and abs(got[:3]).max() == 0 and abs(got[7:]).max() == 0
+
+
+def test_get_j_matches_fftdf_pin(be):
+    """S6 vs the oracle AND the reference's known-answer fp(vj) (test_fft.py:643-644)."""
+    cell = cells.cell_he_c()
+    aoT = _oracle_ao(cell)[0]
+    G = aoT.shape[1]
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(1)
+    dms = np.stack([np.eye(nao), rng.standard_normal((nao, nao))])
+    dms[1] = dms[1] + dms[1].T
+    vj = be.empty((2, nao, nao))
+    be.get_j(be.to_device(aoT), G, cell.mesh, cell.lattice_vectors(), be.to_device(dms), vj)
+    got = be.to_host(vj)
+    ref = oisdf.get_j(aoT, dms, cell.lattice_vectors(), cell.mesh)
+    assert abs(got - ref).max() < 1e-11
+    assert abs(tools.fp(got[0]) - 3.7955873127283377) < 1e-8
+
+
+def test_get_k(be):
+    """S7 vs the oracle on random W (symmetric) and dm; also a row-sharded partial sum."""
+    rng = np.random.default_rng(2)
+    P, nao = 300, 17
+    aoP = rng.standard_normal((P, nao))
+    W = rng.standard_normal((P, P)); W = W + W.T
+    dms = rng.standard_normal((2, nao, nao))
+    vk = be.empty((2, nao, nao))
+    be.get_k(be.to_device(aoP), be.to_device(W), 0, P, be.to_device(dms), vk)
+    ref = oisdf.get_k(aoP, W, dms)
+    assert abs(be.to_host(vk) - ref).max() < 1e-10 * abs(ref).max()
+    part = np.zeros_like(ref)
+    for r0, nr in ((0, 100), (100, 77), (177, 123)):
+        be.get_k(be.to_device(aoP), be.to_device(W), r0, nr, be.to_device(dms), vk)
+        part += be.to_host(vk)
+    assert abs(part - ref).max() < 1e-10 * abs(ref).max()
+
+
+@pytest.mark.parametrize('select', ['global', 'local'])
+def test_isdf_object_end_to_end(select):
+    """The drop-in object: build + get_jk on the reference's He/C fixture.  At full rank (21 pair
+    products) ISDF is exact, so K must reproduce the reference's fp(vk) pin (test_fft.py:645)."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    nao = cell.nao_nr()
+    df = ISDF(cell, c_isdf=4, select=select)
+    dm = np.eye(nao)
+    vj, vk = df.get_jk(dm, exxdiv=None)
+    assert vj.shape == (nao, nao) and vj.dtype == np.float64 and vk.dtype == np.float64
+    assert abs(tools.fp(vj) - 3.7955873127283377) < 1e-8
+    if select == 'global':
+        assert len(df.ip) == 21
+        assert abs(tools.fp(vk) - 4.290076429522121) < 1e-7
+    # shapes: (nset, nao, nao) in -> same out; with_k=False -> None
+    vj2, vk2 = df.get_jk(np.stack([dm, 2 * dm]), with_k=False)
+    assert vk2 is None and vj2.shape == (2, nao, nao) and abs(vj2[1] - 2 * vj).max() < 1e-10
+
+
+def test_isdf_object_vs_oracle_pipeline_diamond():
+    """Symmetric crystal (diamond, gth-dzvp, d shells).  The oracle pipeline is fed the GPU's AO
+    values so that both sides see bit-identical inputs; pivots must then agree and J/K energies
+    agree to 1e-9 Eh (target in BASELINE.json: 1e-6 Eh)."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_diamond_prim('gth-dzvp', (12, 12, 12))
+    nao = cell.nao_nr()
+    df = ISDF(cell, c_isdf=6, select='global')
+    df.build()
+    aoT = df.backend.to_host(df.ao)
+    ref_ao = _oracle_ao(cell)[0]
+    assert abs(aoT - ref_ao).max() < 1e-12
+    a = cell.lattice_vectors()
+    ref = oisdf.build_global(aoT, a, cell.mesh, 6 * nao)
+    assert np.array_equal(ref['ip'], df.ip)
+    rng = np.random.default_rng(20240203)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao); occ[:cell.nelectron // 2] = 2
+    dm = (c * occ).dot(c.T)
+    vj, vk = df.get_jk(dm)
+    vj_ref = oisdf.get_j(aoT, dm, a, cell.mesh)
+    vk_ref = oisdf.get_k(ref['aoP'], ref['W'], dm)
+    assert abs(np.einsum('ij,ji', vj - vj_ref, dm)) / 2 < 1e-9
+    assert abs(np.einsum('ij,ji', vk - vk_ref, dm)) / 4 < 1e-9
+    assert abs(vj - vj_ref).max() < 1e-9 and abs(vk - vk_ref).max() < 1e-8
