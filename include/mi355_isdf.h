@@ -91,11 +91,24 @@ int isdf_fit_from_chol(isdf_handle h, double* d_L, int k, int64_t m, int64_t ldL
                        const int64_t* d_piv);
 
 /* S3b. Global least-squares fit for an arbitrary interpolation-point set d_ip (grid indices):
- * Theta = [(aoP aoP^T)^2]^-1 (aoP ao)^2 by Cholesky.  Also returns
- * d_aoP (P, nao) = phi at the interpolation points.  Returns ISDF_ERR_NUM if A_PP is not
- * numerically positive definite. */
+ * Theta = [(aoP aoP^T)^2 + reg*max(diag)*I]^-1 (aoP ao)^2 by Cholesky.
+ * reg_rel >= 0 is the requested relative diagonal shift; if the factorisation breaks down the shift
+ * is raised (1e-14, then x100 per retry, 4 retries) and the value finally used is returned in
+ * *reg_used (host; may be NULL).  ISDF_ERR_NUM if it still fails.
+ *   isdf_fit_prepare: d_aoP (P, nao) = phi at the points, d_chol (P, P) = Cholesky factor.
+ *                     Synchronises the stream (breakdown is reported to the host).
+ *   isdf_fit_apply:   Theta columns for any slice of the grid: d_ao points at the slice's first
+ *                     column (nao, ld), ng columns; d_theta likewise (P, ldt).  Grid slices are
+ *                     independent, which is what grid-sharded multi-GPU runs use.
+ *   isdf_fit_global:  both, on the whole grid, factor kept in the context workspace. */
+int isdf_fit_prepare(isdf_handle h, const double* d_ao, int nao, int64_t ld,
+                     const int64_t* d_ip, int P, double reg_rel, double* d_aoP, double* d_chol,
+                     double* reg_used);
+int isdf_fit_apply(isdf_handle h, const double* d_chol, const double* d_aoP, int P, int nao,
+                   const double* d_ao, int64_t ng, int64_t ld, double* d_theta, int64_t ldt);
 int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, int64_t ld,
-                    const int64_t* d_ip, int P, double* d_theta, int64_t ldt, double* d_aoP);
+                    const int64_t* d_ip, int P, double reg_rel, double* d_theta, int64_t ldt,
+                    double* d_aoP, double* reg_used);
 
 /* S4+S5. Coulomb convolution and W:  for rows p in [row0, row0+nrows):
  *   V_p = ifft( coulG * fft(theta_p) ).real,   W[p, q] = (vol/G) * sum_g V_p[g] theta_q[g],  q < P.

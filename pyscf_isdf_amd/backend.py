@@ -93,11 +93,28 @@ class HipBackend:
         self._stream()
         self.handle.call('isdf_fit_from_chol', self._p(L), int(k), int(m), L.stride(0), self._p(piv))
 
-    def fit_global(self, ao, ngrids, ip, theta, aoP):
+    def fit_prepare(self, ao, ip, reg_rel, aoP, chol):
+        """Returns the diagonal shift actually used."""
+        self._stream()
+        assert ip.dtype == torch.int64 and aoP.is_contiguous() and chol.is_contiguous()
+        reg = ctypes.c_double(0.0)
+        self.handle.call('isdf_fit_prepare', self._p(ao), ao.shape[0], ao.stride(0), self._p(ip), ip.numel(),
+                         float(reg_rel), self._p(aoP), self._p(chol), ctypes.byref(reg))
+        return reg.value
+
+    def fit_apply(self, chol, aoP, ao, ng, theta):
+        """theta (P, >=ng) <- fit on the ng grid columns ``ao`` (nao, >=ng) starts at."""
+        self._stream()
+        self.handle.call('isdf_fit_apply', self._p(chol), self._p(aoP), aoP.shape[0], aoP.shape[1], self._p(ao),
+                         int(ng), ao.stride(0), self._p(theta), theta.stride(0))
+
+    def fit_global(self, ao, ngrids, ip, reg_rel, theta, aoP):
         self._stream()
         assert ip.dtype == torch.int64 and aoP.is_contiguous()
+        reg = ctypes.c_double(0.0)
         self.handle.call('isdf_fit_global', self._p(ao), ao.shape[0], int(ngrids), ao.stride(0), self._p(ip),
-                         ip.numel(), self._p(theta), theta.stride(0), self._p(aoP))
+                         ip.numel(), float(reg_rel), self._p(theta), theta.stride(0), self._p(aoP), ctypes.byref(reg))
+        return reg.value
 
     def coulomb_W(self, theta, mesh, a, row0, nrows, batch, W):
         self._stream()

@@ -54,50 +54,96 @@ extern "C" int isdf_fit_from_chol(isdf_handle h, double* d_L, int k, int64_t m, 
   return ISDF_OK;
 }
 
-extern "C" int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, int64_t ld,
-                               const int64_t* d_ip, int P, double* d_theta, int64_t ldt,
-                               double* d_aoP) {
+namespace {
+__global__ void add_diag_kernel(double* __restrict__ A, int n, const double* __restrict__ maxdiag, double rel) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[(int64_t)i * n + i] += rel * maxdiag[0];
+}
+__global__ void max_diag_kernel(const double* __restrict__ A, int n, double* __restrict__ out) {
+  // single workgroup
+  __shared__ double red[256];
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, A[(int64_t)i * n + i]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+}  // namespace
+
+extern "C" int isdf_fit_prepare(isdf_handle h, const double* d_ao, int nao, int64_t ld,
+                                const int64_t* d_ip, int P, double reg_rel, double* d_aoP,
+                                double* d_chol, double* reg_used) {
   if (!h) return ISDF_ERR_ARG;
-  ARG_CHECK(h, d_ao && d_ip && d_theta && d_aoP && nao > 0 && P > 0 && ngrids >= P && ld >= ngrids && ldt >= ngrids);
-  ARG_CHECK(h, nao <= 65535 && P <= 65535 && ldt < (int64_t)2147483647);
-  // aoP (P, nao)
+  ARG_CHECK(h, d_ao && d_ip && d_aoP && d_chol && nao > 0 && P > 0 && reg_rel >= 0.0);
+  ARG_CHECK(h, nao <= 65535 && P <= 65535);
   hipLaunchKernelGGL(transpose_gather_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)nao), dim3(256), 0,
                      h->stream, d_ao, ld, d_ip, P, nao, d_aoP);
   KERNEL_CHECK(h);
-  // A_PP = (aoP aoP^T)^2, Cholesky (lower in row-major == upper in column-major view; we just
-  // hand rocSOLVER the symmetric matrix and ask for the factor it stores in the "upper" triangle
-  // of the column-major view, i.e. row-major lower:  A = Lr Lr^T with Lr row-major lower.)
-  double* A = (double*)isdf_ws(h, "fit_APP", sizeof(double) * (size_t)P * P);
   int* info = (int*)isdf_ws(h, "fit_info", 256);
-  if (!A || !info) return ISDF_ERR_HIP;
-  int rc = gemm_rm(h, 'N', 'T', P, P, nao, 1.0, d_aoP, nao, d_aoP, nao, 0.0, A, P);
+  if (!info) return ISDF_ERR_HIP;
+  double* maxdiag = (double*)(info + 16);
+  double reg = reg_rel;
+  for (int attempt = 0; attempt < 5; ++attempt) {
+    // A_PP = (aoP aoP^T)^2 (+ reg * max diag * I), Cholesky A = U^T U in the column-major view
+    int rc = gemm_rm(h, 'N', 'T', P, P, nao, 1.0, d_aoP, nao, d_aoP, nao, 0.0, d_chol, P);
+    if (rc) return rc;
+    hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)P), dim3(256), 0, h->stream,
+                       d_chol, (int64_t)P, (int64_t)P, (int64_t)P);
+    if (reg > 0.0) {
+      hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, h->stream, d_chol, P, maxdiag);
+      hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, h->stream, d_chol, P,
+                         maxdiag, reg);
+    }
+    KERNEL_CHECK(h);
+    BLAS_TRY(h, rocsolver_dpotrf(h->blas, rocblas_fill_upper, P, d_chol, P, info));
+    int h_info = 0;
+    HIP_TRY(h, hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h_info == 0) {
+      if (reg_used) *reg_used = reg;
+      return ISDF_OK;
+    }
+    reg = (reg > 0.0) ? reg * 100.0 : 1e-14;
+  }
+  return isdf_fail(h, ISDF_ERR_NUM,
+                   "A_PP = (aoP aoP^T)^2 is not numerically positive definite even with diagonal shift %g * max diag",
+                   reg / 100.0);
+}
+
+extern "C" int isdf_fit_apply(isdf_handle h, const double* d_chol, const double* d_aoP, int P, int nao,
+                              const double* d_ao, int64_t ng, int64_t ld, double* d_theta, int64_t ldt) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_chol && d_aoP && d_ao && d_theta && P > 0 && nao > 0 && ng > 0 && ld >= ng && ldt >= ng);
+  ARG_CHECK(h, P <= 65535 && ldt < (int64_t)2147483647 && ng < (int64_t)2147483647);
+  // B = (aoP ao)^2 (P x ng, row-major) written straight into theta; then in the column-major view
+  // X = B_cm U^-1 U^-T  (A = U^T U).
+  int rc = gemm_rm(h, 'N', 'N', P, ng, nao, 1.0, d_aoP, nao, d_ao, ld, 0.0, d_theta, ldt);
   if (rc) return rc;
-  hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)P), dim3(256), 0, h->stream, A,
-                     (int64_t)P, (int64_t)P, (int64_t)P);
-  KERNEL_CHECK(h);
-  BLAS_TRY(h, rocsolver_dpotrf(h->blas, rocblas_fill_upper, P, A, P, info));
-  int h_info = 0;
-  HIP_TRY(h, hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  if (h_info != 0)
-    return isdf_fail(h, ISDF_ERR_NUM,
-                     "A_PP = (aoP aoP^T)^2 is not numerically positive definite (leading minor %d of %d)",
-                     h_info, P);
-  // Column-major view: A_cm = U^T U with U upper (column-major).  In row-major terms U_cm = Lr^T
-  // where A = Lr Lr^T.  We need Theta = A^-1 B with B = (aoP ao)^2 (P x G row-major).
-  // Column-major view of B is B^T (G x P, ld = ldt):  X_cm = B_cm A^-1 = B_cm U^-1 U^-T.
-  // B in grid chunks (keeps the GEMM well shaped and bounds nothing extra: written straight into theta).
-  rc = gemm_rm(h, 'N', 'N', P, ngrids, nao, 1.0, d_aoP, nao, d_ao, ld, 0.0, d_theta, ldt);
-  if (rc) return rc;
-  hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(ngrids, 256), (unsigned)P), dim3(256), 0, h->stream,
-                     d_theta, (int64_t)P, ngrids, ldt);
+  hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(ng, 256), (unsigned)P), dim3(256), 0, h->stream,
+                     d_theta, (int64_t)P, ng, ldt);
   KERNEL_CHECK(h);
   const double one = 1.0;
   BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
-                            rocblas_diagonal_non_unit, (rocblas_int)ngrids, P, &one, A, P, d_theta,
+                            rocblas_diagonal_non_unit, (rocblas_int)ng, P, &one, d_chol, P, d_theta,
                             (rocblas_int)ldt));
   BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_transpose,
-                            rocblas_diagonal_non_unit, (rocblas_int)ngrids, P, &one, A, P, d_theta,
+                            rocblas_diagonal_non_unit, (rocblas_int)ng, P, &one, d_chol, P, d_theta,
                             (rocblas_int)ldt));
   return ISDF_OK;
+}
+
+extern "C" int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, int64_t ld,
+                               const int64_t* d_ip, int P, double reg_rel, double* d_theta,
+                               int64_t ldt, double* d_aoP, double* reg_used) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, P > 0 && ngrids >= P);
+  double* A = (double*)isdf_ws(h, "fit_APP", sizeof(double) * (size_t)P * P);
+  if (!A) return ISDF_ERR_HIP;
+  int rc = isdf_fit_prepare(h, d_ao, nao, ld, d_ip, P, reg_rel, d_aoP, A, reg_used);
+  if (rc) return rc;
+  return isdf_fit_apply(h, A, d_aoP, P, nao, d_ao, ngrids, ld, d_theta, ldt);
 }

@@ -70,6 +70,8 @@ class ISDF:
         self.c_isdf = c_isdf
         self.select = select              # 'local': per-atom Voronoi blocks + global fit; 'global': one block
         self.tie_rtol = 1e-10
+        self.reg_rel = 1e-12             # relative diagonal shift of A_PP in the global fit
+        self.reg_used = 0.0
         self.fft_batch = None             # rows per FFT batch (None: sized from free memory)
         self._backend = backend
         self._comm = comm
@@ -211,7 +213,7 @@ class ISDF:
             t0 = self._tick('S2_select_ip', t0)
             theta = be.empty((P, G))
             self.aoP = be.empty((P, nao))
-            be.fit_global(self.ao, G, be.to_device(self.ip), theta, self.aoP)
+            self.reg_used = be.fit_global(self.ao, G, be.to_device(self.ip), self.reg_rel, theta, self.aoP)
             t0 = self._tick('S3_fit', t0)
         else:
             raise ValueError("select must be 'local' or 'global'")

@@ -28,7 +28,9 @@ SIGNATURES = {
     'isdf_gather_cols': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_i64]),
     'isdf_select_ip': (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_i64, c_vp, c_vp]),
     'isdf_fit_from_chol': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp]),
-    'isdf_fit_global': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_i64, c_vp]),
+    'isdf_fit_prepare': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_dbl, c_vp, c_vp, ctypes.POINTER(c_dbl)]),
+    'isdf_fit_apply': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64]),
+    'isdf_fit_global': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_vp, c_i64, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_coulomb_W': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64]),
     'isdf_get_j': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_vp]),
     'isdf_rho': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_i64]),

@@ -148,7 +148,8 @@ def test_fit_global(be):
     ip = np.sort(ip)                                         # arbitrary order
     theta = be.empty((14, G))
     aoP = be.empty((14, aoT.shape[0]))
-    be.fit_global(be.to_device(aoT), G, be.to_device(ip), theta, aoP)
+    reg = be.fit_global(be.to_device(aoT), G, be.to_device(ip), 0.0, theta, aoP)
+    assert reg == 0.0
     assert np.array_equal(be.to_host(aoP), aoT[:, ip].T)
     ref = oisdf.fit_theta_normal_equations(aoT, ip)
     assert abs(be.to_host(theta) - ref).max() < 1e-7 * abs(ref).max()
