@@ -152,6 +152,39 @@ def build_local(aoT, a, mesh, owner, nip_per_block, tie_rtol=TIE_RTOL):
     return dict(ip=ip, blocks=blocks, W=W, aoP=np.ascontiguousarray(aoT[:, ip].T))
 
 
+def fit_theta_global_chol(aoT, ip, reg_rel=0.0):
+    """Regularised Cholesky fit used by the scalable variant:
+    Theta = [(aoP^T aoP)^2 + reg_rel * max(diag) * I]^-1 (aoP^T ao)^2  (include/mi355_isdf.h S3b)."""
+    aoP = aoT[:, ip]
+    A = aoP.T.dot(aoP) ** 2
+    if reg_rel > 0:
+        A = A + reg_rel * np.diag(A).max() * np.eye(len(ip))
+    B = aoP.T.dot(aoT) ** 2
+    return scipy.linalg.cho_solve(scipy.linalg.cho_factor(A), B)
+
+
+def build_local_select_global_fit(aoT, a, mesh, owner, nip_per_block, reg_rel=1e-12, tie_rtol=TIE_RTOL,
+                                  select=None):
+    """Interpolation points chosen independently inside each block (grid points regrouped block by
+    block with a stable sort, exactly like the product), then ONE global least-squares fit."""
+    select = select or select_ip
+    perm = np.argsort(owner, kind='stable')
+    counts = np.bincount(owner, minlength=len(nip_per_block))
+    off = np.append(0, np.cumsum(counts))
+    ips = []
+    for b in range(len(nip_per_block)):
+        idx = perm[off[b]:off[b + 1]]
+        k = min(int(nip_per_block[b]), len(idx))
+        if k == 0:
+            continue
+        piv, _ = select(aoT[:, idx], k, tie_rtol=tie_rtol)
+        ips.append(idx[piv])
+    ip = np.concatenate(ips)
+    theta = fit_theta_global_chol(aoT, ip, reg_rel)
+    W = build_W(theta, a, mesh)
+    return dict(ip=ip, theta=theta, W=W, aoP=np.ascontiguousarray(aoT[:, ip].T))
+
+
 def theta_dense_from_blocks(blocks, G):
     P = sum(len(b['ip_local']) for b in blocks)
     th = np.zeros((P, G))

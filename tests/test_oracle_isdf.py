@@ -1,0 +1,106 @@
+"""CPU tests of the ISDF oracle: pinned to the reference's pivot rule through golden vectors made
+from the reference's own pivoted_cholesky_python, to algebraic identities, and to the pinned exact
+FFTDF J/K through convergence.  No GPU."""
+import json
+import os
+import numpy as np
+import pytest
+import cells
+from pyscf_isdf_amd import gto
+from oracle import ao as oao, isdf as oisdf, fftdf, pbc_tools as tools, c_oracle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pivoted_cholesky_golden.json')
+
+
+def _make_ao(seed, nao, m):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((nao, m)) * np.exp(-3.0 * rng.random(m))
+
+
+@pytest.mark.parametrize('impl', ['numpy', 'c'])
+def test_pivots_match_reference_golden(impl):
+    """Implicit-Gram selection == the reference's pivoted Cholesky on the explicit Gram matrix
+    (same pivots, same rank under tol=-1, same factor diagonal)."""
+    with open(GOLD) as f:
+        gold = json.load(f)
+    for case in gold['cases']:
+        ao = _make_ao(case['seed'], case['nao'], case['m'])
+        fn = oisdf.select_ip if impl == 'numpy' else c_oracle.select_ip
+        piv, L = fn(ao, case['m'], tol=-1.0, tie_rtol=0.0)
+        assert len(piv) == case['rank']
+        assert list(piv) == case['piv']
+        assert np.allclose(L[np.arange(len(piv)), piv], case['diag'], rtol=1e-7, atol=0)
+
+
+def test_c_oracle_equals_numpy_oracle():
+    ao = _make_ao(42, 12, 3000)
+    p1, L1 = oisdf.select_ip(ao, 60)
+    p2, L2 = c_oracle.select_ip(ao, 60)
+    assert np.array_equal(p1, p2)
+    assert abs(L1 - L2).max() < 1e-10 * abs(L1).max()
+
+
+def test_tie_rule_picks_lowest_index():
+    base = _make_ao(7, 4, 200)
+    ao = np.concatenate([base, base], axis=1)
+    for fn in (oisdf.select_ip, c_oracle.select_ip):
+        piv, _ = fn(ao, 8)
+        assert (piv < 200).all()
+
+
+@pytest.fixture(scope='module')
+def hec():
+    cell = cells.cell_he_c()
+    coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    ao = oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, rule='point')
+    return cell, ao, np.ascontiguousarray(ao.T)
+
+
+def test_fit_identities(hec):
+    cell, ao, aoT = hec
+    piv, L = oisdf.select_ip(aoT, 15)
+    theta = oisdf.fit_theta(L, piv)
+    assert abs(theta[:, piv] - np.eye(15)).max() < 1e-12          # interpolation property
+    ne = oisdf.fit_theta_normal_equations(aoT, piv)                # SURVEY 7.1-3 form
+    assert abs(theta - ne).max() < 1e-7 * abs(ne).max()
+    # residual of the pair densities decreases with the number of points
+    i, j = np.tril_indices(cell.nao_nr())
+    pairs = aoT[i] * aoT[j]
+    errs = []
+    for k in (6, 12, 18, 21):
+        p, Lk = oisdf.select_ip(aoT, k)
+        th = oisdf.fit_theta(Lk, p)
+        errs.append(abs(pairs - pairs[:, p].dot(th)).max())
+    assert errs[0] > errs[1] > errs[2] > errs[3] and errs[3] < 1e-10
+
+
+def test_isdf_converges_to_pinned_fftdf(hec):
+    """At full rank ISDF is exact: K and the ERIs reproduce the reference's known answers
+    (test_fft.py:645, :695) through the ISDF formulas — this pins W's normalisation."""
+    cell, ao, aoT = hec
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    r = oisdf.build_global(aoT, a, mesh, 40)
+    assert len(r['ip']) == 21
+    dm = np.eye(cell.nao_nr())
+    vk = oisdf.get_k(r['aoP'], r['W'], dm)
+    assert abs(tools.fp(vk) - 4.290076429522121) < 1e-8
+    assert abs(tools.fp(oisdf.isdf_eri_s4(r['aoP'], r['W'])) - 0.80425358275734926) < 1e-8
+    assert abs(tools.fp(oisdf.get_j(aoT, dm, a, mesh)) - 3.7955873127283377) < 1e-8
+    errs = [abs(oisdf.get_k(*(lambda q: (q['aoP'], q['W']))(oisdf.build_global(aoT, a, mesh, k)), dm)
+                - fftdf.get_k(ao, dm, a, mesh)).max() for k in (12, 18, 21)]
+    assert errs[0] > errs[1] > errs[2]
+
+
+def test_local_blocks_with_global_fit(hec):
+    """Per-atom selection + regularised global fit (the scalable variant) also converges."""
+    cell, ao, aoT = hec
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    owner = oisdf.partition_by_atom(cell.get_uniform_grids(), cell.atom_coords(), a)
+    assert set(np.unique(owner)) == {0, 1}
+    r = oisdf.build_local_select_global_fit(aoT, a, mesh, owner, [8, 16], reg_rel=1e-12)
+    dm = np.eye(cell.nao_nr())
+    vk = oisdf.get_k(r['aoP'], r['W'], dm)
+    # 24 points for 21 independent pair products: the diagonal shift bounds the accuracy here
+    assert abs(vk - fftdf.get_k(ao, dm, a, mesh)).max() < 1e-5
