@@ -115,10 +115,14 @@ int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, 
  * FFT conventions of pyscf/pbc/tools/pbc.py:149-211 (forward unscaled, inverse 1/G), Coulomb kernel
  * 4 pi/|G|^2 with G=0 -> 0 (pbc.py:352-356) on the fftfreq-ordered mesh (cell.py:552-587),
  * normalisation of pyscf/pbc/df/fft_ao2mo.py:154-184.  a = lattice vectors (3,3 row-major, Bohr).
- * d_W rows [row0, row0+nrows) are written (row-major, ldw >= P).  batch = rows per FFT batch. */
+ * d_W rows [row0, row0+nrows) are written (row-major, ldw >= P).  batch = rows per FFT batch.
+ * upper_only != 0: W is symmetric, so for each batch only the columns from the batch's first row on
+ * are computed (half the flops); call isdf_symmetrize_upper once all rows are done. */
 int isdf_coulomb_W(isdf_handle h, const double* d_theta, int P, int64_t ldt,
                    const int32_t mesh[3], const double a[9],
-                   int row0, int nrows, int batch, double* d_W, int64_t ldw);
+                   int row0, int nrows, int batch, int upper_only, double* d_W, int64_t ldw);
+/* W[q][p] = W[p][q] for q > p. */
+int isdf_symmetrize_upper(isdf_handle h, double* d_W, int P, int64_t ldw);
 
 /* S6. J exactly as pyscf/pbc/df/fft_jk.py:63-107 (Γ, real dm):
  *   rho = sum_mn dm_mn ao_m ao_n;  v = (vol/G) ifft(coulG fft rho).real;  vj = ao (v .* ao)^T.
@@ -142,6 +146,14 @@ int isdf_vj_from_vR(isdf_handle h, const double* d_ao, int nao, int64_t ng, int6
 int isdf_get_k(isdf_handle h, const double* d_aoP, int P, int nao,
                const double* d_W, int64_t ldw, int row0, int nrows,
                const double* d_dm, int nset, double* d_vk);
+
+/* Dense helper behind S5/S6 (exposed for tests and micro-benchmarks):
+ *   C (M, ldc) = alpha * A (M, lda) * (B (N, ldb) .* kscale[None, :])^T + beta * C,
+ * K contiguous in both operands (the W = V Theta^T / vj = ao (v.ao)^T shape); d_kscale may be NULL.
+ * Hand-written v_mfma_f64_16x16x4_f64 kernel, deterministic slab reduction. */
+int isdf_gemm_nt(isdf_handle h, int M, int N, int64_t K, double alpha, const double* d_A, int64_t lda,
+                 const double* d_B, int64_t ldb, const double* d_kscale, double beta, double* d_C,
+                 int64_t ldc);
 
 #ifdef __cplusplus
 }

@@ -116,12 +116,16 @@ class HipBackend:
                          ip.numel(), float(reg_rel), self._p(theta), theta.stride(0), self._p(aoP), ctypes.byref(reg))
         return reg.value
 
-    def coulomb_W(self, theta, mesh, a, row0, nrows, batch, W):
+    def coulomb_W(self, theta, mesh, a, row0, nrows, batch, W, upper_only=False):
         self._stream()
         mesh = np.ascontiguousarray(mesh, dtype=np.int32)
         a = np.ascontiguousarray(a, dtype=np.float64)
         self.handle.call('isdf_coulomb_W', self._p(theta), theta.shape[0], theta.stride(0), _np_ptr(mesh), _np_ptr(a),
-                         int(row0), int(nrows), int(batch), self._p(W), W.stride(0))
+                         int(row0), int(nrows), int(batch), int(bool(upper_only)), self._p(W), W.stride(0))
+
+    def symmetrize_upper(self, W):
+        self._stream()
+        self.handle.call('isdf_symmetrize_upper', self._p(W), W.shape[0], W.stride(0))
 
     def get_j(self, ao, ngrids, mesh, a, dm, vj):
         self._stream()
@@ -152,3 +156,13 @@ class HipBackend:
         assert aoP.is_contiguous() and dm.is_contiguous() and vk.is_contiguous()
         self.handle.call('isdf_get_k', self._p(aoP), aoP.shape[0], aoP.shape[1], self._p(W), W.stride(0), int(row0),
                          int(nrows), self._p(dm), dm.shape[0], self._p(vk))
+
+    def gemm_nt(self, A, B, C, alpha=1.0, beta=0.0, kscale=None):
+        """C = alpha * A (B .* kscale)^T + beta * C; A (M,K), B (N,K) row-major, K contiguous."""
+        self._stream()
+        M, K = A.shape
+        N = B.shape[0]
+        assert B.shape[1] == K and C.shape == (M, N) and A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1
+        ks = self._p(kscale) if kscale is not None else _vp(0)
+        self.handle.call('isdf_gemm_nt', M, N, K, float(alpha), self._p(A), A.stride(0), self._p(B), B.stride(0), ks,
+                         float(beta), self._p(C), C.stride(0))

@@ -68,6 +68,10 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // "NT with K contiguous in both operands": the shape of W = V Theta^T and of J = ao (v.ao)^T.
 int gemm_nt_f64(isdf_handle h, int M, int N, int64_t K, double alpha, const double* A, int64_t lda,
                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+// same with B scaled per k on the fly: C = alpha * A * (B .* kscale[None,:])^T + beta * C
+int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, const double* kscale, double beta, double* C,
+                       int64_t ldc);
 // Row-major wrappers over rocBLAS for the well-shaped products.
 // C (M x N, ldc) = alpha * op(A) * op(B) + beta * C, all row-major; opA/opB 'N' or 'T'.
 int gemm_rm(isdf_handle h, char opA, char opB, int64_t M, int64_t N, int64_t K, double alpha,

@@ -100,9 +100,37 @@ static int convolve_rows(isdf_handle h, const double* d_in, double* d_out, int n
   return ISDF_OK;
 }
 
+namespace {
+// W[q][p] = W[p][q] for q > p (the Coulomb operator is symmetric; only the block-upper part is computed)
+__global__ void mirror_upper_kernel(double* __restrict__ W, int P, int64_t ldw) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x, by = blockIdx.y;     // tile (by, bx) of the upper triangle, bx >= by
+  if (bx < by) return;
+  const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = by * 32 + i, cc = bx * 32 + tx;
+    tile[i][tx] = (r < P && cc < P) ? W[(int64_t)r * ldw + cc] : 0.0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int r = bx * 32 + i, cc = by * 32 + tx;   // transposed position
+    if (r < P && cc < P && r > cc) W[(int64_t)r * ldw + cc] = tile[tx][i];
+  }
+}
+}  // namespace
+
+extern "C" int isdf_symmetrize_upper(isdf_handle h, double* d_W, int P, int64_t ldw) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_W && P > 0 && ldw >= P);
+  const unsigned nt = (unsigned)cdiv(P, 32);
+  hipLaunchKernelGGL(mirror_upper_kernel, dim3(nt, nt), dim3(32, 8), 0, h->stream, d_W, P, ldw);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
 extern "C" int isdf_coulomb_W(isdf_handle h, const double* d_theta, int P, int64_t ldt,
                               const int32_t mesh[3], const double a[9], int row0, int nrows,
-                              int batch, double* d_W, int64_t ldw) {
+                              int batch, int upper_only, double* d_W, int64_t ldw) {
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_theta && mesh && a && d_W && P > 0 && batch > 0 && ldw >= P);
   ARG_CHECK(h, row0 >= 0 && nrows >= 0 && row0 + nrows <= P);
@@ -124,8 +152,11 @@ extern "C" int isdf_coulomb_W(isdf_handle h, const double* d_theta, int P, int64
     const int nb = std::min(batch, row0 + nrows - r);
     rc = convolve_rows(h, d_theta + (int64_t)r * ldt, V, nb, mesh, cg, Z);
     if (rc) return rc;
-    // W[r:r+nb, :] = w * V (nb x G) * Theta^T (G x P)
-    rc = gemm_nt_f64(h, nb, P, G, w, V, G, d_theta, ldt, 0.0, d_W + (int64_t)r * ldw, ldw);
+    // W[r:r+nb, c0:] = w * V (nb x G) * Theta[c0:]^T ; with upper_only the columns left of the batch's
+    // first row are skipped (filled later by isdf_symmetrize_upper)
+    const int c0 = upper_only ? r : 0;
+    rc = gemm_nt_f64(h, nb, P - c0, G, w, V, G, d_theta + (int64_t)c0 * ldt, ldt, 0.0,
+                     d_W + (int64_t)r * ldw + c0, ldw);
     if (rc) return rc;
   }
   return ISDF_OK;

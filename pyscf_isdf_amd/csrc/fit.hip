@@ -126,13 +126,40 @@ extern "C" int isdf_fit_apply(isdf_handle h, const double* d_chol, const double*
   hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(ng, 256), (unsigned)P), dim3(256), 0, h->stream,
                      d_theta, (int64_t)P, ng, ldt);
   KERNEL_CHECK(h);
+  // Theta = A^-1 B with A = Lr Lr^T (Lr = the factor read row-major, lower).  Blocked triangular
+  // solves: the diagonal blocks go to rocBLAS TRSM (a few % of the flops), the trailing updates are
+  // plain GEMMs of shape (rows x ng x NB), which run at the MFMA rate; a monolithic rocBLAS TRSM
+  // reaches only ~43 TF/s on this shape (profiles/r01_probe_rocblas_hipfft_mfma64.log).
   const double one = 1.0;
-  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
-                            rocblas_diagonal_non_unit, (rocblas_int)ng, P, &one, d_chol, P, d_theta,
-                            (rocblas_int)ldt));
-  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_transpose,
-                            rocblas_diagonal_non_unit, (rocblas_int)ng, P, &one, d_chol, P, d_theta,
-                            (rocblas_int)ldt));
+  const int NB = 512;
+  // forward: Y = Lr^-1 B
+  for (int jb = 0; jb < P; jb += NB) {
+    const int nb = std::min(NB, P - jb);
+    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
+                              rocblas_diagonal_non_unit, (rocblas_int)ng, nb, &one,
+                              d_chol + (int64_t)jb * P + jb, P, d_theta + (int64_t)jb * ldt, (rocblas_int)ldt));
+    const int j1 = jb + nb;
+    if (j1 < P) {
+      rc = gemm_rm(h, 'N', 'N', P - j1, ng, nb, -1.0, d_chol + (int64_t)j1 * P + jb, P,
+                   d_theta + (int64_t)jb * ldt, ldt, 1.0, d_theta + (int64_t)j1 * ldt, ldt);
+      if (rc) return rc;
+    }
+  }
+  // backward: Theta = Lr^-T Y
+  const int nblk = (int)cdiv(P, NB);
+  for (int b = nblk - 1; b >= 0; --b) {
+    const int jb = b * NB;
+    const int nb = std::min(NB, P - jb);
+    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_transpose,
+                              rocblas_diagonal_non_unit, (rocblas_int)ng, nb, &one,
+                              d_chol + (int64_t)jb * P + jb, P, d_theta + (int64_t)jb * ldt, (rocblas_int)ldt));
+    if (jb > 0) {
+      // Y[:jb] -= Lr[jb:jb+nb, :jb]^T Theta[jb:jb+nb]
+      rc = gemm_rm(h, 'T', 'N', jb, ng, nb, -1.0, d_chol + (int64_t)jb * P, P,
+                   d_theta + (int64_t)jb * ldt, ldt, 1.0, d_theta, ldt);
+      if (rc) return rc;
+    }
+  }
   return ISDF_OK;
 }
 

@@ -1,9 +1,20 @@
 // Dense FP64 products for the ISDF path.
 //  * gemm_rm: row-major wrapper over rocBLAS dgemm for the well-shaped products (rocBLAS reaches
 //    70-74 TF/s of the 78.6 TF/s FP64 MFMA peak on them: profiles/r01_probe_rocblas_hipfft_mfma64.log).
-//  * gemm_nt_f64: C = alpha * A * B^T + beta * C with K contiguous in BOTH operands and K >> M, N —
-//    the shape of W = V Theta^T (K = ngrids) and of vj = ao (v.ao)^T.  rocBLAS runs this shape at
-//    1-13 TF/s (same log), so it gets a hand-written v_mfma_f64_16x16x4_f64 split-K kernel here.
+//  * gemm_nt_f64: C = alpha * A * (B .* kscale)^T + beta * C with K contiguous in BOTH operands and
+//    K >> M, N — the shape of W = V Theta^T (K = ngrids) and of vj = ao (v .* ao)^T.  rocBLAS runs
+//    this shape at 1-13 TF/s (same log), so it gets a hand-written v_mfma_f64_16x16x4_f64 kernel:
+//      - 128x128 output tile per 256-thread workgroup, each wave a 64x64 sub-tile = 4x4 MFMA
+//        accumulators (128 VGPRs);
+//      - K is cut into slabs; one work unit = (slab, tile).  Units are ordered slab-major with the
+//        row tile fastest so that workgroups that share an operand panel run at the same time, and
+//        the block id is remapped so that such neighbours land on the same XCD (its L2);
+//      - operands are staged global -> registers -> LDS in 16-deep K chunks (one full 128-B line per
+//        row per chunk), double buffered, rows padded to 144 B so that the ds_read_b64 fragment
+//        reads are bank-conflict free;
+//      - partial tiles of the slabs go to a workspace and are summed in a fixed order (deterministic,
+//        no float atomics).
+//    Algorithmic work: 2*M*N*K flop; bound: FP64 MFMA (78.6 TF/s).
 #include "common.h"
 
 int gemm_rm(isdf_handle h, char opA, char opB, int64_t M, int64_t N, int64_t K, double alpha,
@@ -19,7 +30,216 @@ int gemm_rm(isdf_handle h, char opA, char opB, int64_t M, int64_t N, int64_t K, 
   return ISDF_OK;
 }
 
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDT = 18;          // doubles per LDS row: 16 + 2 pad (144 B) -> conflict-free b64 fragment reads
+constexpr int TPB = 256;
+
+struct GemmArgs {
+  const double* A; int64_t lda;
+  const double* B; int64_t ldb;
+  const double* kscale;          // optional per-k scale applied to B (nullptr: none)
+  double* P;                     // partials [nslab][M][N] (or C itself when nslab == 1 && direct)
+  int64_t ldp, slab_stride;
+  int M, N;
+  int64_t K, kslab;              // kslab multiple of BK
+  int ntm, ntn, nslab;
+  int64_t nunits, nunits_pad;    // nunits_pad: rounded up to a multiple of 8 (XCD remap)
+  double alpha, beta;            // used only when direct
+  int direct;
+};
+
+// FAST: lda, ldb even (16-byte aligned rows given 16-byte aligned bases) and no K tail handling
+// needed inside a chunk (K % BK == 0).  Otherwise the generic path loads element-wise with guards.
+template <bool FAST>
+__global__ __launch_bounds__(TPB, 2) void gemm_nt_mfma_kernel(GemmArgs g) {
+  __shared__ double sA[2][BM * LDT];
+  __shared__ double sB[2][BN * LDT];
+
+  // XCD-aware unit id: hardware deals consecutive block ids round-robin over 8 XCDs; give each XCD a
+  // contiguous range of units so that neighbours (which share operand panels) share an L2.
+  const int64_t bid = blockIdx.x;
+  const int64_t per_xcd = g.nunits_pad / 8;
+  const int64_t unit = (bid % 8) * per_xcd + bid / 8;
+  if (unit >= g.nunits) return;
+  const int tm = (int)(unit % g.ntm);
+  const int tn = (int)((unit / g.ntm) % g.ntn);
+  const int slab = (int)(unit / ((int64_t)g.ntm * g.ntn));
+  const int64_t k0 = (int64_t)slab * g.kslab;
+  const int64_t k1 = (k0 + g.kslab < g.K) ? k0 + g.kslab : g.K;
+  const int nchunks = (int)((k1 - k0 + BK - 1) / BK);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // staging map: piece p = tid + 256*i, i < 4: row = p / 8, 16-byte segment = p % 8
+  const int srow = tid >> 3;            // 0..31, +32*i
+  const int sseg = tid & 7;             // k offset sseg*2
+  // row offsets are recomputed per chunk (cheap next to 64 MFMAs) instead of keeping 8 pointers live;
+  // out-of-range rows are clamped: they are computed but never stored
+  const int arow0 = tm * BM + srow, brow0 = tn * BN + srow;
+  const int mlast = g.M - 1, nlast = g.N - 1;
+  const double* __restrict__ Ag = g.A;
+  const double* __restrict__ Bg = g.B;
+  const int64_t lda = g.lda, ldb = g.ldb;
+
+  // staging registers as named scalars (arrays captured by the helpers below ended up in scratch)
+  double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define ISDF_LOAD_ONE(I, RA, RB)                                                              \
+  {                                                                                           \
+    const int ra = min(arow0 + 32 * I, mlast), rb = min(brow0 + 32 * I, nlast);               \
+    const double* pa = Ag + (int64_t)ra * lda + k;                                            \
+    const double* pb = Bg + (int64_t)rb * ldb + k;                                            \
+    if (FAST) {                                                                               \
+      RA = *reinterpret_cast<const double2*>(pa);                                             \
+      RB = *reinterpret_cast<const double2*>(pb);                                             \
+    } else {                                                                                  \
+      RA.x = v0 ? pa[0] : 0.0; RA.y = v1 ? pa[1] : 0.0;                                       \
+      RB.x = v0 ? pb[0] : 0.0; RB.y = v1 ? pb[1] : 0.0;                                       \
+    }                                                                                         \
+    RB.x *= s0; RB.y *= s1;                                                                   \
+  }
+#define ISDF_LOAD_CHUNK(C)                                                                    \
+  {                                                                                           \
+    const int64_t k = k0 + (int64_t)(C) * BK + sseg * 2;                                      \
+    const bool v0 = FAST || (k < k1), v1 = FAST || (k + 1 < k1);                              \
+    double s0 = 1.0, s1 = 1.0;                                                                \
+    if (g.kscale) { if (v0) s0 = g.kscale[k]; if (v1) s1 = g.kscale[k + 1]; }                 \
+    ISDF_LOAD_ONE(0, ra0, rb0) ISDF_LOAD_ONE(1, ra1, rb1)                                     \
+    ISDF_LOAD_ONE(2, ra2, rb2) ISDF_LOAD_ONE(3, ra3, rb3)                                     \
+  }
+#define ISDF_STORE_ONE(BUF, I, RA, RB)                                                        \
+  *reinterpret_cast<double2*>(&sA[BUF][(srow + 32 * I) * LDT + sseg * 2]) = RA;               \
+  *reinterpret_cast<double2*>(&sB[BUF][(srow + 32 * I) * LDT + sseg * 2]) = RB;
+#define ISDF_STORE_CHUNK(BUF)                                                                 \
+  { ISDF_STORE_ONE(BUF, 0, ra0, rb0) ISDF_STORE_ONE(BUF, 1, ra1, rb1)                         \
+    ISDF_STORE_ONE(BUF, 2, ra2, rb2) ISDF_STORE_ONE(BUF, 3, ra3, rb3) }
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  ISDF_LOAD_CHUNK(0)
+  ISDF_STORE_CHUNK(0)
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) ISDF_LOAD_CHUNK(c + 1)
+    const double* pa = &sA[buf][(wm * 64 + frow) * LDT + fk];
+    const double* pb = &sB[buf][(wn * 64 + frow) * LDT + fk];
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = pa[i * 16 * LDT + kk * 4];
+        b[i] = pb[i * 16 * LDT + kk * 4];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (c + 1 < nchunks) ISDF_STORE_CHUNK(buf ^ 1)
+    __syncthreads();
+  }
+
+  // epilogue: D[row = (lane>>4) + 4r][col = lane&15] per 16x16 accumulator
+  double* out = g.P + (int64_t)slab * g.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tm * BM + wm * 64 + i * 16 + (lane >> 4) + 4 * r;
+      if (row >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = tn * BN + wn * 64 + j * 16 + (lane & 15);
+        if (col >= g.N) continue;
+        double* q = out + (int64_t)row * g.ldp + col;
+        const double v = acc[i][j][r];
+        if (g.direct) *q = (g.beta == 0.0) ? g.alpha * v : g.alpha * v + g.beta * (*q);
+        else *q = v;
+      }
+    }
+  }
+}
+
+__global__ void reduce_slabs_kernel(const double* __restrict__ P, int nslab, int64_t slab_stride,
+                                    int M, int N, double alpha, double beta, double* __restrict__ C,
+                                    int64_t ldc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx % N);
+  double s = 0.0;
+  for (int t = 0; t < nslab; ++t) s += P[(int64_t)t * slab_stride + idx];
+  double* q = C + (int64_t)m * ldc + n;
+  *q = (beta == 0.0) ? alpha * s : alpha * s + beta * (*q);
+}
+
+}  // namespace
+
+int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, const double* kscale, double beta, double* C,
+                       int64_t ldc) {
+  ARG_CHECK(h, M > 0 && N > 0 && K > 0 && A && B && C && lda >= K && ldb >= K && ldc >= N);
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.kscale = kscale;
+  g.M = M; g.N = N; g.K = K;
+  g.ntm = (int)cdiv(M, BM); g.ntn = (int)cdiv(N, BN);
+  const int64_t ntiles = (int64_t)g.ntm * g.ntn;
+  // enough units to fill 2 workgroups per CU about 8 times over, slabs at least 2048 deep,
+  // partial workspace at most 2 GiB
+  const int64_t slots = (int64_t)h->num_cu * 2;
+  int64_t nslab = cdiv(8 * slots, ntiles);
+  nslab = std::min<int64_t>(nslab, std::max<int64_t>(1, K / 2048));
+  nslab = std::min<int64_t>(nslab, std::max<int64_t>(1, ((int64_t)2 << 30) / ((int64_t)M * N * 8)));
+  nslab = std::max<int64_t>(nslab, 1);
+  g.kslab = cdiv(cdiv(K, nslab), BK) * BK;
+  g.nslab = (int)cdiv(K, g.kslab);
+  g.nunits = ntiles * g.nslab;
+  g.nunits_pad = cdiv(g.nunits, 8) * 8;
+  g.alpha = alpha; g.beta = beta;
+  if (g.nslab == 1) {
+    g.direct = 1; g.P = C; g.ldp = ldc; g.slab_stride = 0;
+  } else {
+    g.direct = 0;
+    g.P = (double*)isdf_ws(h, "gemm_partials", sizeof(double) * (size_t)g.nslab * M * N);
+    if (!g.P) return ISDF_ERR_HIP;
+    g.ldp = N; g.slab_stride = (int64_t)M * N;
+  }
+  const bool fast = (lda % 2 == 0) && (ldb % 2 == 0) && (K % BK == 0) &&
+                    (((uintptr_t)A) % 16 == 0) && (((uintptr_t)B) % 16 == 0) &&
+                    (!kscale || ((uintptr_t)kscale) % 16 == 0);
+  ARG_CHECK(h, g.nunits_pad < 2147483647LL);
+  if (fast) hipLaunchKernelGGL(gemm_nt_mfma_kernel<true>, dim3((unsigned)g.nunits_pad), dim3(TPB), 0, h->stream, g);
+  else hipLaunchKernelGGL(gemm_nt_mfma_kernel<false>, dim3((unsigned)g.nunits_pad), dim3(TPB), 0, h->stream, g);
+  KERNEL_CHECK(h);
+  if (!g.direct) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdiv((int64_t)M * N, 256)), dim3(256), 0, h->stream,
+                       g.P, g.nslab, g.slab_stride, M, N, alpha, beta, C, ldc);
+    KERNEL_CHECK(h);
+  }
+  return ISDF_OK;
+}
+
 int gemm_nt_f64(isdf_handle h, int M, int N, int64_t K, double alpha, const double* A, int64_t lda,
                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
-  return gemm_rm(h, 'N', 'T', M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+  return gemm_nt_f64_scaled(h, M, N, K, alpha, A, lda, B, ldb, nullptr, beta, C, ldc);
+}
+
+// Exposed for tests and benchmarks (declared in include/mi355_isdf.h).
+extern "C" int isdf_gemm_nt(isdf_handle h, int M, int N, int64_t K, double alpha, const double* d_A,
+                            int64_t lda, const double* d_B, int64_t ldb, const double* d_kscale,
+                            double beta, double* d_C, int64_t ldc) {
+  if (!h) return ISDF_ERR_ARG;
+  return gemm_nt_f64_scaled(h, M, N, K, alpha, d_A, lda, d_B, ldb, d_kscale, beta, d_C, ldc);
 }

@@ -20,15 +20,6 @@ __global__ void rho_reduce_kernel(const double* __restrict__ T, int64_t ldT,
   rho[g] = s;
 }
 
-// S[mu,g] = ao[mu,g] * v[g]
-__global__ void scale_cols_kernel(const double* __restrict__ ao, int64_t ld, const double* __restrict__ v,
-                                  int64_t ng, double* __restrict__ S, int64_t ldS) {
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= ng) return;
-  const int64_t mu = blockIdx.y;
-  S[mu * ldS + g] = ao[mu * ld + g] * v[g];
-}
-
 __global__ void hadamard_kernel(double* __restrict__ M, int64_t ldm, const double* __restrict__ W,
                                 int64_t ldw, int64_t rows, int64_t cols) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -61,19 +52,12 @@ extern "C" int isdf_rho(isdf_handle h, const double* d_ao, int nao, int64_t ng, 
 extern "C" int isdf_vj_from_vR(isdf_handle h, const double* d_ao, int nao, int64_t ng, int64_t ld,
                                const double* d_vR, int nset, int64_t ldv, double* d_vj) {
   if (!h) return ISDF_ERR_ARG;
-  ARG_CHECK(h, d_ao && d_vR && d_vj && nao > 0 && nao <= 65535 && ng > 0 && ld >= ng && nset > 0 && ldv >= ng);
-  double* S = (double*)isdf_ws(h, "jk_T", sizeof(double) * (size_t)nao * JCHUNK);
-  if (!S) return ISDF_ERR_HIP;
+  ARG_CHECK(h, d_ao && d_vR && d_vj && nao > 0 && ng > 0 && ld >= ng && nset > 0 && ldv >= ng);
+  // vj = ao (v .* ao)^T: the potential is applied to the B operand while it is staged (no scaled copy)
   for (int i = 0; i < nset; ++i) {
-    double* vj = d_vj + (int64_t)i * nao * nao;
-    for (int64_t g0 = 0; g0 < ng; g0 += JCHUNK) {
-      const int64_t nc = std::min(JCHUNK, ng - g0);
-      hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)cdiv(nc, 256), (unsigned)nao), dim3(256), 0, h->stream,
-                         d_ao + g0, ld, d_vR + (int64_t)i * ldv + g0, nc, S, JCHUNK);
-      KERNEL_CHECK(h);
-      int rc = gemm_nt_f64(h, nao, nao, nc, 1.0, d_ao + g0, ld, S, JCHUNK, g0 == 0 ? 0.0 : 1.0, vj, nao);
-      if (rc) return rc;
-    }
+    int rc = gemm_nt_f64_scaled(h, nao, nao, ng, 1.0, d_ao, ld, d_ao, ld, d_vR + (int64_t)i * ldv, 0.0,
+                                d_vj + (int64_t)i * nao * nao, nao);
+    if (rc) return rc;
   }
   return ISDF_OK;
 }

@@ -221,7 +221,8 @@ class ISDF:
         # S4 + S5 Coulomb convolution and W
         self.W = be.empty((P, P))
         batch = self.fft_batch or _default_fft_batch(G, P)
-        be.coulomb_W(theta, mesh, a, 0, P, batch, self.W)
+        be.coulomb_W(theta, mesh, a, 0, P, batch, self.W, upper_only=True)
+        be.symmetrize_upper(self.W)
         del theta
         t0 = self._tick('S4S5_coulomb_W', t0)
         self._built = True

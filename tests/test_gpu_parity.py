@@ -174,6 +174,12 @@ def test_coulomb_W(be, mk):
         W.zero_()
         be.coulomb_W(be.to_device(theta), cell.mesh, a, 0, k, batch, W)
         assert abs(be.to_host(W) - ref).max() < 1e-10 * abs(ref).max()
+    # symmetric shortcut: block-upper part + mirror
+    W.zero_()
+    be.coulomb_W(be.to_device(theta), cell.mesh, a, 0, k, 5, W, upper_only=True)
+    be.symmetrize_upper(W)
+    got = be.to_host(W)
+    assert abs(got - ref).max() < 1e-10 * abs(ref).max() and abs(got - got.T).max() == 0
     # row range (multi-GPU sharding of P)
     W.zero_()
     be.coulomb_W(be.to_device(theta), cell.mesh, a, 3, 4, 3, W)
@@ -261,3 +267,18 @@ def test_isdf_object_vs_oracle_pipeline_diamond():
     assert abs(np.einsum('ij,ji', vj - vj_ref, dm)) / 2 < 1e-9
     assert abs(np.einsum('ij,ji', vk - vk_ref, dm)) / 4 < 1e-9
     assert abs(vj - vj_ref).max() < 1e-9 and abs(vk - vk_ref).max() < 1e-8
+
+
+@pytest.mark.parametrize('M,N,K,scaled', [(128, 128, 4096, False), (130, 257, 4112, True), (7, 300, 9261, True),
+                                          (384, 520, 65536, False), (64, 64, 17, False), (1, 1, 1, True)])
+def test_gemm_nt_mfma(be, M, N, K, scaled):
+    """The FP64 MFMA kernel behind W and vj: C = alpha A (B.*s)^T + beta C against numpy, incl. ragged
+    tiles, odd K / unaligned rows (generic path) and multi-slab reduction.  1e-12 relative to |A||B|."""
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((N, K)); C0 = rng.standard_normal((M, N))
+    s = rng.standard_normal(K) if scaled else None
+    ref = 0.7 * A.dot((B * s).T if scaled else B.T) - 0.3 * C0
+    C = be.to_device(C0)
+    be.gemm_nt(be.to_device(A), be.to_device(B), C, alpha=0.7, beta=-0.3, kscale=be.to_device(s) if scaled else None)
+    scale = np.sqrt(K) * 10
+    assert abs(be.to_host(C) - ref).max() < 1e-12 * scale
