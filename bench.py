@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""bench.py — ISDF build + 1x get_jk on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--no-cpu-baseline]
+
+One "step" = ISDF.build() (collocation, interpolation-point selection, fit, Coulomb W) followed by
+one get_jk() on a synthetic density matrix; the cell tables and the density matrix are already
+resident when the timed region starts.  N > 1 is launched by torch.distributed.run (one rank per
+GPU, RCCL).  Rank 0 prints ONE JSON line (see the contract in the task description) with two extra
+objects: "roofline" for the dominant hand-written kernel (measured live with HIP events on the work
+stream by the library's profiling hooks) and "cpu_baseline" (the numpy/scipy oracle timed on the
+host on a bounded sample of the same workload, extrapolated stage by stage).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet, MI355X FP64 matrix (the guide's table has no f64 row);
+                               # best rocBLAS dgemm measured on the box: 73.8 (profiles/r01_probe_*.log)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default=os.environ.get('ISDF_BENCH_WORKLOAD', 'diamond-444-dzvp-120'))
+    ap.add_argument('--select', default='local', choices=['local', 'global'])
+    ap.add_argument('--c-isdf', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--stage-report', default=None, help='write the per-kernel table to this file')
+    return ap.parse_args()
+
+
+def cpu_baseline(cell, c_isdf, gpu_stage_sizes):
+    """Time the numpy/scipy oracle on a bounded sample of the workload and extrapolate each stage
+    linearly in its sampled dimension.  Returns (seconds for the full workload, description)."""
+    import scipy.linalg
+    from pyscf_isdf_amd import gto
+    from oracle import ao as oao, isdf as oisdf, pbc_tools as tools
+    rng = np.random.default_rng(0)
+    t_all = time.perf_counter()
+    mesh = np.asarray(cell.mesh)
+    G = int(np.prod(mesh))
+    nao = cell.nao_nr()
+    natm = cell.natm
+    P = gpu_stage_sizes['P']
+    a = cell.lattice_vectors()
+    coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    est = {}
+    # S1 collocation: a contiguous run of grid points
+    n1 = min(G, 16384)
+    t = time.perf_counter()
+    aoT_s = np.ascontiguousarray(oao.eval_ao(cell._atm, cell._bas, cell._env, coords[:n1], Ls, rcut, rule='point').T)
+    est['S1_eval_ao'] = (time.perf_counter() - t) * G / n1
+    # S2 selection: one atom block of average size with its share of points, synthetic AO columns of the right shape
+    m_b = G // natm
+    k_b = max(1, P // natm)
+    reps = max(1, m_b // n1 + 1)
+    ao_blk = np.tile(aoT_s, (1, reps))[:, :m_b] * (1.0 + 0.01 * rng.standard_normal(m_b))
+    t = time.perf_counter()
+    oisdf.select_ip(ao_blk, k_b)
+    est['S2_select_ip'] = (time.perf_counter() - t) * natm
+    # S3 fit: Cholesky of the full A_PP (exact size) + solves on a slice of grid columns
+    aoP = rng.standard_normal((P, nao)) / np.sqrt(nao)
+    t = time.perf_counter()
+    A = aoP.dot(aoP.T) ** 2
+    A[np.diag_indices(P)] += 1e-3 * A.diagonal().max()
+    cf = scipy.linalg.cho_factor(A, overwrite_a=True)
+    t_chol = time.perf_counter() - t
+    n3 = min(G, 1024)
+    t = time.perf_counter()
+    B = aoP.dot(aoT_s[:, :n3]) ** 2
+    theta_s = scipy.linalg.cho_solve(cf, B)
+    est['S3_fit'] = t_chol + (time.perf_counter() - t) * G / n3
+    del A, cf
+    # S4 Coulomb convolution of a few full-grid rows; S5 W rows
+    n4 = 4
+    rows = rng.standard_normal((n4, G))
+    t = time.perf_counter()
+    V = oisdf.coulomb_V(rows, a, mesh)
+    est['S4_coulomb_fft'] = (time.perf_counter() - t) * P / n4
+    n5 = min(G, 65536)
+    th = rng.standard_normal((P, n5))
+    t = time.perf_counter()
+    V[:, :n5].dot(th.T)
+    est['S5_W_gemm'] = (time.perf_counter() - t) * (P / n4) * (G / n5) * 0.5   # symmetric half, like the GPU path
+    del th
+    # S6 J (two N x N x G contractions on a slice) and S7 K (exact size if affordable, else row slice)
+    dm = rng.standard_normal((nao, nao))
+    t = time.perf_counter()
+    tmp = dm.dot(aoT_s)
+    np.einsum('ig,ig->g', tmp, aoT_s)
+    (aoT_s * tmp[0]).dot(aoT_s.T)
+    est['S6_get_j'] = (time.perf_counter() - t) * G / n1
+    n7 = min(P, 1024)
+    Wr = rng.standard_normal((n7, P))
+    t = time.perf_counter()
+    X = aoP.dot(dm)
+    M = X[:n7].dot(aoP.T) * Wr
+    aoP[:n7].T.dot(M.dot(aoP))
+    est['S7_get_k'] = (time.perf_counter() - t) * P / n7
+    total = sum(est.values())
+    sample = ('numpy/scipy oracle, stage samples extrapolated linearly: S1 %d of %d grid points; S2 1 of %d atom blocks '
+              '(%d pts, %d pivots); S3 full %dx%d Cholesky + %d of %d grid columns; S4 %d of %d FFT rows; S5 %d rows x %d cols; '
+              'S6 %d grid points; S7 %d of %d rows; measured %.1f s of CPU work; per-stage estimate (s): %s'
+              % (n1, G, natm, m_b, k_b, P, P, n3, G, n4, P, n4, n5, n1, n7, P, time.perf_counter() - t_all,
+                 {k: round(v, 1) for k, v in est.items()}))
+    return total, sample
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from pyscf_isdf_amd import workloads
+    from pyscf_isdf_amd.isdf import ISDF
+    from pyscf_isdf_amd.parallel import Comm
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    comm = Comm.from_env()
+
+    cell = workloads.make_cell(args.workload)
+    dm, mo_coeff, mo_occ = workloads.make_dm(cell)
+    df = ISDF(cell, c_isdf=args.c_isdf, select=args.select, comm=comm)
+    be = df.backend
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        df.build()
+        return df.get_jk(dm)
+
+    for _ in range(args.warmup):
+        step()
+    be.prof_reset()
+    be.prof_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vj, vk = step()
+    barrier()
+    t1 = time.perf_counter()
+    be.prof_enable(False)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=be.device)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    sec_per_step = elapsed.item() / args.steps
+
+    if rank == 0:
+        prof = be.prof_results()
+        rows = []
+        for name, r in prof.items():
+            kind = 'flop' if name.endswith('[flop]') else 'byte'
+            per_launch_ms = r['ms'] / max(r['launches'], 1)
+            rate = r['work'] / (r['ms'] * 1e-3) if r['ms'] > 0 else 0.0
+            rows.append(dict(kernel=name, launches=r['launches'], total_ms=r['ms'], avg_ms=per_launch_ms,
+                             achieved=(rate / 1e12 if kind == 'flop' else rate / 1e9),
+                             unit=('TFLOP/s' if kind == 'flop' else 'GB/s'),
+                             work_per_launch=r['work'] / max(r['launches'], 1)))
+        rows.sort(key=lambda x: -x['total_ms'])
+        # dominant HAND-WRITTEN kernel (library calls are listed in the stage report, not used for the roofline)
+        own = [r for r in rows if not r['kernel'].startswith(('rocblas', 'rocsolver'))]
+        dom = own[0] if own else rows[0]
+        if dom['unit'] == 'TFLOP/s':
+            roof = dict(bound='mfma', kernel=dom['kernel'], achieved=round(dom['achieved'], 2), peak=FP64_MFMA_PEAK_TFLOPS,
+                        unit='TFLOP/s', frac=round(dom['achieved'] / FP64_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        avg_launch_ms=round(dom['avg_ms'], 3), launches=dom['launches'])
+        else:
+            roof = dict(bound='hbm', kernel=dom['kernel'], achieved=round(dom['achieved'], 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=round(dom['achieved'] / HBM_PEAK_GBS, 4), traffic=None, avg_launch_ms=round(dom['avg_ms'], 3),
+                        launches=dom['launches'])
+        G = int(np.prod(cell.mesh))
+        nao = cell.nao_nr()
+        P = len(df.ip)
+        alg_bytes = 40.0 * G * nao + 40.0 * G * P       # BASELINE.md section 3 (whole-path algorithmic bytes)
+        out = {
+            'metric': 'isdf_build_plus_get_jk_wall_time', 'value': round(sec_per_step, 4), 'unit': 's',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(sec_per_step * 1e3, 2),
+            'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': workloads.WORKLOADS[args.workload][1], 'natm': cell.natm, 'nao': nao, 'ngrids': G,
+                       'nip': P, 'c_isdf': args.c_isdf, 'select': args.select, 'parallelism': 'grid-shard x%d' % world},
+            'whole_path_algorithmic_GBps': round(alg_bytes / sec_per_step / 1e9, 1),
+            'stage_seconds_last_step': {k: round(v, 4) for k, v in df.timings.items()},
+            'energies': {'EJ': float(np.einsum('ij,ji', vj, dm) / 2), 'EK': float(np.einsum('ij,ji', vk, dm) / 4)},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ncores = os.cpu_count() or 1
+            val, sample = cpu_baseline(cell, args.c_isdf, dict(P=P))
+            out['cpu_baseline'] = {'value': round(val, 1), 'unit': 's', 'cores': ncores, 'kind': 'port', 'sample': sample}
+        else:
+            out['cpu_baseline'] = None
+        if args.stage_report:
+            with open(args.stage_report, 'w') as f:
+                f.write('per-kernel table, %d timed steps (HIP events on the work stream)\n' % args.steps)
+                for r in rows:
+                    f.write('%-36s launches %6d  total %10.2f ms  avg %9.3f ms  %8.2f %s\n' %
+                            (r['kernel'], r['launches'], r['total_ms'], r['avg_ms'], r['achieved'], r['unit']))
+                f.write('stage wall times of the last step (s): %s\n' % out['stage_seconds_last_step'])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

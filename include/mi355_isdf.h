@@ -52,6 +52,16 @@ int64_t isdf_workspace_bytes(isdf_handle h);
 /* Release cached workspace and FFT plans (keeps the context usable). */
 int isdf_release_workspace(isdf_handle h);
 
+/* Optional in-library profiling (bench.py's roofline leg): when enabled, the library brackets its
+ * hot kernel launches with HIP events on the work stream and accumulates, per kernel name, the number
+ * of launches, the elapsed milliseconds and the ALGORITHMIC work (bytes for HBM-bound kernels, flops
+ * for MFMA-bound ones; DESIGN.md lists which).  isdf_prof_get synchronises the stream. */
+int isdf_prof_enable(isdf_handle h, int on);
+int isdf_prof_reset(isdf_handle h);
+int isdf_prof_count(isdf_handle h);
+int isdf_prof_get(isdf_handle h, int index, char* name, int name_cap, int64_t* launches,
+                  double* total_ms, double* total_work);
+
 /* S1. Periodic AO collocation, Γ point, real spherical GTOs, l <= 2.
  * Replaces PBCGTOval_sph_deriv0 (pyscf/lib/pbc/grid_ao.c:524-534, driver :439-486, per-shell image
  * loop :301-429; radial/angular parts pyscf/lib/gto/deriv1.c:31-165) as called from

@@ -43,11 +43,34 @@ class HipBackend:
     def to_host(self, t):
         return t.detach().cpu().numpy()
 
+    def empty_cache(self):
+        torch.cuda.empty_cache()
+
     def synchronize(self):
         torch.cuda.synchronize(self.device)
 
     def release_workspace(self):
         self.handle.call('isdf_release_workspace')
+
+    # ---- in-library profiling ------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self.handle.call('isdf_prof_enable', int(bool(on)))
+
+    def prof_reset(self):
+        self.handle.call('isdf_prof_reset')
+
+    def prof_results(self):
+        """{kernel name: dict(launches, ms, work)} accumulated since the last reset."""
+        out = {}
+        n = self.handle.lib.isdf_prof_count(self.handle.h)
+        for i in range(n):
+            name = ctypes.create_string_buffer(128)
+            launches = ctypes.c_int64(0)
+            ms = ctypes.c_double(0)
+            work = ctypes.c_double(0)
+            self.handle.call('isdf_prof_get', i, name, 128, ctypes.byref(launches), ctypes.byref(ms), ctypes.byref(work))
+            out[name.value.decode()] = dict(launches=launches.value, ms=ms.value, work=work.value)
+        return out
 
     def _stream(self):
         s = torch.cuda.current_stream(self.device).cuda_stream

@@ -17,7 +17,21 @@ struct FftPlan {
   size_t work_bytes = 0;
 };
 
+// Optional in-library profiling: HIP event pairs on the work stream around named kernel launches,
+// with the algorithmic work (bytes or flops) each launch stands for.  Off by default.
+struct ProfRec {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+struct ProfEntry {
+  std::vector<ProfRec> recs;
+  double work = 0.0;        // summed algorithmic work
+  double ms = 0.0;          // resolved on query
+  int64_t launches = 0;
+};
+
 struct isdf_ctx {
+  int profiling = 0;
+  std::map<std::string, ProfEntry> prof;
   int device = 0;
   hipStream_t stream = nullptr;
   rocblas_handle blas = nullptr;
@@ -62,6 +76,26 @@ int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out
   } while (0)
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// RAII marker: records event pairs around the launches issued during its lifetime when profiling is on.
+struct ProfScope {
+  isdf_handle h;
+  ProfRec rec;
+  ProfEntry* ent = nullptr;
+  ProfScope(isdf_handle h_, const char* name, double work, int64_t launches = 1) : h(h_) {
+    if (!h || !h->profiling) return;
+    ent = &h->prof[name];
+    ent->work += work;
+    ent->launches += launches;
+    if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) { ent = nullptr; return; }
+    (void)hipEventRecord(rec.e0, h->stream);
+  }
+  ~ProfScope() {
+    if (!ent) return;
+    (void)hipEventRecord(rec.e1, h->stream);
+    ent->recs.push_back(rec);
+  }
+};
 
 // ---- dense FP64 helpers implemented in gemm_f64.hip -------------------------------------------
 // C (M x N row-major, ldc) = alpha * A (M x K row-major, lda) * B(N x K row-major, ldb)^T + beta * C

@@ -91,6 +91,8 @@ static int convolve_rows(isdf_handle h, const double* d_in, double* d_out, int n
   FftPlan* plan = nullptr;
   int rc = isdf_get_plan(h, mesh, nb, &plan);
   if (rc) return rc;
+  const int64_t Gfull = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  ProfScope ps(h, "coulomb_conv_d2z_mul_z2d[byte]", 32.0 * (double)Gfull * nb, 3);
   FFT_TRY(h, hipfftExecD2Z(plan->fwd, (hipfftDoubleReal*)d_in, (hipfftDoubleComplex*)zbuf));
   const int64_t total = gc * nb;
   const unsigned nblocks = (unsigned)std::min<int64_t>(cdiv(total, 256), (int64_t)h->num_cu * 16);

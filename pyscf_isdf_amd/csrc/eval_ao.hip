@@ -234,6 +234,7 @@ extern "C" int isdf_eval_ao(isdf_handle h, const int32_t* atm, int natm, const i
 
   dim3 grid((unsigned)cdiv(ngrids, TPB), (unsigned)natm);
   ARG_CHECK(h, natm <= 65535);
+  ProfScope ps(h, "eval_ao_kernel[byte]", 8.0 * (double)ngrids * ao0);
   hipLaunchKernelGGL(eval_ao_kernel, grid, dim3(TPB), (size_t)nimgs * sizeof(int), h->stream,
                      d_atoms, d_shells, d_env, d_Ls, nimgs, d_coords, ngrids, d_ao, ld);
   KERNEL_CHECK(h);

@@ -3,6 +3,7 @@
 //   (b) for an arbitrary point set:  Theta = [(aoP aoP^T)^2]^-1 (aoP ao)^2  by Cholesky
 // The triangular solves run over all G right-hand sides in place on the (P, G) row-major array.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -99,7 +100,8 @@ extern "C" int isdf_fit_prepare(isdf_handle h, const double* d_ao, int nao, int6
                          maxdiag, reg);
     }
     KERNEL_CHECK(h);
-    BLAS_TRY(h, rocsolver_dpotrf(h->blas, rocblas_fill_upper, P, d_chol, P, info));
+    { ProfScope ps(h, "rocsolver_dpotrf[flop]", (double)P * P * P / 3.0);
+    BLAS_TRY(h, rocsolver_dpotrf(h->blas, rocblas_fill_upper, P, d_chol, P, info)); }
     int h_info = 0;
     HIP_TRY(h, hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -126,39 +128,46 @@ extern "C" int isdf_fit_apply(isdf_handle h, const double* d_chol, const double*
   hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(ng, 256), (unsigned)P), dim3(256), 0, h->stream,
                      d_theta, (int64_t)P, ng, ldt);
   KERNEL_CHECK(h);
-  // Theta = A^-1 B with A = Lr Lr^T (Lr = the factor read row-major, lower).  Blocked triangular
-  // solves: the diagonal blocks go to rocBLAS TRSM (a few % of the flops), the trailing updates are
-  // plain GEMMs of shape (rows x ng x NB), which run at the MFMA rate; a monolithic rocBLAS TRSM
-  // reaches only ~43 TF/s on this shape (profiles/r01_probe_rocblas_hipfft_mfma64.log).
+  // Theta = A^-1 B with A = Lr Lr^T (Lr = the factor read row-major, lower).  Blocked LEFT-looking
+  // triangular solves: block row jb first receives the contribution of all finished block rows in
+  // ONE deep GEMM (NB x ng x K, K up to P: the shape rocBLAS runs at the MFMA rate, and it only
+  // READS the finished rows), then a small TRSM with the diagonal block.  A monolithic rocBLAS TRSM
+  // reaches ~43 TF/s here (profiles/r01_probe_rocblas_hipfft_mfma64.log), a right-looking variant is
+  // bound by re-reading and re-writing the trailing rows at every step.
   const double one = 1.0;
-  const int NB = 512;
+  int NB = 512;
+  if (const char* e = getenv("ISDF_TRSM_NB")) NB = std::max(64, atoi(e));
+  const int nblk = (int)cdiv(P, NB);
   // forward: Y = Lr^-1 B
-  for (int jb = 0; jb < P; jb += NB) {
+  for (int b = 0; b < nblk; ++b) {
+    const int jb = b * NB;
     const int nb = std::min(NB, P - jb);
+    if (jb > 0) {
+      // B[jb:jb+nb] -= Lr[jb:jb+nb, :jb] Y[:jb]
+      rc = gemm_rm(h, 'N', 'N', nb, ng, jb, -1.0, d_chol + (int64_t)jb * P, P, d_theta, ldt, 1.0,
+                   d_theta + (int64_t)jb * ldt, ldt);
+      if (rc) return rc;
+    }
+    ProfScope ps(h, "rocblas_dtrsm[flop]", (double)ng * nb * nb);
     BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
                               rocblas_diagonal_non_unit, (rocblas_int)ng, nb, &one,
                               d_chol + (int64_t)jb * P + jb, P, d_theta + (int64_t)jb * ldt, (rocblas_int)ldt));
-    const int j1 = jb + nb;
-    if (j1 < P) {
-      rc = gemm_rm(h, 'N', 'N', P - j1, ng, nb, -1.0, d_chol + (int64_t)j1 * P + jb, P,
-                   d_theta + (int64_t)jb * ldt, ldt, 1.0, d_theta + (int64_t)j1 * ldt, ldt);
-      if (rc) return rc;
-    }
   }
   // backward: Theta = Lr^-T Y
-  const int nblk = (int)cdiv(P, NB);
   for (int b = nblk - 1; b >= 0; --b) {
     const int jb = b * NB;
     const int nb = std::min(NB, P - jb);
+    const int j1 = jb + nb;
+    if (j1 < P) {
+      // Y[jb:j1] -= Lr[j1:, jb:j1]^T Theta[j1:]
+      rc = gemm_rm(h, 'T', 'N', nb, ng, P - j1, -1.0, d_chol + (int64_t)j1 * P + jb, P,
+                   d_theta + (int64_t)j1 * ldt, ldt, 1.0, d_theta + (int64_t)jb * ldt, ldt);
+      if (rc) return rc;
+    }
+    ProfScope ps(h, "rocblas_dtrsm[flop]", (double)ng * nb * nb);
     BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_transpose,
                               rocblas_diagonal_non_unit, (rocblas_int)ng, nb, &one,
                               d_chol + (int64_t)jb * P + jb, P, d_theta + (int64_t)jb * ldt, (rocblas_int)ldt));
-    if (jb > 0) {
-      // Y[:jb] -= Lr[jb:jb+nb, :jb]^T Theta[jb:jb+nb]
-      rc = gemm_rm(h, 'T', 'N', jb, ng, nb, -1.0, d_chol + (int64_t)jb * P, P,
-                   d_theta + (int64_t)jb * ldt, ldt, 1.0, d_theta, ldt);
-      if (rc) return rc;
-    }
   }
   return ISDF_OK;
 }

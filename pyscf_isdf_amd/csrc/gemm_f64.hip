@@ -25,6 +25,7 @@ int gemm_rm(isdf_handle h, char opA, char opB, int64_t M, int64_t N, int64_t K, 
                    ldb < 2147483647LL && ldc < 2147483647LL);
   const rocblas_operation ta = (opA == 'N') ? rocblas_operation_none : rocblas_operation_transpose;
   const rocblas_operation tb = (opB == 'N') ? rocblas_operation_none : rocblas_operation_transpose;
+  ProfScope ps(h, "rocblas_dgemm[flop]", 2.0 * M * N * (double)K);
   BLAS_TRY(h, rocblas_dgemm(h->blas, tb, ta, (rocblas_int)N, (rocblas_int)M, (rocblas_int)K, &alpha, B,
                             (rocblas_int)ldb, A, (rocblas_int)lda, &beta, C, (rocblas_int)ldc));
   return ISDF_OK;
@@ -220,6 +221,7 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
                     (((uintptr_t)A) % 16 == 0) && (((uintptr_t)B) % 16 == 0) &&
                     (!kscale || ((uintptr_t)kscale) % 16 == 0);
   ARG_CHECK(h, g.nunits_pad < 2147483647LL);
+  ProfScope ps(h, "gemm_nt_mfma_kernel[flop]", 2.0 * M * N * (double)K);
   if (fast) hipLaunchKernelGGL(gemm_nt_mfma_kernel<true>, dim3((unsigned)g.nunits_pad), dim3(TPB), 0, h->stream, g);
   else hipLaunchKernelGGL(gemm_nt_mfma_kernel<false>, dim3((unsigned)g.nunits_pad), dim3(TPB), 0, h->stream, g);
   KERNEL_CHECK(h);

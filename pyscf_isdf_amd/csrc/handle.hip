@@ -57,7 +57,7 @@ int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out
 
 extern "C" {
 
-int isdf_abi_version(void) { return 2; }
+int isdf_abi_version(void) { return 3; }
 
 int isdf_create(int device_id, isdf_handle* out) {
   if (!out) return ISDF_ERR_ARG;
@@ -98,6 +98,7 @@ int isdf_release_workspace(isdf_handle h) {
 
 int isdf_destroy(isdf_handle h) {
   if (!h) return ISDF_OK;
+  isdf_prof_reset(h);
   isdf_release_workspace(h);
   if (h->blas) rocblas_destroy_handle(h->blas);
   delete h;
@@ -116,6 +117,41 @@ int isdf_set_stream(isdf_handle h, void* hip_stream) {
 }
 
 const char* isdf_last_error(isdf_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int isdf_prof_enable(isdf_handle h, int on) {
+  if (!h) return ISDF_ERR_ARG;
+  h->profiling = on ? 1 : 0;
+  return ISDF_OK;
+}
+
+int isdf_prof_reset(isdf_handle h) {
+  if (!h) return ISDF_ERR_ARG;
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& kv : h->prof)
+    for (auto& r : kv.second.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  h->prof.clear();
+  return ISDF_OK;
+}
+
+int isdf_prof_count(isdf_handle h) { return h ? (int)h->prof.size() : 0; }
+
+int isdf_prof_get(isdf_handle h, int index, char* name, int name_cap, int64_t* launches, double* total_ms,
+                  double* total_work) {
+  if (!h || index < 0 || index >= (int)h->prof.size()) return ISDF_ERR_ARG;
+  auto it = h->prof.begin();
+  std::advance(it, index);
+  (void)hipStreamSynchronize(h->stream);
+  double ms = 0.0;
+  for (auto& r : it->second.recs) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) ms += t;
+  }
+  if (name && name_cap > 0) { strncpy(name, it->first.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (launches) *launches = it->second.launches;
+  if (total_ms) *total_ms = ms;
+  if (total_work) *total_work = it->second.work;
+  return ISDF_OK;
+}
 
 int64_t isdf_workspace_bytes(isdf_handle h) {
   if (!h) return 0;

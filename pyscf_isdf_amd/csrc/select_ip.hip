@@ -240,6 +240,7 @@ extern "C" int isdf_select_ip(isdf_handle h, const double* d_ao, int nao, int64_
     hipLaunchKernelGGL(take_pivot_kernel, dim3(nblk), dim3(TPB), 0, h->stream, d_ao, nao, ld, d_L, ldL,
                        d_d, d_off, d_nip, j, tol, kmax, d_st, d_piv, d_pv, d_pl);
     if (j == kmax) break;   // the last take_pivot only marks every block done
+    ProfScope ps(h, "select_update_kernel[byte]", 8.0 * (double)mtot * (nao + j + 3));
     hipLaunchKernelGGL(update_kernel, dim3(nwg), dim3(TPB), sizeof(double) * ((size_t)nao + j), h->stream,
                        d_ao, nao, ld, d_L, ldL, d_d, d_wg_blk, d_wg_lo, d_off, j, kmax, d_st, d_pv, d_pl);
   }

@@ -155,6 +155,8 @@ class ISDF:
         self.check_sanity()
         cell, be = self.cell, self.backend
         self.timings = {}
+        self.ao = self.aoP = self.W = None
+        be.empty_cache()                 # the (P, G) fit buffer needs one contiguous segment
         t0 = time.perf_counter()
         mesh = np.asarray(self.mesh, dtype=np.int32)
         G = int(np.prod(mesh))
@@ -206,6 +208,7 @@ class ISDF:
             piv = be.empty((cell.natm, kmax), dtype=torch.int64)
             rank = be.select_ip(ao_sel, blk_off, nip, -1.0, self.tie_rtol, L, piv)
             del ao_sel, L
+            be.empty_cache()
             piv_h = be.to_host(piv)
             ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(cell.natm)])
             self.ip = ip.astype(np.int64)
@@ -224,6 +227,7 @@ class ISDF:
         be.coulomb_W(theta, mesh, a, 0, P, batch, self.W, upper_only=True)
         be.symmetrize_upper(self.W)
         del theta
+        be.empty_cache()
         t0 = self._tick('S4S5_coulomb_W', t0)
         self._built = True
         return self

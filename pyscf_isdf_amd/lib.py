@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -24,6 +24,10 @@ SIGNATURES = {
     'isdf_last_error': (ctypes.c_char_p, [c_vp]),
     'isdf_workspace_bytes': (c_i64, [c_vp]),
     'isdf_release_workspace': (c_int, [c_vp]),
+    'isdf_prof_enable': (c_int, [c_vp, c_int]),
+    'isdf_prof_reset': (c_int, [c_vp]),
+    'isdf_prof_count': (c_int, [c_vp]),
+    'isdf_prof_get': (c_int, [c_vp, c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]),
     'isdf_eval_ao': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_i64]),
     'isdf_gather_cols': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_i64]),
     'isdf_select_ip': (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_i64, c_vp, c_vp]),

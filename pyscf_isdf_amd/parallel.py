@@ -1,0 +1,44 @@
+"""Process-group plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+the GPU box, "gloo" in CPU tests).  Only thin wrappers; every collective the ISDF path issues is
+listed here so the communication pattern can be read in one place (multi-GPU section)."""
+import os
+import torch
+import torch.distributed as dist
+
+
+class Comm:
+    def __init__(self, rank=0, size=1, local_rank=0, group=None):
+        self.rank, self.size, self.local_rank, self.group = rank, size, local_rank, group
+
+    @classmethod
+    def from_env(cls):
+        if dist.is_available() and dist.is_initialized():
+            return cls(dist.get_rank(), dist.get_world_size(), int(os.environ.get('LOCAL_RANK', '0')))
+        return cls()
+
+    def split_range(self, n, r=None):
+        """Contiguous share [lo, hi) of range(n) for rank r (default: this rank)."""
+        r = self.rank if r is None else r
+        base, rem = divmod(n, self.size)
+        lo = r * base + min(r, rem)
+        return lo, lo + base + (1 if r < rem else 0)
+
+    def all_reduce_sum(self, t):
+        if self.size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_gather_rows(self, t_local, counts):
+        """Concatenate row blocks of unequal height (counts[r] rows from rank r)."""
+        if self.size == 1:
+            return t_local
+        mx = max(counts)
+        pad = torch.zeros((mx,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
+        pad[:t_local.shape[0]] = t_local
+        bufs = [torch.empty_like(pad) for _ in range(self.size)]
+        dist.all_gather(bufs, pad, group=self.group)
+        return torch.cat([bufs[r][:counts[r]] for r in range(self.size)], dim=0)
+
+    def barrier(self):
+        if self.size > 1:
+            dist.barrier(group=self.group)
