@@ -131,6 +131,11 @@ int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, 
 int isdf_coulomb_W(isdf_handle h, const double* d_theta, int P, int64_t ldt,
                    const int32_t mesh[3], const double a[9],
                    int row0, int nrows, int batch, int upper_only, double* d_W, int64_t ldw);
+/* S4 alone: d_out rows = ifft(coulG * fft(d_in rows)).real (no weight), rows of length G contiguous
+ * (ld == ldo == G); in place allowed.  Used by the grid-sharded multi-GPU path, where the rows are
+ * assembled by an all-to-all before and scattered by another one after this call. */
+int isdf_coulomb_rows(isdf_handle h, const double* d_in, int nrows, int64_t ld,
+                      const int32_t mesh[3], const double a[9], int batch, double* d_out, int64_t ldo);
 /* W[q][p] = W[p][q] for q > p. */
 int isdf_symmetrize_upper(isdf_handle h, double* d_W, int P, int64_t ldw);
 

@@ -146,6 +146,15 @@ class HipBackend:
         self.handle.call('isdf_coulomb_W', self._p(theta), theta.shape[0], theta.stride(0), _np_ptr(mesh), _np_ptr(a),
                          int(row0), int(nrows), int(batch), int(bool(upper_only)), self._p(W), W.stride(0))
 
+    def coulomb_rows(self, rows, mesh, a, batch, out=None):
+        """out rows = ifft(coulG fft(rows)).real; rows (n, G) contiguous; in place when out is None."""
+        self._stream()
+        out = rows if out is None else out
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self.handle.call('isdf_coulomb_rows', self._p(rows), rows.shape[0], rows.stride(0), _np_ptr(mesh), _np_ptr(a),
+                         int(batch), self._p(out), out.stride(0))
+
     def symmetrize_upper(self, W):
         self._stream()
         self.handle.call('isdf_symmetrize_upper', self._p(W), W.shape[0], W.stride(0))

@@ -180,3 +180,26 @@ extern "C" int isdf_coulomb_potential(isdf_handle h, double* d_rho, int nset, in
   if (!Z) return ISDF_ERR_HIP;
   return convolve_rows(h, d_rho, d_rho, nset, mesh, cg, Z);
 }
+
+extern "C" int isdf_coulomb_rows(isdf_handle h, const double* d_in, int nrows, int64_t ld,
+                                 const int32_t mesh[3], const double a[9], int batch, double* d_out,
+                                 int64_t ldo) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_in && d_out && mesh && a && nrows >= 0 && batch > 0);
+  const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  const int64_t gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
+  ARG_CHECK(h, ld == G && ldo == G);
+  if (nrows == 0) return ISDF_OK;
+  if (batch > nrows) batch = nrows;
+  double* cg = nullptr;
+  int rc = get_coulG_half(h, mesh, a, 1.0, &cg);
+  if (rc) return rc;
+  double2* Z = (double2*)isdf_ws(h, "coul_Z", sizeof(double2) * (size_t)batch * gc);
+  if (!Z) return ISDF_ERR_HIP;
+  for (int r = 0; r < nrows; r += batch) {
+    const int nb = std::min(batch, nrows - r);
+    rc = convolve_rows(h, d_in + (int64_t)r * ld, d_out + (int64_t)r * ldo, nb, mesh, cg, Z);
+    if (rc) return rc;
+  }
+  return ISDF_OK;
+}

@@ -135,7 +135,7 @@ extern "C" int isdf_fit_apply(isdf_handle h, const double* d_chol, const double*
   // reaches ~43 TF/s here (profiles/r01_probe_rocblas_hipfft_mfma64.log), a right-looking variant is
   // bound by re-reading and re-writing the trailing rows at every step.
   const double one = 1.0;
-  int NB = 512;
+  int NB = 1024;
   if (const char* e = getenv("ISDF_TRSM_NB")) NB = std::max(64, atoi(e));
   const int nblk = (int)cdiv(P, NB);
   // forward: Y = Lr^-1 B

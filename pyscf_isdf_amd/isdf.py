@@ -77,6 +77,7 @@ class ISDF:
         self._comm = comm
         self._rsh_df = {}
         self._built = False
+        self._bufs = {}
         self.timings = {}
         # device state
         self.ao = None        # (nao, G)
@@ -109,6 +110,9 @@ class ISDF:
             self.cell = cell
         self.grids = UniformGrids(self.cell, self.cell.mesh)
         self.ao = self.aoP = self.W = self.ip = None
+        self._bufs = {}
+        if self._backend is not None:
+            self._backend.empty_cache()
         self._rsh_df = {}
         self._built = False
         return self
@@ -141,6 +145,19 @@ class ISDF:
         return mf
 
     # ---- build ---------------------------------------------------------------------------------
+    def _buffer(self, name, shape, dtype=torch.float64):
+        """Persistent device buffer, reused across builds: releasing and re-mapping the (P, G) fit
+        buffer (214 GiB at 4x4x4) costs seconds per build, so the big buffers live until reset()."""
+        n = int(np.prod(shape))
+        buf = self._bufs.get(name)
+        if buf is None or buf.numel() < n or buf.dtype != dtype:
+            self._bufs.pop(name, None)
+            buf = None
+            self.backend.empty_cache()
+            buf = self.backend.empty((n,), dtype=dtype)
+            self._bufs[name] = buf
+        return buf[:n].view(*shape)
+
     def _tick(self, name, t0):
         self.backend.synchronize()
         t1 = time.perf_counter()
@@ -151,12 +168,19 @@ class ISDF:
         aosl = _aoslice_by_atom(self.cell)
         return (np.asarray(aosl[:, 1] - aosl[:, 0]) * self.c_isdf).astype(np.int32)
 
+    @property
+    def comm(self):
+        if self._comm is None:
+            from .parallel import Comm
+            self._comm = Comm()
+        return self._comm
+
     def build(self):
         self.check_sanity()
+        if self.comm.size > 1:
+            return self._build_sharded()
         cell, be = self.cell, self.backend
         self.timings = {}
-        self.ao = self.aoP = self.W = None
-        be.empty_cache()                 # the (P, G) fit buffer needs one contiguous segment
         t0 = time.perf_counter()
         mesh = np.asarray(self.mesh, dtype=np.int32)
         G = int(np.prod(mesh))
@@ -170,7 +194,7 @@ class ISDF:
 
         # S1 collocation
         coords_soa = be.to_device(np.ascontiguousarray(coords.T))
-        self.ao = be.empty((nao, G))
+        self.ao = self._buffer('ao', (nao, G))
         be.eval_ao(*self._ao_args, coords_soa, self.ao)
         del coords_soa
         t0 = self._tick('S1_eval_ao', t0)
@@ -178,7 +202,7 @@ class ISDF:
         # S2 + S3 selection and fit
         if self.select == 'global':
             P = int(min(self.c_isdf * nao, G))
-            theta = be.empty((P, G))
+            theta = self._buffer('theta', (P, G))
             piv = be.empty((1, P), dtype=torch.int64)
             rank = be.select_ip(self.ao, [0, G], [P], -1.0, self.tie_rtol, theta, piv)
             P = int(rank[0])
@@ -187,7 +211,7 @@ class ISDF:
             piv = piv[0, :P].contiguous()
             be.fit_from_chol(theta, P, G, piv)
             self.ip = be.to_host(piv).astype(np.int64)
-            self.aoP = be.empty((P, nao))
+            self.aoP = self._buffer('aoP', (P, nao))
             tmp = be.empty((nao, P))
             be.gather_cols(self.ao, piv, tmp)
             self.aoP.copy_(tmp.T)
@@ -202,32 +226,34 @@ class ISDF:
             kmax = int(nip.max())
             t0 = self._tick('host_partition', t0)
             d_perm = be.to_device(perm)
-            ao_sel = be.empty((nao, G))
+            # the block-major copy of phi and the Cholesky rows are scratch that dies before the fit:
+            # they live inside the (P, G) fit buffer, which is not in use yet
+            Pmax = int(nip.sum())
+            scratch = self._buffer('theta', (max(Pmax, nao + kmax), G))
+            ao_sel = scratch[:nao]
+            L = scratch[nao:nao + kmax]
             be.gather_cols(self.ao, d_perm, ao_sel)
-            L = be.empty((kmax, G))
             piv = be.empty((cell.natm, kmax), dtype=torch.int64)
             rank = be.select_ip(ao_sel, blk_off, nip, -1.0, self.tie_rtol, L, piv)
-            del ao_sel, L
-            be.empty_cache()
+            del ao_sel, L, scratch
             piv_h = be.to_host(piv)
             ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(cell.natm)])
             self.ip = ip.astype(np.int64)
             P = len(ip)
             t0 = self._tick('S2_select_ip', t0)
-            theta = be.empty((P, G))
-            self.aoP = be.empty((P, nao))
+            theta = self._buffer('theta', (max(Pmax, nao + kmax), G))[:P]
+            self.aoP = self._buffer('aoP', (P, nao))
             self.reg_used = be.fit_global(self.ao, G, be.to_device(self.ip), self.reg_rel, theta, self.aoP)
             t0 = self._tick('S3_fit', t0)
         else:
             raise ValueError("select must be 'local' or 'global'")
 
         # S4 + S5 Coulomb convolution and W
-        self.W = be.empty((P, P))
+        self.W = self._buffer('W', (P, P))
         batch = self.fft_batch or _default_fft_batch(G, P)
         be.coulomb_W(theta, mesh, a, 0, P, batch, self.W, upper_only=True)
         be.symmetrize_upper(self.W)
         del theta
-        be.empty_cache()
         t0 = self._tick('S4S5_coulomb_W', t0)
         self._built = True
         return self
@@ -260,6 +286,8 @@ class ISDF:
         d_dm = be.to_device(dms)
         vj = vk = None
         t0 = time.perf_counter()
+        if self.comm.size > 1:
+            return self._get_jk_sharded(d_dm, dm_in.shape, with_j, with_k)
         if with_j:
             d_vj = be.empty((nset, nao, nao))
             be.get_j(self.ao, G, mesh, a, d_dm, d_vj)
@@ -271,6 +299,155 @@ class ISDF:
             be.get_k(self.aoP, self.W, 0, P, d_dm, d_vk)
             t0 = self._tick('S7_get_k', t0)
             vk = be.to_host(d_vk).reshape(dm_in.shape)
+        return vj, vk
+
+
+    # ---- multi-GPU: grid-sharded build, row-sharded K (DESIGN.md "Multi-GPU") -------------------------
+    def _build_sharded(self):
+        """Every rank owns a contiguous slice S_r of the grid (natural order).
+
+        S1  collocation on the slice                               no communication
+        S2  per-atom selection, atom blocks dealt round-robin       all_gather of the point lists (P ints)
+        S3  A_PP Cholesky replicated (P^3/3, small); fit on slice   no communication
+        S4  rows of Theta assembled by all-to-all, FFT convolution, scattered back by all-to-all
+        S5  W_r = w V[:, S_r] Theta[:, S_r]^T                       all_reduce(W)  (RCCL over xGMI)
+        Streaming over row batches bounds memory at any rank count.
+        """
+        cell, be, comm = self.cell, self.backend, self.comm
+        if self.select != 'local':
+            raise NotImplementedError("multi-GPU build needs select='local'")
+        R, rk = comm.size, comm.rank
+        self.timings = {}
+        t0 = time.perf_counter()
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        nao = cell.nao_nr()
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        coords = self.grids.coords
+        rcut = gto.estimate_rcut_per_shell(cell)
+        Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+        ao_args = (np.asarray(cell._atm), np.asarray(cell._bas), np.asarray(cell._env), Ls, rcut)
+        g0, g1 = comm.split_range(G)
+        self._slice = (g0, g1)
+        ng = g1 - g0
+        t0 = self._tick('host_setup', t0)
+
+        # S1 on the slice
+        self.ao = self._buffer('ao', (nao, ng))
+        be.eval_ao(*ao_args, be.to_device(np.ascontiguousarray(coords[g0:g1].T)), self.ao)
+        t0 = self._tick('S1_eval_ao', t0)
+
+        # S2 selection on this rank's atom blocks
+        owner = partition_grid_by_atom(coords, cell.atom_coords(), a)
+        perm = np.argsort(owner, kind='stable').astype(np.int64)
+        counts = np.bincount(owner, minlength=cell.natm)
+        blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)
+        nip = np.minimum(self.nip_per_atom(), counts).astype(np.int32)
+        mine = [b for b in range(cell.natm) if b % R == rk and nip[b] > 0]
+        t0 = self._tick('host_partition', t0)
+        my_ips = {}
+        if mine:
+            idx = np.concatenate([perm[blk_off[b]:blk_off[b + 1]] for b in mine])
+            loc_off = np.append(0, np.cumsum([counts[b] for b in mine])).astype(np.int64)
+            ao_sel = be.empty((nao, len(idx)))
+            be.eval_ao(*ao_args, be.to_device(np.ascontiguousarray(coords[idx].T)), ao_sel)
+            kmax = int(max(nip[b] for b in mine))
+            L = be.empty((kmax, len(idx)))
+            piv = be.empty((len(mine), kmax), dtype=torch.int64)
+            rank = be.select_ip(ao_sel, loc_off, [nip[b] for b in mine], -1.0, self.tie_rtol, L, piv)
+            piv_h = be.to_host(piv)
+            for k, b in enumerate(mine):
+                my_ips[b] = idx[loc_off[k] + piv_h[k, :rank[k]]]
+            del ao_sel, L, piv
+        all_ips = comm.all_gather_object(my_ips)
+        merged = {}
+        for d in all_ips:
+            merged.update(d)
+        self.ip = np.concatenate([merged[b] for b in sorted(merged)]).astype(np.int64)
+        P = len(self.ip)
+        t0 = self._tick('S2_select_ip', t0)
+
+        # S3: phi at the points (tiny collocation, replicated), Cholesky replicated, fit on the slice
+        aoP_T = be.empty((nao, P))
+        be.eval_ao(*ao_args, be.to_device(np.ascontiguousarray(coords[self.ip].T)), aoP_T)
+        self.aoP = self._buffer('aoP', (P, nao))
+        chol = self._buffer('chol', (P, P))
+        self.reg_used = be.fit_prepare(aoP_T, be.to_device(np.arange(P, dtype=np.int64)), self.reg_rel, self.aoP, chol)
+        del aoP_T
+        theta = self._buffer('theta', (P, ng))
+        be.fit_apply(chol, self.aoP, self.ao, ng, theta)
+        del chol
+        t0 = self._tick('S3_fit', t0)
+
+        # S4 + S5 streamed over row batches: rank q convolves rows P_q[t*nb : (t+1)*nb] in step t
+        w = cell.vol / G
+        self.W = self._buffer('W', (P, P))
+        self.W.zero_()
+        slices = [comm.split_range(G, r) for r in range(R)]
+        rows = [comm.split_range(P, r) for r in range(R)]
+        nb = self.fft_batch or _default_fft_batch(G, max(1, P // R))
+        nsteps = max(-(-(hi - lo) // nb) for lo, hi in rows)
+        for t in range(nsteps):
+            bat = [(min(lo + t * nb, hi), min(lo + (t + 1) * nb, hi)) for lo, hi in rows]   # rows handled by rank q
+            nrow = [hi - lo for lo, hi in bat]
+            # all-to-all 1: send Theta[bat_q, S_r] to q; receive Theta[bat_r, S_q] from q
+            send = [theta[lo:hi] for lo, hi in bat]
+            recv = [be.empty((nrow[rk], s1 - s0)) for s0, s1 in slices]
+            comm.all_to_all(recv, send)
+            full = be.empty((nrow[rk], G))
+            for (s0, s1), piece in zip(slices, recv):
+                full[:, s0:s1] = piece
+            del recv
+            if nrow[rk]:
+                be.coulomb_rows(full, mesh, a, max(1, nrow[rk]))
+            # all-to-all 2: send V[bat_r, S_q] to q; receive V[bat_q, S_r] from q
+            send = [full[:, s0:s1].contiguous() for s0, s1 in slices]
+            recv = [be.empty((nrow[q], ng)) for q in range(R)]
+            comm.all_to_all(recv, send)
+            del full, send
+            for q in range(R):
+                if nrow[q]:
+                    # W[bat_q, :] += w V[bat_q, S_r] Theta[:, S_r]^T   (partial over this rank's slice)
+                    be.gemm_nt(recv[q], theta, self.W[bat[q][0]:bat[q][1]], alpha=w, beta=0.0)
+            del recv
+        del theta
+        comm.all_reduce_sum(self.W)
+        t0 = self._tick('S4S5_coulomb_W', t0)
+        self._built = True
+        return self
+
+    def _get_jk_sharded(self, d_dm, out_shape, with_j, with_k):
+        cell, be, comm = self.cell, self.backend, self.comm
+        nao = cell.nao_nr()
+        nset = d_dm.shape[0]
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        g0, g1 = self._slice
+        vj = vk = None
+        t0 = time.perf_counter()
+        if with_j:
+            # rho on the slice -> all_reduce of the zero-padded density -> potential (replicated FFT) ->
+            # vj partial from the slice -> all_reduce
+            rho = be.zeros((nset, G))
+            rho_loc = be.empty((nset, g1 - g0))
+            be.rho(self.ao, g1 - g0, d_dm, rho_loc)
+            rho[:, g0:g1] = rho_loc
+            comm.all_reduce_sum(rho)
+            be.coulomb_potential(rho, mesh, a)
+            d_vj = be.empty((nset, nao, nao))
+            be.vj_from_vR(self.ao, g1 - g0, rho[:, g0:g1].contiguous(), d_vj)
+            comm.all_reduce_sum(d_vj)
+            t0 = self._tick('S6_get_j', t0)
+            vj = be.to_host(d_vj).reshape(out_shape)
+        if with_k:
+            P = self.W.shape[0]
+            r0, r1 = comm.split_range(P)
+            d_vk = be.empty((nset, nao, nao))
+            be.get_k(self.aoP, self.W, r0, r1 - r0, d_dm, d_vk)
+            comm.all_reduce_sum(d_vk)
+            t0 = self._tick('S7_get_k', t0)
+            vk = be.to_host(d_vk).reshape(out_shape)
         return vj, vk
 
     # ---- ERIs from the factorisation (small systems; reached from SCF.get_jk's incore branch,
@@ -307,6 +484,10 @@ def _aoslice_by_atom(cell):
 
 
 def _default_fft_batch(G, P):
-    """Rows per FFT batch: ~6 GiB for the real batch + ~6 GiB for its half spectrum."""
-    nb = int((6 << 30) // (8 * G))
-    return max(1, min(P, nb, 1024))
+    """Rows per FFT batch: up to ~7 GiB for the real batch (+ as much for its half spectrum), a
+    multiple of the GEMM's 128-row tile so that no MFMA work is wasted on padding."""
+    nb = int((7 << 30) // (8 * G))
+    nb = min(P, nb, 1024)
+    if nb >= 128:
+        nb -= nb % 128
+    return max(1, nb)

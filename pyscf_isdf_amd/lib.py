@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -36,6 +36,7 @@ SIGNATURES = {
     'isdf_fit_apply': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64]),
     'isdf_fit_global': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_vp, c_i64, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_coulomb_W': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64]),
+    'isdf_coulomb_rows': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_vp, c_i64]),
     'isdf_symmetrize_upper': (c_int, [c_vp, c_vp, c_int, c_i64]),
     'isdf_get_j': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_vp]),
     'isdf_rho': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_i64]),

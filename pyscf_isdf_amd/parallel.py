@@ -39,6 +39,33 @@ class Comm:
         dist.all_gather(bufs, pad, group=self.group)
         return torch.cat([bufs[r][:counts[r]] for r in range(self.size)], dim=0)
 
+    def all_gather_object(self, obj):
+        if self.size == 1:
+            return [obj]
+        out = [None] * self.size
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def all_to_all(self, recv, send):
+        """recv[q] <- what rank q put in its send[self.rank]; lists of contiguous tensors."""
+        if self.size == 1:
+            recv[0].copy_(send[0])
+            return
+        send = [s.contiguous() for s in send]
+        if dist.get_backend(self.group) == 'gloo':
+            # gloo has no all_to_all: pairwise exchange (CPU tests only)
+            reqs = []
+            for q in range(self.size):
+                if q == self.rank:
+                    recv[q].copy_(send[q])
+                else:
+                    reqs.append(dist.isend(send[q], q, group=self.group))
+                    reqs.append(dist.irecv(recv[q], q, group=self.group))
+            for r in reqs:
+                r.wait()
+        else:
+            dist.all_to_all(recv, send, group=self.group)
+
     def barrier(self):
         if self.size > 1:
             dist.barrier(group=self.group)

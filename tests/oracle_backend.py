@@ -1,0 +1,125 @@
+"""A checker backend with the method set of pyscf_isdf_amd.backend.HipBackend, computing every stage
+with the CPU oracle on CPU torch tensors.  TEST-ONLY: lets the host driver's orchestration and the
+multi-rank sharding logic be exercised without a GPU (gloo, world_size 2).  The product never uses it."""
+import numpy as np
+import scipy.linalg
+import torch
+from oracle import ao as oao, isdf as oisdf, pbc_tools as tools
+
+
+class OracleBackend:
+    name = 'oracle-cpu'
+    device = torch.device('cpu')
+
+    def empty(self, shape, dtype=torch.float64):
+        return torch.zeros(shape, dtype=dtype)
+
+    zeros = empty
+
+    def to_device(self, a, dtype=None):
+        t = torch.as_tensor(np.ascontiguousarray(a))
+        return t.to(dtype) if dtype is not None else t
+
+    def to_host(self, t):
+        return t.detach().numpy().copy()
+
+    def synchronize(self):
+        pass
+
+    def empty_cache(self):
+        pass
+
+    def prof_enable(self, on=True):
+        pass
+
+    def prof_reset(self):
+        pass
+
+    def prof_results(self):
+        return {}
+
+    # ---- stages ----
+    def eval_ao(self, atm, bas, env, Ls, rcut, coords_soa, ao):
+        v = oao.eval_ao(atm, bas, env, coords_soa.numpy().T, Ls, rcut, rule='point')
+        ao[:, :v.shape[0]] = torch.from_numpy(np.ascontiguousarray(v.T))
+
+    def gather_cols(self, src, idx, dst):
+        dst[:, :idx.numel()] = src[:, idx]
+
+    def select_ip(self, ao, blk_off, nip, tol, tie_rtol, L, piv):
+        rank = np.zeros(len(nip), dtype=np.int32)
+        A = ao.numpy()
+        for b in range(len(nip)):
+            if nip[b] == 0:
+                continue
+            p, Lb = oisdf.select_ip(A[:, blk_off[b]:blk_off[b + 1]], int(nip[b]), tol=tol, tie_rtol=tie_rtol)
+            rank[b] = len(p)
+            piv[b, :len(p)] = torch.from_numpy(p)
+            L[:len(p), blk_off[b]:blk_off[b + 1]] = torch.from_numpy(Lb)
+        return rank
+
+    def fit_from_chol(self, L, k, m, piv):
+        th = oisdf.fit_theta(L.numpy()[:k, :m], piv.numpy()[:k])
+        L[:k, :m] = torch.from_numpy(th)
+
+    def fit_prepare(self, ao, ip, reg_rel, aoP, chol):
+        a = ao.numpy()[:, ip.numpy()]
+        aoP.copy_(torch.from_numpy(np.ascontiguousarray(a.T)))
+        A = a.T.dot(a) ** 2
+        A[np.diag_indices(len(A))] += reg_rel * A.diagonal().max()
+        chol.copy_(torch.from_numpy(np.linalg.cholesky(A)))      # lower factor, row-major
+        return reg_rel
+
+    def fit_apply(self, chol, aoP, ao, ng, theta):
+        B = aoP.numpy().dot(ao.numpy()[:, :ng]) ** 2
+        theta[:, :ng] = torch.from_numpy(scipy.linalg.cho_solve((chol.numpy(), True), B))
+
+    def fit_global(self, ao, ngrids, ip, reg_rel, theta, aoP):
+        chol = torch.zeros((ip.numel(), ip.numel()), dtype=torch.float64)
+        self.fit_prepare(ao, ip, reg_rel, aoP, chol)
+        self.fit_apply(chol, aoP, ao, ngrids, theta)
+        return reg_rel
+
+    def coulomb_rows(self, rows, mesh, a, batch, out=None):
+        out = rows if out is None else out
+        out.copy_(torch.from_numpy(oisdf.coulomb_V(rows.numpy(), a, mesh)))
+
+    def coulomb_W(self, theta, mesh, a, row0, nrows, batch, W, upper_only=False):
+        G = int(np.prod(mesh))
+        w = abs(np.linalg.det(a)) / G
+        th = theta.numpy()
+        V = oisdf.coulomb_V(th[row0:row0 + nrows], a, mesh)
+        W[row0:row0 + nrows, :th.shape[0]] = torch.from_numpy(w * V.dot(th.T))
+
+    def symmetrize_upper(self, W):
+        w = W.numpy()
+        iu = np.triu_indices(len(w), 1)
+        w.T[iu] = w[iu]
+
+    def gemm_nt(self, A, B, C, alpha=1.0, beta=0.0, kscale=None):
+        b = B.numpy() if kscale is None else B.numpy() * kscale.numpy()
+        C.copy_(torch.from_numpy(alpha * A.numpy().dot(b.T) + beta * C.numpy()))
+
+    def rho(self, ao, ng, dm, rho):
+        a = ao.numpy()[:, :ng]
+        for i in range(dm.shape[0]):
+            rho[i, :ng] = torch.from_numpy(np.einsum('ig,ig->g', dm[i].numpy().dot(a), a))
+
+    def coulomb_potential(self, rho, mesh, a):
+        G = int(np.prod(mesh))
+        w = abs(np.linalg.det(a)) / G
+        rho.copy_(torch.from_numpy(w * oisdf.coulomb_V(rho.numpy(), a, mesh)))
+
+    def vj_from_vR(self, ao, ng, vR, vj):
+        a = ao.numpy()[:, :ng]
+        for i in range(vR.shape[0]):
+            vj[i] = torch.from_numpy((a * vR[i, :ng].numpy()).dot(a.T))
+
+    def get_j(self, ao, ngrids, mesh, a, dm, vj):
+        vj.copy_(torch.from_numpy(oisdf.get_j(ao.numpy()[:, :ngrids], dm.numpy(), a, mesh)))
+
+    def get_k(self, aoP, W, row0, nrows, dm, vk):
+        ap, w = aoP.numpy(), W.numpy()
+        for i in range(dm.shape[0]):
+            M = ap[row0:row0 + nrows].dot(dm[i].numpy()).dot(ap.T) * w[row0:row0 + nrows]
+            vk[i] = torch.from_numpy(ap[row0:row0 + nrows].T.dot(M).dot(ap))

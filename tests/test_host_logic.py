@@ -1,0 +1,65 @@
+"""Host-side logic (no GPU): cell tables, grid partition, shape conventions, argument errors."""
+import numpy as np
+import pytest
+import cells
+from pyscf_isdf_amd import gto
+from pyscf_isdf_amd.isdf import ISDF, partition_grid_by_atom
+from oracle import isdf as oisdf
+
+
+def test_cp2k_basis_parser_shell_layout():
+    cell = cells.cell_diamond_prim('gth-dzvp')
+    # C DZVP-GTH: s(2 ctr, 4 prim), p(2 ctr, 4 prim), d(1 ctr, 1 prim) -> 2 + 6 + 5 = 13 AOs per atom
+    assert cell.nao_nr() == 26 and cell.nbas == 6
+    assert [cell.bas_angular(i) for i in range(3)] == [0, 1, 2]
+    assert [cell.bas_nctr(i) for i in range(3)] == [2, 2, 1]
+    assert cell.bas_exp(0)[0] > cell.bas_exp(0)[-1]          # descending exponents (mole.py:995-1000)
+    assert cell.nelectron == 8                                 # GTH-PADE q4 per carbon
+    szv = cells.cell_diamond_prim('gth-szv')
+    assert szv.nao_nr() == 8
+
+
+def test_supercell_counts_match_baseline_table():
+    c = gto.diamond_supercell(2, 'gth-dzvp', (8, 8, 8))
+    assert c.natm == 16 and c.nao_nr() == 208                 # BASELINE.md section 2, cfg 2
+    assert abs(c.vol - 8 * gto.diamond_primitive().vol) < 1e-9
+
+
+def test_grid_order_and_Gv_follow_fftfreq():
+    cell = cells.cell_he2_triclinic()
+    coords = cell.get_uniform_grids([3, 4, 5])
+    a = cell.lattice_vectors()
+    # index (1, 0, 0) is +1/3 a0, index (2,0,0) wraps to -1/3 a0 (cell.py:889-893)
+    assert np.allclose(coords[1 * 20], a[0] / 3) and np.allclose(coords[2 * 20], -a[0] / 3)
+    Gv = cell.get_Gv([3, 4, 5])
+    b = cell.reciprocal_vectors()
+    assert np.allclose(Gv[1], b[2]) and np.allclose(Gv[3], -2 * b[2])
+    assert np.allclose(a.dot(b.T), 2 * np.pi * np.eye(3))
+
+
+def test_partition_matches_bruteforce_oracle():
+    cell = cells.cell_diamond_prim('gth-szv', (10, 10, 10))
+    coords = cell.get_uniform_grids()
+    a = cell.lattice_vectors()
+    own = partition_grid_by_atom(coords, cell.atom_coords(), a)
+    ref = oisdf.partition_by_atom(coords, cell.atom_coords(), a)
+    assert np.array_equal(own, ref)
+    assert set(np.unique(own)) == {0, 1}
+
+
+def test_isdf_surface_and_errors():
+    cell = cells.cell_he_c()
+    df = ISDF(cell)
+    for name in ('build', 'reset', 'dump_flags', 'check_sanity', 'get_jk', 'get_naoaux', 'update_mf', 'get_ao_eri', 'get_eri'):
+        assert callable(getattr(df, name))
+    assert list(df.mesh) == [21, 21, 21] and df.grids.weights.shape == (9261,)
+    assert abs(df.grids.weights.sum() - cell.vol) < 1e-9
+    with pytest.raises(NotImplementedError):
+        df.get_jk(np.eye(6), kpts=np.array([0.1, 0.2, 0.3]))
+    with pytest.raises(NotImplementedError):
+        df.get_jk(np.eye(6), omega=0.3)
+    with pytest.raises(NotImplementedError):
+        df.get_jk(np.eye(6), exxdiv='ewald')
+    df.kpts = np.array([[0.1, 0., 0.]])
+    with pytest.raises(NotImplementedError):
+        df.check_sanity()
