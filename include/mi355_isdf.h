@@ -110,15 +110,30 @@ int isdf_fit_from_chol(isdf_handle h, double* d_L, int k, int64_t m, int64_t ldL
  *   isdf_fit_apply:   Theta columns for any slice of the grid: d_ao points at the slice's first
  *                     column (nao, ld), ng columns; d_theta likewise (P, ldt).  Grid slices are
  *                     independent, which is what grid-sharded multi-GPU runs use.
+ *                     forward_only != 0 stops after the forward solve and returns Y = Lr^-1 B
+ *                     (A_PP = Lr Lr^T) instead of Theta = Lr^-T Y: half the flops.  W is then
+ *                     obtained as Lr^-T [w conv(Y) Y^T] Lr^-1 by isdf_W_from_factor — the same W in
+ *                     exact arithmetic (DESIGN.md section 2 discusses the conditioning).
  *   isdf_fit_global:  both, on the whole grid, factor kept in the context workspace. */
 int isdf_fit_prepare(isdf_handle h, const double* d_ao, int nao, int64_t ld,
                      const int64_t* d_ip, int P, double reg_rel, double* d_aoP, double* d_chol,
                      double* reg_used);
 int isdf_fit_apply(isdf_handle h, const double* d_chol, const double* d_aoP, int P, int nao,
-                   const double* d_ao, int64_t ng, int64_t ld, double* d_theta, int64_t ldt);
+                   const double* d_ao, int64_t ng, int64_t ld, int forward_only,
+                   double* d_theta, int64_t ldt);
 int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, int64_t ld,
                     const int64_t* d_ip, int P, double reg_rel, double* d_theta, int64_t ldt,
                     double* d_aoP, double* reg_used);
+
+/* T (k, k) row-major upper triangular, T[t][s] = L[t][piv[s]] for s >= t: the triangular factor that
+ * turns the selection's Cholesky rows into interpolation vectors (Theta = T^-1 L). */
+int isdf_gather_T(isdf_handle h, const double* d_L, int k, int64_t ldL, const int64_t* d_piv,
+                  double* d_T);
+/* W = S^-1 M S^-T in place on d_M (P, ldm), where Theta = S^-1 Y and M = w conv(Y) Y^T:
+ *   kind 0: d_F = Cholesky factor written by isdf_fit_prepare (S = Lr^T),  Y from isdf_fit_apply(forward_only)
+ *   kind 1: d_F = T from isdf_gather_T (S = T),                           Y = L, the selection's rows.
+ * Replaces the second O(P^2 G) triangular solve by two O(P^3) ones. */
+int isdf_W_from_factor(isdf_handle h, const double* d_F, int P, int kind, double* d_M, int64_t ldm);
 
 /* S4+S5. Coulomb convolution and W:  for rows p in [row0, row0+nrows):
  *   V_p = ifft( coulG * fft(theta_p) ).real,   W[p, q] = (vol/G) * sum_g V_p[g] theta_q[g],  q < P.

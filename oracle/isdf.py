@@ -89,6 +89,14 @@ def build_W(theta, a, mesh):
     return w * V.dot(theta.T)
 
 
+def W_from_factor(S, Y, a, mesh):
+    """W for Theta = S^-1 Y (S upper triangular) without forming Theta:
+    W = S^-1 [w conv(Y) Y^T] S^-T  (include/mi355_isdf.h isdf_W_from_factor)."""
+    M = build_W(Y, a, mesh)
+    Z = scipy.linalg.solve_triangular(S, M, lower=False)
+    return scipy.linalg.solve_triangular(S, Z.T, lower=False).T
+
+
 # ---- global (dense) ISDF ---------------------------------------------------------------------
 def build_global(aoT, a, mesh, nip, tie_rtol=TIE_RTOL):
     piv, L = select_ip(aoT, nip, tie_rtol=tie_rtol)

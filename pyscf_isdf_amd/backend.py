@@ -125,11 +125,23 @@ class HipBackend:
                          float(reg_rel), self._p(aoP), self._p(chol), ctypes.byref(reg))
         return reg.value
 
-    def fit_apply(self, chol, aoP, ao, ng, theta):
-        """theta (P, >=ng) <- fit on the ng grid columns ``ao`` (nao, >=ng) starts at."""
+    def fit_apply(self, chol, aoP, ao, ng, theta, forward_only=False):
+        """theta (P, >=ng) <- fit on the ng grid columns ``ao`` (nao, >=ng) starts at
+        (forward_only: Y = Lr^-1 B instead of Theta)."""
         self._stream()
         self.handle.call('isdf_fit_apply', self._p(chol), self._p(aoP), aoP.shape[0], aoP.shape[1], self._p(ao),
-                         int(ng), ao.stride(0), self._p(theta), theta.stride(0))
+                         int(ng), ao.stride(0), int(bool(forward_only)), self._p(theta), theta.stride(0))
+
+    def gather_T(self, L, k, piv, T):
+        self._stream()
+        assert T.is_contiguous() and T.shape == (k, k)
+        self.handle.call('isdf_gather_T', self._p(L), int(k), L.stride(0), self._p(piv), self._p(T))
+
+    def W_from_factor(self, F, kind, M):
+        """M <- S^-1 M S^-T (kind 0: F = Cholesky factor from fit_prepare; kind 1: F = T)."""
+        self._stream()
+        assert F.is_contiguous()
+        self.handle.call('isdf_W_from_factor', self._p(F), M.shape[0], int(kind), self._p(M), M.stride(0))
 
     def fit_global(self, ao, ngrids, ip, reg_rel, theta, aoP):
         self._stream()

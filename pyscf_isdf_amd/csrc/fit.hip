@@ -117,7 +117,8 @@ extern "C" int isdf_fit_prepare(isdf_handle h, const double* d_ao, int nao, int6
 }
 
 extern "C" int isdf_fit_apply(isdf_handle h, const double* d_chol, const double* d_aoP, int P, int nao,
-                              const double* d_ao, int64_t ng, int64_t ld, double* d_theta, int64_t ldt) {
+                              const double* d_ao, int64_t ng, int64_t ld, int forward_only,
+                              double* d_theta, int64_t ldt) {
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_chol && d_aoP && d_ao && d_theta && P > 0 && nao > 0 && ng > 0 && ld >= ng && ldt >= ng);
   ARG_CHECK(h, P <= 65535 && ldt < (int64_t)2147483647 && ng < (int64_t)2147483647);
@@ -153,6 +154,7 @@ extern "C" int isdf_fit_apply(isdf_handle h, const double* d_chol, const double*
                               rocblas_diagonal_non_unit, (rocblas_int)ng, nb, &one,
                               d_chol + (int64_t)jb * P + jb, P, d_theta + (int64_t)jb * ldt, (rocblas_int)ldt));
   }
+  if (forward_only) return ISDF_OK;   // caller wants Y = Lr^-1 B (see isdf_W_from_factor)
   // backward: Theta = Lr^-T Y
   for (int b = nblk - 1; b >= 0; --b) {
     const int jb = b * NB;
@@ -181,5 +183,39 @@ extern "C" int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64
   if (!A) return ISDF_ERR_HIP;
   int rc = isdf_fit_prepare(h, d_ao, nao, ld, d_ip, P, reg_rel, d_aoP, A, reg_used);
   if (rc) return rc;
-  return isdf_fit_apply(h, A, d_aoP, P, nao, d_ao, ngrids, ld, d_theta, ldt);
+  return isdf_fit_apply(h, A, d_aoP, P, nao, d_ao, ngrids, ld, 0, d_theta, ldt);
+}
+
+extern "C" int isdf_gather_T(isdf_handle h, const double* d_L, int k, int64_t ldL, const int64_t* d_piv,
+                             double* d_T) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_L && d_piv && d_T && k > 0 && k <= 65535);
+  hipLaunchKernelGGL(gather_T_kernel, dim3((unsigned)cdiv(k, 256), (unsigned)k), dim3(256), 0, h->stream, d_L,
+                     ldL, d_piv, k, d_T);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_W_from_factor(isdf_handle h, const double* d_F, int P, int kind, double* d_M,
+                                  int64_t ldm) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_F && d_M && P > 0 && ldm >= P && (kind == 0 || kind == 1));
+  const double one = 1.0;
+  ProfScope ps(h, "rocblas_dtrsm[flop]", 2.0 * (double)P * P * P, 2);
+  if (kind == 0) {
+    // F = Cholesky factor of A_PP as stored by isdf_fit_prepare: column-major upper U, A = U^T U,
+    // Theta = U^-1 Y  =>  W = U^-1 M U^-T
+    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none,
+                              rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
+    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_transpose,
+                              rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
+  } else {
+    // F = T (row-major upper) from isdf_gather_T, i.e. column-major lower Lc = T^T,
+    // Theta = T^-1 L  =>  W = T^-1 M T^-T = Lc^-T M Lc^-1
+    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                              rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
+    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none,
+                              rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
+  }
+  return ISDF_OK;
 }

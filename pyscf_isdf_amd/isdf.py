@@ -72,6 +72,7 @@ class ISDF:
         self.tie_rtol = 1e-10
         self.reg_rel = 1e-12             # relative diagonal shift of A_PP in the global fit
         self.reg_used = 0.0
+        self.explicit_theta = False      # True: form Theta itself (second O(P^2 G) solve); same W in exact arithmetic
         self.fft_batch = None             # rows per FFT batch (None: sized from free memory)
         self._backend = backend
         self._comm = comm
@@ -209,7 +210,13 @@ class ISDF:
             t0 = self._tick('S2_select_ip', t0)
             theta = theta[:P]
             piv = piv[0, :P].contiguous()
-            be.fit_from_chol(theta, P, G, piv)
+            if self.explicit_theta:
+                be.fit_from_chol(theta, P, G, piv)
+                factor = None
+            else:
+                # keep the Cholesky rows L and apply T^-1 to the small (P, P) matrix instead of the (P, G) one
+                factor = (self._buffer('factor', (P, P)), 1)
+                be.gather_T(theta, P, piv, factor[0])
             self.ip = be.to_host(piv).astype(np.int64)
             self.aoP = self._buffer('aoP', (P, nao))
             tmp = be.empty((nao, P))
@@ -243,7 +250,11 @@ class ISDF:
             t0 = self._tick('S2_select_ip', t0)
             theta = self._buffer('theta', (max(Pmax, nao + kmax), G))[:P]
             self.aoP = self._buffer('aoP', (P, nao))
-            self.reg_used = be.fit_global(self.ao, G, be.to_device(self.ip), self.reg_rel, theta, self.aoP)
+            chol = self._buffer('factor', (P, P))
+            self.reg_used = be.fit_prepare(self.ao, be.to_device(self.ip), self.reg_rel, self.aoP, chol)
+            # forward solve only (Y = Lr^-1 B); the backward solve is applied to the (P, P) matrix below
+            be.fit_apply(chol, self.aoP, self.ao, G, theta, forward_only=not self.explicit_theta)
+            factor = None if self.explicit_theta else (chol, 0)
             t0 = self._tick('S3_fit', t0)
         else:
             raise ValueError("select must be 'local' or 'global'")
@@ -253,6 +264,8 @@ class ISDF:
         batch = self.fft_batch or _default_fft_batch(G, P)
         be.coulomb_W(theta, mesh, a, 0, P, batch, self.W, upper_only=True)
         be.symmetrize_upper(self.W)
+        if factor is not None:
+            be.W_from_factor(factor[0], factor[1], self.W)
         del theta
         t0 = self._tick('S4S5_coulomb_W', t0)
         self._built = True
@@ -375,8 +388,7 @@ class ISDF:
         self.reg_used = be.fit_prepare(aoP_T, be.to_device(np.arange(P, dtype=np.int64)), self.reg_rel, self.aoP, chol)
         del aoP_T
         theta = self._buffer('theta', (P, ng))
-        be.fit_apply(chol, self.aoP, self.ao, ng, theta)
-        del chol
+        be.fit_apply(chol, self.aoP, self.ao, ng, theta, forward_only=not self.explicit_theta)
         t0 = self._tick('S3_fit', t0)
 
         # S4 + S5 streamed over row batches: rank q convolves rows P_q[t*nb : (t+1)*nb] in step t
@@ -412,6 +424,8 @@ class ISDF:
             del recv
         del theta
         comm.all_reduce_sum(self.W)
+        if not self.explicit_theta:
+            be.W_from_factor(chol, 0, self.W)
         t0 = self._tick('S4S5_coulomb_W', t0)
         self._built = True
         return self

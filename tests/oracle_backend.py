@@ -70,9 +70,20 @@ class OracleBackend:
         chol.copy_(torch.from_numpy(np.linalg.cholesky(A)))      # lower factor, row-major
         return reg_rel
 
-    def fit_apply(self, chol, aoP, ao, ng, theta):
+    def fit_apply(self, chol, aoP, ao, ng, theta, forward_only=False):
         B = aoP.numpy().dot(ao.numpy()[:, :ng]) ** 2
-        theta[:, :ng] = torch.from_numpy(scipy.linalg.cho_solve((chol.numpy(), True), B))
+        if forward_only:
+            theta[:, :ng] = torch.from_numpy(scipy.linalg.solve_triangular(chol.numpy(), B, lower=True))
+        else:
+            theta[:, :ng] = torch.from_numpy(scipy.linalg.cho_solve((chol.numpy(), True), B))
+
+    def gather_T(self, L, k, piv, T):
+        T.copy_(torch.from_numpy(np.triu(L.numpy()[:k][:, piv.numpy()[:k]])))
+
+    def W_from_factor(self, F, kind, M):
+        S = F.numpy().T if kind == 0 else F.numpy()          # upper triangular S, Theta = S^-1 Y
+        Z = scipy.linalg.solve_triangular(S, M.numpy(), lower=False)
+        M.copy_(torch.from_numpy(scipy.linalg.solve_triangular(S, Z.T, lower=False).T))
 
     def fit_global(self, ao, ngrids, ip, reg_rel, theta, aoP):
         chol = torch.zeros((ip.numel(), ip.numel()), dtype=torch.float64)

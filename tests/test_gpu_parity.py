@@ -282,3 +282,60 @@ def test_gemm_nt_mfma(be, M, N, K, scaled):
     be.gemm_nt(be.to_device(A), be.to_device(B), C, alpha=0.7, beta=-0.3, kscale=be.to_device(s) if scaled else None)
     scale = np.sqrt(K) * 10
     assert abs(be.to_host(C) - ref).max() < 1e-12 * scale
+
+
+def test_W_from_factor_both_kinds(be):
+    """W without forming Theta: S^-1 [w conv(Y) Y^T] S^-T must give the same K as the explicit-Theta
+    route (W itself may differ in directions K cannot see)."""
+    import torch
+    cell = cells.cell_diamond_prim('gth-szv', (12, 12, 12))
+    aoT = _oracle_ao(cell)[0]
+    G = aoT.shape[1]
+    a = cell.lattice_vectors()
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(4)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    # kind 1: selection rows L and T
+    k = 20
+    piv, L = oisdf.select_ip(aoT, k)
+    W_ref = oisdf.build_W(oisdf.fit_theta(L, piv), a, cell.mesh)
+    dL = be.to_device(L)
+    T = be.empty((k, k))
+    be.gather_T(dL, k, be.to_device(piv), T)
+    assert abs(be.to_host(T) - np.triu(L[:, piv])).max() == 0
+    W = be.empty((k, k))
+    be.coulomb_W(dL, cell.mesh, a, 0, k, k, W, upper_only=True)
+    be.symmetrize_upper(W)
+    be.W_from_factor(T, 1, W)
+    aoP = np.ascontiguousarray(aoT[:, piv].T)
+    k_ref = oisdf.get_k(aoP, W_ref, dm)
+    assert abs(oisdf.get_k(aoP, be.to_host(W), dm) - k_ref).max() < 1e-10 * abs(k_ref).max()
+    assert abs(be.to_host(W) - oisdf.W_from_factor(np.triu(L[:, piv]), L, a, cell.mesh)).max() < 1e-9 * abs(W_ref).max()
+    # kind 0: Cholesky factor + forward solve only
+    ip = np.sort(piv)
+    d_ao = be.to_device(aoT)
+    aoPd = be.empty((k, nao)); chol = be.empty((k, k)); Y = be.empty((k, G))
+    reg = be.fit_prepare(d_ao, be.to_device(ip), 1e-12, aoPd, chol)
+    be.fit_apply(chol, aoPd, d_ao, G, Y, forward_only=True)
+    be.coulomb_W(Y, cell.mesh, a, 0, k, 7, W, upper_only=True)
+    be.symmetrize_upper(W)
+    be.W_from_factor(chol, 0, W)
+    theta = oisdf.fit_theta_global_chol(aoT, ip, reg)
+    W_ref = oisdf.build_W(theta, a, cell.mesh)
+    aoP = np.ascontiguousarray(aoT[:, ip].T)
+    k_ref = oisdf.get_k(aoP, W_ref, dm)
+    assert abs(oisdf.get_k(aoP, be.to_host(W), dm) - k_ref).max() < 1e-10 * abs(k_ref).max()
+
+
+def test_explicit_theta_and_factor_routes_agree():
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_diamond_prim('gth-szv', (12, 12, 12))
+    nao = cell.nao_nr()
+    dm = np.eye(nao)
+    out = []
+    for explicit in (True, False):
+        for select in ('local', 'global'):
+            df = ISDF(cell, c_isdf=5, select=select)
+            df.explicit_theta = explicit
+            out.append(df.get_jk(dm)[1])
+    assert abs(out[0] - out[2]).max() < 1e-10 and abs(out[1] - out[3]).max() < 1e-10
