@@ -16,6 +16,7 @@
 //        no float atomics).
 //    Algorithmic work: 2*M*N*K flop; bound: FP64 MFMA (78.6 TF/s).
 #include "common.h"
+#include <cstdlib>
 
 int gemm_rm(isdf_handle h, char opA, char opB, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
@@ -36,7 +37,8 @@ namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDT = 18;          // doubles per LDS row: 16 + 2 pad (144 B) -> conflict-free b64 fragment reads
+constexpr int LDT = 17;          // doubles per LDS row: 16 + 1 pad (136 B = 34 banks): the fragment reads (ds_read2_b64,
+                                 // banked mod 32 in 16-lane groups) hit 16 distinct bank pairs
 constexpr int TPB = 256;
 
 struct GemmArgs {
@@ -51,6 +53,7 @@ struct GemmArgs {
   int64_t nunits, nunits_pad;    // nunits_pad: rounded up to a multiple of 8 (XCD remap)
   double alpha, beta;            // used only when direct
   int direct;
+  int debug_nomem;               // experiment only: skip operand reloads after the first chunk (wrong results)
 };
 
 // FAST: lda, ldb even (16-byte aligned rows given 16-byte aligned bases) and no K tail handling
@@ -114,8 +117,9 @@ __global__ __launch_bounds__(TPB, 2) void gemm_nt_mfma_kernel(GemmArgs g) {
     ISDF_LOAD_ONE(2, ra2, rb2) ISDF_LOAD_ONE(3, ra3, rb3)                                     \
   }
 #define ISDF_STORE_ONE(BUF, I, RA, RB)                                                        \
-  *reinterpret_cast<double2*>(&sA[BUF][(srow + 32 * I) * LDT + sseg * 2]) = RA;               \
-  *reinterpret_cast<double2*>(&sB[BUF][(srow + 32 * I) * LDT + sseg * 2]) = RB;
+  { double* qa = &sA[BUF][(srow + 32 * I) * LDT + sseg * 2];                                  \
+    double* qb = &sB[BUF][(srow + 32 * I) * LDT + sseg * 2];                                  \
+    qa[0] = RA.x; qa[1] = RA.y; qb[0] = RB.x; qb[1] = RB.y; }
 #define ISDF_STORE_CHUNK(BUF)                                                                 \
   { ISDF_STORE_ONE(BUF, 0, ra0, rb0) ISDF_STORE_ONE(BUF, 1, ra1, rb1)                         \
     ISDF_STORE_ONE(BUF, 2, ra2, rb2) ISDF_STORE_ONE(BUF, 3, ra3, rb3) }
@@ -132,23 +136,28 @@ __global__ __launch_bounds__(TPB, 2) void gemm_nt_mfma_kernel(GemmArgs g) {
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    if (c + 1 < nchunks) ISDF_LOAD_CHUNK(c + 1)
+    if (c + 1 < nchunks && !g.debug_nomem) ISDF_LOAD_CHUNK(c + 1)
     const double* pa = &sA[buf][(wm * 64 + frow) * LDT + fk];
     const double* pb = &sB[buf][(wn * 64 + frow) * LDT + fk];
-#pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      double a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = pa[i * 16 * LDT + kk * 4];
-        b[i] = pb[i * 16 * LDT + kk * 4];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    // fragments of k-step kk+1 are fetched from LDS while the 16 MFMAs of k-step kk run
+    double a0[4], b0[4], a1[4], b1[4];
+#define ISDF_FRAGS(KK, AF, BF)                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+      AF[i] = pa[i * 16 * LDT + (KK) * 4];                                                    \
+      BF[i] = pb[i * 16 * LDT + (KK) * 4];                                                    \
     }
+#define ISDF_MFMA16(AF, BF)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(AF[i], BF[j], acc[i][j], 0, 0, 0);
+    ISDF_FRAGS(0, a0, b0)
+    ISDF_FRAGS(1, a1, b1)
+    ISDF_MFMA16(a0, b0)
+    ISDF_FRAGS(2, a0, b0)
+    ISDF_MFMA16(a1, b1)
+    ISDF_FRAGS(3, a1, b1)
+    ISDF_MFMA16(a0, b0)
+    ISDF_MFMA16(a1, b1)
     if (c + 1 < nchunks) ISDF_STORE_CHUNK(buf ^ 1)
     __syncthreads();
   }
@@ -209,6 +218,7 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
   g.nunits = ntiles * g.nslab;
   g.nunits_pad = cdiv(g.nunits, 8) * 8;
   g.alpha = alpha; g.beta = beta;
+  g.debug_nomem = getenv("ISDF_GEMM_NOMEM") ? 1 : 0;
   if (g.nslab == 1) {
     g.direct = 1; g.P = C; g.ldp = ldc; g.slab_stride = 0;
   } else {

@@ -72,6 +72,7 @@ class ISDF:
         self.tie_rtol = 1e-10
         self.reg_rel = 1e-12             # relative diagonal shift of A_PP in the global fit
         self.reg_used = 0.0
+        self.force_sharded = False       # run the multi-GPU code path even on one rank (tests)
         self.explicit_theta = False      # True: form Theta itself (second O(P^2 G) solve); same W in exact arithmetic
         self.fft_batch = None             # rows per FFT batch (None: sized from free memory)
         self._backend = backend
@@ -178,7 +179,7 @@ class ISDF:
 
     def build(self):
         self.check_sanity()
-        if self.comm.size > 1:
+        if self.comm.size > 1 or self.force_sharded:
             return self._build_sharded()
         cell, be = self.cell, self.backend
         self.timings = {}
@@ -299,7 +300,7 @@ class ISDF:
         d_dm = be.to_device(dms)
         vj = vk = None
         t0 = time.perf_counter()
-        if self.comm.size > 1:
+        if self.comm.size > 1 or self.force_sharded:
             return self._get_jk_sharded(d_dm, dm_in.shape, with_j, with_k)
         if with_j:
             d_vj = be.empty((nset, nao, nao))
