@@ -183,6 +183,148 @@ __global__ __launch_bounds__(TPB, 2) void gemm_nt_mfma_kernel(GemmArgs g) {
   }
 }
 
+// ---- variant B: 256x128 tile, 8 waves (one workgroup per CU), operand loads two chunks ahead ------
+// Motivation (profiles/r01_pmc_gemm_nt_mfma_v1.json): with 128x128 tiles every workgroup streams its
+// operands from the fabric (sharers run in lockstep and all miss in L2), and the single register
+// staging set gives a load only one chunk of MFMAs (~3.5 us) to land: ~14% of the time is spent in
+// s_waitcnt vmcnt(0).  Here the B panel is shared by twice as many rows inside the workgroup, and two
+// staging register sets keep TWO chunks of loads in flight.
+constexpr int BM2 = 256;
+constexpr int TPB2 = 512;
+
+template <bool SCALED>
+__global__ __launch_bounds__(TPB2, 2) void gemm_nt_mfma_kernel_b(GemmArgs g) {
+  // aligned path only: K % 32 == 0, kslab % 32 == 0 (an even number of 16-deep chunks per slab),
+  // 16-byte aligned rows.  No conditionals in the main loop: the tail re-loads the last chunk.
+  extern __shared__ double smem[];                      // [2][BM2*LDT] A | [2][BN*LDT] B
+  double* sA = smem;
+  double* sB = smem + 2 * BM2 * LDT;
+  const int64_t bid = blockIdx.x;
+  const int64_t per_xcd = g.nunits_pad / 8;
+  const int64_t unit = (bid % 8) * per_xcd + bid / 8;
+  if (unit >= g.nunits) return;
+  const int tm = (int)(unit % g.ntm);
+  const int tn = (int)((unit / g.ntm) % g.ntn);
+  const int slab = (int)(unit / ((int64_t)g.ntm * g.ntn));
+  const int64_t k0 = (int64_t)slab * g.kslab;
+  const int64_t k1 = (k0 + g.kslab < g.K) ? k0 + g.kslab : g.K;
+  const int nchunks = (int)((k1 - k0) / BK);            // even
+  const int last = nchunks - 1;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;              // 4 x 2 waves, 64x64 each
+  const int srow = tid >> 3;                            // 0..63
+  const int sseg = tid & 7;
+  const int mlast = g.M - 1, nlast = g.N - 1;
+  // six row pointers (A: rows srow + 64 i, B: rows srow + 64 i), clamped at the matrix edge
+  const double* pA0 = g.A + (int64_t)min(tm * BM2 + srow, mlast) * g.lda + k0 + sseg * 2;
+  const double* pA1 = g.A + (int64_t)min(tm * BM2 + srow + 64, mlast) * g.lda + k0 + sseg * 2;
+  const double* pA2 = g.A + (int64_t)min(tm * BM2 + srow + 128, mlast) * g.lda + k0 + sseg * 2;
+  const double* pA3 = g.A + (int64_t)min(tm * BM2 + srow + 192, mlast) * g.lda + k0 + sseg * 2;
+  const double* pB0 = g.B + (int64_t)min(tn * BN + srow, nlast) * g.ldb + k0 + sseg * 2;
+  const double* pB1 = g.B + (int64_t)min(tn * BN + srow + 64, nlast) * g.ldb + k0 + sseg * 2;
+  const double* pS = SCALED ? g.kscale + k0 + sseg * 2 : nullptr;
+
+  double2 xa0, xa1, xa2, xa3, xb0, xb1, ya0, ya1, ya2, ya3, yb0, yb1;
+#define ISDF_LOADB(C, A0, A1, A2, A3, B0, B1)                                                 \
+  {                                                                                           \
+    const int off = (C) * BK;                                                                 \
+    A0 = *reinterpret_cast<const double2*>(pA0 + off);                                        \
+    A1 = *reinterpret_cast<const double2*>(pA1 + off);                                        \
+    A2 = *reinterpret_cast<const double2*>(pA2 + off);                                        \
+    A3 = *reinterpret_cast<const double2*>(pA3 + off);                                        \
+    B0 = *reinterpret_cast<const double2*>(pB0 + off);                                        \
+    B1 = *reinterpret_cast<const double2*>(pB1 + off);                                        \
+    if (SCALED) {                                                                             \
+      const double2 sc = *reinterpret_cast<const double2*>(pS + off);                         \
+      B0.x *= sc.x; B0.y *= sc.y; B1.x *= sc.x; B1.y *= sc.y;                                 \
+    }                                                                                         \
+  }
+#define ISDF_ST1(P, R) { double* q_ = (P); q_[0] = R.x; q_[1] = R.y; }
+#define ISDF_STOREB(BUF, A0, A1, A2, A3, B0, B1)                                              \
+  {                                                                                           \
+    double* qa = sA + (BUF) * BM2 * LDT + srow * LDT + sseg * 2;                              \
+    double* qb = sB + (BUF) * BN * LDT + srow * LDT + sseg * 2;                               \
+    ISDF_ST1(qa, A0) ISDF_ST1(qa + 64 * LDT, A1) ISDF_ST1(qa + 128 * LDT, A2)                 \
+    ISDF_ST1(qa + 192 * LDT, A3) ISDF_ST1(qb, B0) ISDF_ST1(qb + 64 * LDT, B1)                 \
+  }
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int frow = lane & 15, fk = lane >> 4;
+
+#define ISDF_FRAGB(KK, AF, BF)                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+      AF[i] = pa[i * 16 * LDT + (KK) * 4];                                                    \
+      BF[i] = pb[i * 16 * LDT + (KK) * 4];                                                    \
+    }
+#define ISDF_MFMAB(AF, BF)                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(AF[i], BF[j], acc[i][j], 0, 0, 0);
+  // exactly two fragment sets live (the scheduler would otherwise hoist all four k-steps' reads and
+  // spill): reads of k-step kk+1 are issued before the MFMAs of kk, fenced by sched_barrier
+#define ISDF_COMPUTEB(BUF)                                                                    \
+  {                                                                                           \
+    const double* pa = sA + (BUF) * BM2 * LDT + (wm * 64 + frow) * LDT + fk;                  \
+    const double* pb = sB + (BUF) * BN * LDT + (wn * 64 + frow) * LDT + fk;                   \
+    double a0[4], b0[4], a1[4], b1[4];                                                        \
+    ISDF_FRAGB(0, a0, b0)                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    ISDF_FRAGB(1, a1, b1)                                                                     \
+    ISDF_MFMAB(a0, b0)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    ISDF_FRAGB(2, a0, b0)                                                                     \
+    ISDF_MFMAB(a1, b1)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    ISDF_FRAGB(3, a1, b1)                                                                     \
+    ISDF_MFMAB(a0, b0)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    ISDF_MFMAB(a1, b1)                                                                        \
+  }
+
+  // prologue: chunk 0 -> LDS buffer 0; chunk 1 in flight in set Y
+  ISDF_LOADB(0, xa0, xa1, xa2, xa3, xb0, xb1)
+  ISDF_LOADB(1, ya0, ya1, ya2, ya3, yb0, yb1)
+  ISDF_STOREB(0, xa0, xa1, xa2, xa3, xb0, xb1)
+  __syncthreads();
+  // steady state, two chunks per iteration: while chunk c computes, chunk c+1 sits in registers and
+  // chunk c+2 is being loaded, so every load has two chunks of MFMAs to land
+  for (int c = 0; c < nchunks; c += 2) {
+    ISDF_LOADB(min(c + 2, last), xa0, xa1, xa2, xa3, xb0, xb1)
+    ISDF_COMPUTEB(0)
+    ISDF_STOREB(1, ya0, ya1, ya2, ya3, yb0, yb1)
+    __syncthreads();
+    ISDF_LOADB(min(c + 3, last), ya0, ya1, ya2, ya3, yb0, yb1)
+    ISDF_COMPUTEB(1)
+    ISDF_STOREB(0, xa0, xa1, xa2, xa3, xb0, xb1)
+    __syncthreads();
+  }
+
+  double* out = g.P + (int64_t)slab * g.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tm * BM2 + wm * 64 + i * 16 + (lane >> 4) + 4 * r;
+      if (row >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = tn * BN + wn * 64 + j * 16 + (lane & 15);
+        if (col >= g.N) continue;
+        double* q = out + (int64_t)row * g.ldp + col;
+        const double v = acc[i][j][r];
+        if (g.direct) *q = (g.beta == 0.0) ? g.alpha * v : g.alpha * v + g.beta * (*q);
+        else *q = v;
+      }
+    }
+  }
+}
+
 __global__ void reduce_slabs_kernel(const double* __restrict__ P, int nslab, int64_t slab_stride,
                                     int M, int N, double alpha, double beta, double* __restrict__ C,
                                     int64_t ldc) {
@@ -204,16 +346,23 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
   GemmArgs g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.kscale = kscale;
   g.M = M; g.N = N; g.K = K;
-  g.ntm = (int)cdiv(M, BM); g.ntn = (int)cdiv(N, BN);
+  // variant: -1 auto (default), 0 force the 128x128 kernel, 1 force the 256x128 kernel where legal
+  static const int variant = getenv("ISDF_GEMM_VARIANT") ? atoi(getenv("ISDF_GEMM_VARIANT")) : -1;
+  const bool alignedB = (lda % 2 == 0) && (ldb % 2 == 0) && (K % 32 == 0) && (((uintptr_t)A) % 16 == 0) &&
+                        (((uintptr_t)B) % 16 == 0) && (!kscale || ((uintptr_t)kscale) % 16 == 0);
+  // the 256-row tile wins (+8%, profiles/r01_gemm_variants.log) unless its row padding wastes > 10%
+  const bool fitsB = (double)(cdiv(M, BM2) * BM2) <= 1.10 * (double)M;
+  const bool useB = alignedB && M > BM && (variant == 1 || (variant == -1 && fitsB));
+  g.ntm = (int)cdiv(M, useB ? BM2 : BM); g.ntn = (int)cdiv(N, BN);
   const int64_t ntiles = (int64_t)g.ntm * g.ntn;
   // enough units to fill 2 workgroups per CU about 8 times over, slabs at least 2048 deep,
   // partial workspace at most 2 GiB
-  const int64_t slots = (int64_t)h->num_cu * 2;
+  const int64_t slots = (int64_t)h->num_cu * (useB ? 1 : 2);
   int64_t nslab = cdiv(8 * slots, ntiles);
   nslab = std::min<int64_t>(nslab, std::max<int64_t>(1, K / 2048));
   nslab = std::min<int64_t>(nslab, std::max<int64_t>(1, ((int64_t)2 << 30) / ((int64_t)M * N * 8)));
   nslab = std::max<int64_t>(nslab, 1);
-  g.kslab = cdiv(cdiv(K, nslab), BK) * BK;
+  g.kslab = cdiv(cdiv(K, nslab), 2 * BK) * (2 * BK);   // even number of chunks per slab
   g.nslab = (int)cdiv(K, g.kslab);
   g.nunits = ntiles * g.nslab;
   g.nunits_pad = cdiv(g.nunits, 8) * 8;
@@ -232,7 +381,17 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
                     (!kscale || ((uintptr_t)kscale) % 16 == 0);
   ARG_CHECK(h, g.nunits_pad < 2147483647LL);
   ProfScope ps(h, "gemm_nt_mfma_kernel[flop]", 2.0 * M * N * (double)K);
-  if (fast) hipLaunchKernelGGL(gemm_nt_mfma_kernel<true>, dim3((unsigned)g.nunits_pad), dim3(TPB), 0, h->stream, g);
+  if (useB) {
+    const size_t lds = sizeof(double) * 2 * (BM2 + BN) * LDT;
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nt_mfma_kernel_b<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nt_mfma_kernel_b<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    if (kscale) hipLaunchKernelGGL(gemm_nt_mfma_kernel_b<true>, dim3((unsigned)g.nunits_pad), dim3(TPB2), lds, h->stream, g);
+    else hipLaunchKernelGGL(gemm_nt_mfma_kernel_b<false>, dim3((unsigned)g.nunits_pad), dim3(TPB2), lds, h->stream, g);
+  } else if (fast) hipLaunchKernelGGL(gemm_nt_mfma_kernel<true>, dim3((unsigned)g.nunits_pad), dim3(TPB), 0, h->stream, g);
   else hipLaunchKernelGGL(gemm_nt_mfma_kernel<false>, dim3((unsigned)g.nunits_pad), dim3(TPB), 0, h->stream, g);
   KERNEL_CHECK(h);
   if (!g.direct) {

@@ -452,6 +452,34 @@ def super_cell(cell, ncopy, mesh=None):
                 precision=cell.precision, pseudo=cell.pseudo)
 
 
+def madelung(cell, nk=(1, 1, 1)):
+    """Madelung constant of the (nk-fold) cell: -2 x the Ewald energy of one unit point charge with a
+    neutralising background (pyscf/pbc/tools/pbc.py:483-493, Ewald sum of pyscf/pbc/gto/cell.py:692-768).
+    Used for the G=0 exchange correction exxdiv='ewald' (pyscf/pbc/df/df_jk.py:1446-1465)."""
+    from scipy.special import erfc
+    a = np.einsum('xi,x->xi', cell.lattice_vectors(), np.asarray(nk, dtype=float))
+    vol = abs(np.linalg.det(a))
+    b = 2 * np.pi * np.linalg.inv(a.T)
+    eta = np.sqrt(np.pi) / vol ** (1. / 3)
+    # real-space and reciprocal-space cutoffs for ~1e-14 relative truncation
+    rmax = 6.5 / eta
+    gmax = 13.0 * eta
+    heights_inv = np.linalg.norm(b, axis=1) / (2 * np.pi)        # 1 / plane spacing of the direct lattice
+    nr = np.ceil(rmax * heights_inv).astype(int) + 1
+    Ts = cartesian_prod([np.arange(-n, n + 1) for n in nr]).dot(a)
+    r = np.linalg.norm(Ts, axis=1)
+    r = r[(r > 1e-12) & (r < rmax)]
+    e_real = .5 * (erfc(eta * r) / r).sum()
+    gheights_inv = np.linalg.norm(a, axis=1) / (2 * np.pi)
+    ng = np.ceil(gmax * gheights_inv).astype(int) + 1
+    Gs = cartesian_prod([np.arange(-n, n + 1) for n in ng]).dot(b)
+    g2 = np.einsum('gi,gi->g', Gs, Gs)
+    g2 = g2[(g2 > 1e-12) & (g2 < gmax * gmax)]
+    e_recip = .5 * (4 * np.pi / vol) * (np.exp(-g2 / (4 * eta * eta)) / g2).sum()
+    e_self = -eta / np.sqrt(np.pi) - .5 * np.pi / (eta * eta * vol)
+    return -2. * (e_real + e_recip + e_self)
+
+
 # ---- benchmark geometries (BASELINE.md section 2) ----------------------------------------------
 def diamond_primitive(basis='gth-szv', mesh=(40, 40, 40)):
     """Diamond primitive cell, a0 = 3.5668 A (pyscf/pbc/tools/make_test_cell.py:95-111)."""

@@ -80,6 +80,7 @@ class ISDF:
         self._rsh_df = {}
         self._built = False
         self._bufs = {}
+        self._ovlp = None
         self.timings = {}
         # device state
         self.ao = None        # (nao, G)
@@ -113,6 +114,7 @@ class ISDF:
         self.grids = UniformGrids(self.cell, self.cell.mesh)
         self.ao = self.aoP = self.W = self.ip = None
         self._bufs = {}
+        self._ovlp = None
         if self._backend is not None:
             self._backend.empty_cache()
         self._rsh_df = {}
@@ -281,8 +283,10 @@ class ISDF:
             kpts = self.kpts if self._is_gamma(self.kpts) else self.kpts
         if not self._is_gamma(kpts) or not self._is_gamma(kpts_band):
             raise NotImplementedError('ISDF on MI355X: only the Gamma point is implemented in this round')
-        if exxdiv is not None and exxdiv != 'None':
-            raise NotImplementedError("exxdiv=%r: only exxdiv=None is implemented (SURVEY 7.3-8)" % (exxdiv,))
+        if exxdiv is None:
+            exxdiv = self.exxdiv
+        if exxdiv not in (None, 'None', 'ewald'):
+            raise NotImplementedError("exxdiv=%r: only None and 'ewald' are implemented" % (exxdiv,))
         if not self._built:
             self.build()
         be = self.backend
@@ -301,7 +305,7 @@ class ISDF:
         vj = vk = None
         t0 = time.perf_counter()
         if self.comm.size > 1 or self.force_sharded:
-            return self._get_jk_sharded(d_dm, dm_in.shape, with_j, with_k)
+            return self._get_jk_sharded(d_dm, dm_in.shape, with_j, with_k, exxdiv)
         if with_j:
             d_vj = be.empty((nset, nao, nao))
             be.get_j(self.ao, G, mesh, a, d_dm, d_vj)
@@ -431,7 +435,7 @@ class ISDF:
         self._built = True
         return self
 
-    def _get_jk_sharded(self, d_dm, out_shape, with_j, with_k):
+    def _get_jk_sharded(self, d_dm, out_shape, with_j, with_k, exxdiv=None):
         cell, be, comm = self.cell, self.backend, self.comm
         nao = cell.nao_nr()
         nset = d_dm.shape[0]
@@ -461,6 +465,8 @@ class ISDF:
             d_vk = be.empty((nset, nao, nao))
             be.get_k(self.aoP, self.W, r0, r1 - r0, d_dm, d_vk)
             comm.all_reduce_sum(d_vk)
+            if exxdiv == 'ewald':
+                self._add_ewald_exxdiv(d_dm, d_vk)
             t0 = self._tick('S7_get_k', t0)
             vk = be.to_host(d_vk).reshape(out_shape)
         return vj, vk

@@ -358,3 +358,20 @@ def test_sharded_code_path_on_one_gpu():
     vj1, vk1 = df.get_jk(dm)
     assert np.array_equal(ref.ip, df.ip)
     assert abs(vj0 - vj1).max() < 1e-10 and abs(vk0 - vk1).max() < 1e-9 * abs(vk0).max()
+
+
+def test_exxdiv_ewald_adds_madelung_SDS():
+    """exxdiv='ewald' = exxdiv=None + madelung * S D S (df_jk.py:1446-1452) with the grid-quadrature overlap."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(3)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    df = ISDF(cell, c_isdf=3, select='global')
+    vk0 = df.get_jk(dm, exxdiv=None, with_j=False)[1]
+    vk1 = df.get_jk(dm, exxdiv='ewald', with_j=False)[1]
+    aoT = _oracle_ao(cell)[0]
+    S = aoT.dot(aoT.T) * cell.vol / aoT.shape[1]
+    ref = gto.madelung(cell) * S.dot(dm).dot(S)
+    assert abs((vk1 - vk0) - ref).max() < 1e-10
+    assert abs(S - np.eye(nao)).max() < 1.0 and abs(np.diag(S) - 1).max() < 1e-3   # normalised AOs

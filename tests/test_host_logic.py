@@ -59,7 +59,20 @@ def test_isdf_surface_and_errors():
     with pytest.raises(NotImplementedError):
         df.get_jk(np.eye(6), omega=0.3)
     with pytest.raises(NotImplementedError):
-        df.get_jk(np.eye(6), exxdiv='ewald')
+        df.get_jk(np.eye(6), exxdiv='vcut_sph')
     df.kpts = np.array([[0.1, 0., 0.]])
     with pytest.raises(NotImplementedError):
         df.check_sanity()
+
+
+def test_madelung_simple_cubic_textbook_value():
+    """The reference has no numeric pin for madelung (test_pbc.py:172-183 only checks supercell vs
+    k-mesh consistency); pin to the textbook simple-cubic value 2.837297479480620 / L and to the
+    reference's own consistency property."""
+    L = 3.7
+    cell = gto.Cell(atom='He 0 0 0', a=np.eye(3) * L, basis={'He': [[0, [1.0, 1.0]]]}, mesh=[5] * 3, unit='B')
+    assert abs(gto.madelung(cell) * L - 2.837297479480620) < 1e-10
+    fcc = gto.Cell(atom='He 0 0 0', a=np.array([[0, 1.7834, 1.7834], [1.7834, 0, 1.7834], [1.7834, 1.7834, 0]]),
+                   basis={'He': [[0, [1.0, 1.0]]]}, mesh=[5] * 3)
+    sup = gto.super_cell(fcc, [2, 3, 5], mesh=[5] * 3)
+    assert abs(gto.madelung(sup) - gto.madelung(fcc, nk=(2, 3, 5))) < 1e-9
