@@ -182,9 +182,24 @@ def main():
         # dominant HAND-WRITTEN kernel (library calls are listed in the stage report, not used for the roofline)
         own = [r for r in rows if not r['kernel'].startswith(('rocblas', 'rocsolver'))]
         dom = own[0] if own else rows[0]
+        # HBM-side bytes per launch of that kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 per the
+        # gfx950 correction + WRITE_SIZE), which cannot run inside this process: read the committed
+        # profile of the same command if it is there (profiles/r01_pmc_bench_cfg3_fetch_write.json).
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_bench_cfg3_fetch_write.json')) as f:
+                pmc = json.load(f)
+            for k, v in pmc.items():
+                if k.strip().startswith('void') and args.workload == 'diamond-444-dzvp-120' and world == 1:
+                    traffic = dict(bytes_per_launch=round((2 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024),
+                                   algorithmic_bytes_per_launch=round(8.0 * (512 + 8320 + 256) * 1728000),
+                                   source='profiles/r01_pmc_bench_cfg3_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                          'FETCH x2 per MI355X_MICROARCH.md; counts fabric requests incl. Infinity-Cache hits)')
+        except (OSError, KeyError, ValueError):
+            pass
         if dom['unit'] == 'TFLOP/s':
             roof = dict(bound='mfma', kernel=dom['kernel'], achieved=round(dom['achieved'], 2), peak=FP64_MFMA_PEAK_TFLOPS,
-                        unit='TFLOP/s', frac=round(dom['achieved'] / FP64_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        unit='TFLOP/s', frac=round(dom['achieved'] / FP64_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                         avg_launch_ms=round(dom['avg_ms'], 3), launches=dom['launches'])
         else:
             roof = dict(bound='hbm', kernel=dom['kernel'], achieved=round(dom['achieved'], 1), peak=HBM_PEAK_GBS, unit='GB/s',

@@ -315,10 +315,33 @@ class ISDF:
             d_vk = be.empty((nset, nao, nao))
             P = self.W.shape[0]
             be.get_k(self.aoP, self.W, 0, P, d_dm, d_vk)
+            if exxdiv == 'ewald':
+                self._add_ewald_exxdiv(d_dm, d_vk)
             t0 = self._tick('S7_get_k', t0)
             vk = be.to_host(d_vk).reshape(dm_in.shape)
         return vj, vk
 
+    def overlap(self):
+        """AO overlap by quadrature on the FFT grid, S = (vol/G) ao ao^T (device, cached).  The
+        reference takes the analytic lattice-sum overlap (df_jk.py:1447); on the meshes this path
+        runs at the two agree to the grid's quadrature error."""
+        if self._ovlp is None:
+            be = self.backend
+            nao = self.ao.shape[0]
+            G = int(np.prod(self.mesh))
+            S = be.empty((nao, nao))
+            be.gemm_nt(self.ao, self.ao, S, alpha=self.cell.vol / G)
+            if self.comm.size > 1 or self.force_sharded:
+                self.comm.all_reduce_sum(S)
+            self._ovlp = S
+        return self._ovlp
+
+    def _add_ewald_exxdiv(self, d_dm, d_vk):
+        """vk += madelung * S D S  (pyscf/pbc/df/df_jk.py:1446-1452, Gamma point)."""
+        S = self.overlap()
+        mad = gto.madelung(self.cell)
+        for i in range(d_dm.shape[0]):
+            d_vk[i] += mad * (S @ d_dm[i] @ S)       # N^3, negligible; torch matmul as plumbing
 
     # ---- multi-GPU: grid-sharded build, row-sharded K (DESIGN.md "Multi-GPU") -------------------------
     def _build_sharded(self):

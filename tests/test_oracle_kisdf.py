@@ -1,0 +1,58 @@
+"""k-point ISDF oracle against the reference's exact k-point exchange (oracle/fftdf.get_jk_kpts, which
+is pinned to pyscf/pbc/df/test/test_fft.py:670-676).  No GPU."""
+import numpy as np
+import cells
+from pyscf_isdf_amd import gto
+from oracle import ao as oao, fftdf, kisdf
+
+
+def _setup(nk=2):
+    cell = cells.cell_he2_triclinic()           # s and p shells, triclinic lattice, 17^3
+    coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    rng = np.random.default_rng(11)
+    kpts = rng.random((nk, 3)) * 0.6
+    kpts[0] = 0.0                                # Gamma + a generic k-point
+    aos = oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpts=kpts, rule='point')
+    aos = [np.asarray(x, dtype=complex) for x in aos]
+    nao = cell.nao_nr()
+    c = rng.standard_normal((nk, nao, nao)) + 1j * rng.standard_normal((nk, nao, nao))
+    dms = np.einsum('kpi,kqi->kpq', c[:, :, :3], c[:, :, :3].conj())       # Hermitian, rank 3
+    return cell, coords, kpts, aos, dms
+
+
+def test_kisdf_converges_to_exact_k_point_exchange():
+    cell, coords, kpts, aos, dms = _setup(2)
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    vj_ref, vk_ref = fftdf.get_jk_kpts(aos, dms, a, mesh, coords, kpts)
+    errs = []
+    for nip in (40, 120, 400):
+        r = kisdf.build(aos, coords, kpts, a, mesh, nip)
+        vk = kisdf.get_k_kpts(r['aoP'], r['W'], r['qindex'], dms)
+        errs.append(abs(vk - vk_ref).max())
+    assert errs[0] > errs[1] > errs[2]
+    assert errs[2] < 1e-7 * abs(vk_ref).max()
+    assert abs(vk_ref - vk_ref.conj().transpose(0, 2, 1)).max() < 1e-10     # Hermitian K for Hermitian D
+
+
+def test_kisdf_band_kpoints_and_interpolation_property():
+    cell, coords, kpts, aos, dms = _setup(2)
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    kb = np.array([[0.11, -0.2, 0.05]])
+    ao_b = [np.asarray(x, dtype=complex) for x in
+            oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpts=kb, rule='point')]
+    vj_ref, vk_ref = fftdf.get_jk_kpts(aos, dms, a, mesh, coords, kpts, ao_band=ao_b, kpts_band=kb)
+    # the band k-point's periodic parts must be in the fitted set: include it in the selection basis
+    X_all = aos + ao_b
+    k_all = np.vstack([kpts, kb])
+    X = kisdf.periodic_stack(X_all, coords, k_all)
+    piv, L = kisdf.select_ip(X, 300)
+    theta = kisdf.fit_theta(X, piv)
+    assert abs(theta[:, piv] - np.eye(len(piv))).max() < 1e-5          # interpolation property (ill-conditioned A_PP)
+    qs, qidx = kisdf.unique_q(kpts, kb)
+    Ws = [kisdf.build_Wq(theta, a, mesh, q, coords[piv]) for q in qs]
+    vk = kisdf.get_k_kpts([ao[piv] for ao in aos], Ws, qidx, dms, aoP_band=[ao_b[0][piv]])
+    assert abs(vk - vk_ref).max() < 1e-5 * abs(vk_ref).max()             # 300 points: fitting error, not full rank
