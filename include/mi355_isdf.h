@@ -76,6 +76,18 @@ int isdf_eval_ao(isdf_handle h,
                  const double* d_coords, int64_t ngrids,
                  double* d_ao, int64_t ld);
 
+/* k-point collocation: real and imaginary planes (nao rows each, leading dimension ld) of
+ *   periodic_part = 0:  phi^k_m(r) = sum_T exp(i k.T) phi_m(r - T)       (eval_gto.py:137, grid_ao.c:421-422)
+ *   periodic_part = 1:  u^k_m(r) = exp(-i k.r) phi^k_m(r)                 (lattice periodic)
+ * Same tables, truncation rule and arithmetic as isdf_eval_ao. */
+int isdf_eval_ao_k(isdf_handle h,
+                   const int32_t* atm, int natm, const int32_t* bas, int nbas,
+                   const double* env, int nenv,
+                   const double* Ls, int nimgs, const double* rcut,
+                   const double kpt[3], int periodic_part,
+                   const double* d_coords, int64_t ngrids,
+                   double* d_re, double* d_im, int64_t ld);
+
 /* Copy columns: d_dst[mu*ld_dst + i] = d_src[mu*ld_src + d_idx[i]], i < n  (block-major regrouping
  * of the grid for local selection; also picks phi at interpolation points). */
 int isdf_gather_cols(isdf_handle h, const double* d_src, int nrow, int64_t ld_src,
@@ -94,6 +106,14 @@ int isdf_select_ip(isdf_handle h, const double* d_ao, int nao, int64_t ld,
                    int nblk, const int64_t* blk_off, const int32_t* nip,
                    double tol, double tie_rtol,
                    double* d_L, int64_t ldL, int64_t* d_piv, int32_t* rank);
+
+/* Complex (k-point) mode of S2: d_ao holds the lattice-periodic parts u^k_m of all Bloch AOs as
+ * 2*nh real rows, rows [0,nh) = Re u, rows [nh,2nh) = Im u (nao = 2*nh, nh = nk*nao_cell).  The
+ * Gram matrix is A(r,r') = |sum_m conj(u_m(r)) u_m(r')|^2 (real).  nh = 0 is isdf_select_ip. */
+int isdf_select_ip_cplx(isdf_handle h, const double* d_ao, int nao, int nh, int64_t ld,
+                        int nblk, const int64_t* blk_off, const int32_t* nip,
+                        double tol, double tie_rtol,
+                        double* d_L, int64_t ldL, int64_t* d_piv, int32_t* rank);
 
 /* S3a. Fit from the selection's own factor (single block): Theta = T^-1 L in place, with
  * T[t,s] = L[t, piv[s]] upper triangular.  Equals the least-squares fit A_PP^-1 A_P. */
@@ -121,6 +141,14 @@ int isdf_fit_prepare(isdf_handle h, const double* d_ao, int nao, int64_t ld,
 int isdf_fit_apply(isdf_handle h, const double* d_chol, const double* d_aoP, int P, int nao,
                    const double* d_ao, int64_t ng, int64_t ld, int forward_only,
                    double* d_theta, int64_t ldt);
+/* Complex (k-point) mode of the fit, d_ao = [Re u; Im u] as in isdf_select_ip_cplx:
+ * A_PP and B are |S|^2 = (aoP X)^2 + (aoP_rot X)^2 with aoP_rot = [Im u_P | -Re u_P]; Theta is real. */
+int isdf_fit_prepare_cplx(isdf_handle h, const double* d_ao, int nao, int nh, int64_t ld,
+                          const int64_t* d_ip, int P, double reg_rel, double* d_aoP, double* d_chol,
+                          double* reg_used);
+int isdf_fit_apply_cplx(isdf_handle h, const double* d_chol, const double* d_aoP, int P, int nao, int nh,
+                        const double* d_ao, int64_t ng, int64_t ld, int forward_only,
+                        double* d_theta, int64_t ldt);
 int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, int64_t ld,
                     const int64_t* d_ip, int P, double reg_rel, double* d_theta, int64_t ldt,
                     double* d_aoP, double* reg_used);
@@ -176,6 +204,37 @@ int isdf_vj_from_vR(isdf_handle h, const double* d_ao, int nao, int64_t ng, int6
 int isdf_get_k(isdf_handle h, const double* d_aoP, int P, int nao,
                const double* d_W, int64_t ldw, int row0, int nrows,
                const double* d_dm, int nset, double* d_vk);
+
+/* ---- k-points (BASELINE configs[3]); conventions of pyscf/pbc/df/fft_jk.py:177-302 ------------------
+ * Bloch AOs are carried as lattice-periodic parts in two real planes (isdf_eval_ao_k, periodic_part=1);
+ * Theta / Y rows are real and k-independent (complex modes of S2/S3).  Per difference vector
+ * q = k2 - k1 (k1 a band k-point):
+ *   isdf_coulomb_Wq:  rows [row0,row0+nrows) of  M^q = weight * V^q Theta^T,  V^q_P = ifft(coulG_q fft(Theta_P)),
+ *                     d_coulG = the G real values of get_coulG(cell, q) (pbc/tools/pbc.py:230-420) in
+ *                     fftfreq order; complex transform (Z2Z) because coulG(q+G) is not inversion
+ *                     symmetric.  Real and imaginary parts in d_Wre / d_Wim; upper_only as in isdf_coulomb_W.
+ *   isdf_symmetrize_hermitian:  M[q][p] = conj(M[p][q]) for q > p.
+ *   (isdf_W_from_factor is applied to both planes.)
+ *   isdf_finish_Wq:   d_Wc (P, P) complex interleaved = (Wre + i Wim)[p][q] * ph[p] * conj(ph[q]),
+ *                     d_phase = (P, 2) with ph[p] = exp(-i q.r_p).
+ *   isdf_get_k_pair:  d_vk (nao, nao) complex += scale * A1^H [ (A2 D2 A2^H) .* Wq ] A1 with
+ *                     A1, A2 = phi^{k1}, phi^{k2} at the interpolation points, (P, nao) complex interleaved,
+ *                     D2 (nao, nao) complex; rocBLAS zgemm + a fused complex Hadamard kernel.
+ *   isdf_rho_k:       d_rho[g] += scale * sum_ij D_ij u_i(g) conj(u_j(g)) (real part; Hermitian D), with
+ *                     d_DTr/d_DTi = real/imag planes of D^T (fft_jk.py:84-88).
+ *   isdf_vj_k:        vj_ij = sum_g conj(u_i(g)) vR[g] u_j(g)  (fft_jk.py:100-107), planes re/im. */
+int isdf_coulomb_Wq(isdf_handle h, const double* d_theta, int P, int64_t ldt, const int32_t mesh[3],
+                    const double* d_coulG, double weight, int row0, int nrows, int batch,
+                    int upper_only, double* d_Wre, double* d_Wim, int64_t ldw);
+int isdf_symmetrize_hermitian(isdf_handle h, double* d_Wre, double* d_Wim, int P, int64_t ldw);
+int isdf_finish_Wq(isdf_handle h, const double* d_Wre, const double* d_Wim, int P, int64_t ldw,
+                   const double* d_phase, double* d_Wc);
+int isdf_get_k_pair(isdf_handle h, const double* d_A1, const double* d_A2, const double* d_D2,
+                    const double* d_Wq, int P, int nao, double scale, double* d_vk);
+int isdf_rho_k(isdf_handle h, const double* d_ur, const double* d_ui, int nao, int64_t ng, int64_t ld,
+               const double* d_DTr, const double* d_DTi, double scale, double* d_rho);
+int isdf_vj_k(isdf_handle h, const double* d_ur, const double* d_ui, int nao, int64_t ng, int64_t ld,
+              const double* d_vR, double* d_vj_re, double* d_vj_im);
 
 /* Dense helper behind S5/S6 (exposed for tests and micro-benchmarks):
  *   C (M, ldc) = alpha * A (M, lda) * (B (N, ldb) .* kscale[None, :])^T + beta * C,

@@ -20,11 +20,23 @@
 #include <stdlib.h>
 #include <string.h>
 
+long oracle_select_ip_cplx(const double* ao, int nao, int nh, long m, long ld, int k, double tol,
+                           double tie_rtol, long* piv, double* L, long ldL);
+
 long oracle_select_ip(const double* ao, int nao, long m, long ld, int k, double tol,
                       double tie_rtol, long* piv, double* L, long ldL)
 {
+        return oracle_select_ip_cplx(ao, nao, 0, m, ld, k, tol, tie_rtol, piv, L, ldL);
+}
+
+/* nh > 0: complex mode (rows [0,nh) = Re u, [nh,2nh) = Im u): Gram entry = (sum X_i.pv)^2 + (sum X_i.pvr)^2,
+ * pvr = [Im u_p; -Re u_p]; the two sums are separate ascending fma chains, col = fma(s1, s1, s0*s0). */
+long oracle_select_ip_cplx(const double* ao, int nao, int nh, long m, long ld, int k, double tol,
+                           double tie_rtol, long* piv, double* L, long ldL)
+{
         double* d = (double*)malloc(sizeof(double) * m);
         double* pv = (double*)malloc(sizeof(double) * nao);
+        double* pvr = (double*)malloc(sizeof(double) * nao);
         double* pl = (double*)malloc(sizeof(double) * (k > 0 ? k : 1));
         long i, rank = 0;
         int j, mu, t;
@@ -49,6 +61,7 @@ long oracle_select_ip(const double* ao, int nao, long m, long ld, int k, double 
                 piv[j] = p;
                 double dp = sqrt(d[p]);
                 for (mu = 0; mu < nao; mu++) pv[mu] = ao[(long)mu * ld + p];
+                for (mu = 0; mu < nao; mu++) pvr[mu] = (nh > 0) ? ((mu < nh) ? pv[nh + mu] : -pv[mu - nh]) : 0.0;
                 for (t = 0; t < j; t++) pl[t] = L[(long)t * ldL + p];
 #pragma omp parallel for private(mu, t)
                 for (i = 0; i < m; i++) {
@@ -59,9 +72,11 @@ long oracle_select_ip(const double* ao, int nao, long m, long ld, int k, double 
                         } else if (dold < 0.0) {
                                 row = 0.0; dnew = -1.0;
                         } else {
-                                double s0 = 0.0;
+                                double s0 = 0.0, s1 = 0.0;
                                 for (mu = 0; mu < nao; mu++) s0 = fma(ao[(long)mu * ld + i], pv[mu], s0);
-                                double col = s0 * s0;
+                                if (nh > 0)
+                                        for (mu = 0; mu < nao; mu++) s1 = fma(ao[(long)mu * ld + i], pvr[mu], s1);
+                                double col = fma(s1, s1, s0 * s0);
                                 for (t = 0; t < j; t++) col = fma(-L[(long)t * ldL + i], pl[t], col);
                                 row = col / dp;
                                 dnew = fma(-row, row, dold);
@@ -72,6 +87,6 @@ long oracle_select_ip(const double* ao, int nao, long m, long ld, int k, double 
                 }
                 rank++;
         }
-        free(d); free(pv); free(pl);
+        free(d); free(pv); free(pvr); free(pl);
         return rank;
 }

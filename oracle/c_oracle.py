@@ -24,7 +24,24 @@ def _load():
         _lib.oracle_select_ip.restype = ctypes.c_long
         _lib.oracle_select_ip.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_int,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+        _lib.oracle_select_ip_cplx.restype = ctypes.c_long
+        _lib.oracle_select_ip_cplx.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_long,
+                                               ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_long]
     return _lib
+
+
+def select_ip_cplx(X, k, tol=-1.0, tie_rtol=1e-10):
+    """Complex mode: X (2*nh, m) = [Re u; Im u]."""
+    lib = _load()
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    nao, m = X.shape
+    k = int(min(k, m))
+    piv = np.zeros(max(k, 1), dtype=np.int64)
+    L = np.zeros((max(k, 1), m))
+    rank = lib.oracle_select_ip_cplx(X.ctypes.data, nao, nao // 2, m, m, k, float(tol), float(tie_rtol),
+                                     piv.ctypes.data, L.ctypes.data, m)
+    return piv[:rank], L[:rank]
 
 
 def select_ip(aoT, k, tol=-1.0, tie_rtol=1e-10):

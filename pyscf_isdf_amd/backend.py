@@ -210,3 +210,74 @@ class HipBackend:
         ks = self._p(kscale) if kscale is not None else _vp(0)
         self.handle.call('isdf_gemm_nt', M, N, K, float(alpha), self._p(A), A.stride(0), self._p(B), B.stride(0), ks,
                          float(beta), self._p(C), C.stride(0))
+
+    # ---- k-points -----------------------------------------------------------------------------
+    def eval_ao_k(self, atm, bas, env, Ls, rcut, kpt, periodic_part, coords_soa, out_re, out_im):
+        self._stream()
+        atm = np.ascontiguousarray(atm, dtype=np.int32)
+        bas = np.ascontiguousarray(bas, dtype=np.int32)
+        env = np.ascontiguousarray(env, dtype=np.float64)
+        Ls = np.ascontiguousarray(Ls, dtype=np.float64)
+        rcut = np.ascontiguousarray(rcut, dtype=np.float64)
+        kpt = np.ascontiguousarray(kpt, dtype=np.float64)
+        G = coords_soa.shape[1]
+        assert out_re.stride(0) == out_im.stride(0) and out_re.stride(1) == 1
+        self.handle.call('isdf_eval_ao_k', _np_ptr(atm), len(atm), _np_ptr(bas), len(bas), _np_ptr(env), len(env),
+                         _np_ptr(Ls), len(Ls), _np_ptr(rcut), _np_ptr(kpt), int(bool(periodic_part)), self._p(coords_soa), G,
+                         self._p(out_re), self._p(out_im), out_re.stride(0))
+
+    def select_ip_cplx(self, X, nh, blk_off, nip, tol, tie_rtol, L, piv):
+        self._stream()
+        blk_off = np.ascontiguousarray(blk_off, dtype=np.int64)
+        nip = np.ascontiguousarray(nip, dtype=np.int32)
+        rank = np.zeros(len(nip), dtype=np.int32)
+        self.handle.call('isdf_select_ip_cplx', self._p(X), X.shape[0], int(nh), X.stride(0), len(nip), _np_ptr(blk_off),
+                         _np_ptr(nip), float(tol), float(tie_rtol), self._p(L), L.stride(0), self._p(piv), _np_ptr(rank))
+        return rank
+
+    def fit_prepare_cplx(self, X, nh, ip, reg_rel, aoP, chol):
+        self._stream()
+        reg = ctypes.c_double(0.0)
+        self.handle.call('isdf_fit_prepare_cplx', self._p(X), X.shape[0], int(nh), X.stride(0), self._p(ip), ip.numel(),
+                         float(reg_rel), self._p(aoP), self._p(chol), ctypes.byref(reg))
+        return reg.value
+
+    def fit_apply_cplx(self, chol, aoP, nh, X, ng, theta, forward_only=False):
+        self._stream()
+        self.handle.call('isdf_fit_apply_cplx', self._p(chol), self._p(aoP), aoP.shape[0], aoP.shape[1], int(nh),
+                         self._p(X), int(ng), X.stride(0), int(bool(forward_only)), self._p(theta), theta.stride(0))
+
+    def coulomb_Wq(self, theta, mesh, coulG, weight, row0, nrows, batch, Wre, Wim, upper_only=False):
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        self.handle.call('isdf_coulomb_Wq', self._p(theta), theta.shape[0], theta.stride(0), _np_ptr(mesh), self._p(coulG),
+                         float(weight), int(row0), int(nrows), int(batch), int(bool(upper_only)), self._p(Wre),
+                         self._p(Wim), Wre.stride(0))
+
+    def symmetrize_hermitian(self, Wre, Wim):
+        self._stream()
+        self.handle.call('isdf_symmetrize_hermitian', self._p(Wre), self._p(Wim), Wre.shape[0], Wre.stride(0))
+
+    def finish_Wq(self, Wre, Wim, phase, Wc):
+        """Wc (P, P) complex128 <- (Wre + i Wim) * ph[p] * conj(ph[q]); phase (P,) complex128."""
+        self._stream()
+        assert Wc.dtype == torch.complex128 and Wc.is_contiguous() and phase.dtype == torch.complex128
+        self.handle.call('isdf_finish_Wq', self._p(Wre), self._p(Wim), Wre.shape[0], Wre.stride(0), self._p(phase),
+                         self._p(Wc))
+
+    def get_k_pair(self, A1, A2, D2, Wq, scale, vk):
+        self._stream()
+        for t in (A1, A2, D2, Wq, vk):
+            assert t.dtype == torch.complex128 and t.is_contiguous()
+        self.handle.call('isdf_get_k_pair', self._p(A1), self._p(A2), self._p(D2), self._p(Wq), A1.shape[0], A1.shape[1],
+                         float(scale), self._p(vk))
+
+    def rho_k(self, ur, ui, ng, DTr, DTi, scale, rho):
+        self._stream()
+        self.handle.call('isdf_rho_k', self._p(ur), self._p(ui), ur.shape[0], int(ng), ur.stride(0), self._p(DTr),
+                         self._p(DTi), float(scale), self._p(rho))
+
+    def vj_k(self, ur, ui, ng, vR, vj_re, vj_im):
+        self._stream()
+        self.handle.call('isdf_vj_k', self._p(ur), self._p(ui), ur.shape[0], int(ng), ur.stride(0), self._p(vR),
+                         self._p(vj_re), self._p(vj_im))

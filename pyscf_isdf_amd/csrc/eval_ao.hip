@@ -165,6 +165,146 @@ __global__ __launch_bounds__(TPB) void eval_ao_kernel(
   }
 }
 
+// k-point variant: every image contributes with the Bloch factor exp(i k.T) (table per image), the
+// result is multiplied by exp(-i k.r) to give the lattice-periodic part u^k = exp(-i k.r) phi^k
+// (periodic=1) or left as phi^k (periodic=0).  Output: real and imaginary planes.
+template <int L>
+__device__ inline void shell_eval_k(const ShellDev sh, const double* __restrict__ env,
+                                    const double* __restrict__ Ls, const double* __restrict__ phT,
+                                    const int* __restrict__ img_list, int nlist, double px, double py,
+                                    double pz, double ax, double ay, double az, bool valid, double pr,
+                                    double pi, double* __restrict__ out_re, double* __restrict__ out_im,
+                                    int64_t ld, int64_t g) {
+  constexpr int DEG = 2 * L + 1;
+  double accr[NCMAX][DEG], acci[NCMAX][DEG];
+#pragma unroll
+  for (int c = 0; c < NCMAX; ++c)
+#pragma unroll
+    for (int m = 0; m < DEG; ++m) { accr[c][m] = 0.0; acci[c][m] = 0.0; }
+  const double fac = (L == 0) ? FAC_S : (L == 1 ? FAC_P : 1.0);
+  const double* __restrict__ es = env + sh.pexp;
+  const double* __restrict__ cs = env + sh.pcoef;
+  for (int i = 0; i < nlist; ++i) {
+    const int iL = img_list[i];
+    const double dx = px - (ax + Ls[3 * iL + 0]);
+    const double dy = py - (ay + Ls[3 * iL + 1]);
+    const double dz = pz - (az + Ls[3 * iL + 2]);
+    const double rr = dx * dx + dy * dy + dz * dz;
+    if (rr < sh.rcut2) {
+      const double tr = phT[2 * iL], ti = phT[2 * iL + 1];
+      double rad[NCMAX];
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c) rad[c] = 0.0;
+      for (int p = 0; p < sh.nprim; ++p) {
+        const double e = exp(-es[p] * rr) * fac;
+#pragma unroll
+        for (int c = 0; c < NCMAX; ++c)
+          if (c < sh.nctr) rad[c] += cs[c * sh.nprim + p] * e;
+      }
+      double ang[DEG];
+      if (L == 0) {
+        ang[0] = 1.0;
+      } else if (L == 1) {
+        ang[0] = dx; ang[1] = dy; ang[2] = dz;
+      } else {
+        ang[0] = D_XY * dx * dy;
+        ang[1] = D_XY * dy * dz;
+        ang[2] = D_Z2_ZZ * dz * dz - D_Z2_XXYY * (dx * dx + dy * dy);
+        ang[3] = D_XY * dx * dz;
+        ang[4] = D_X2Y2 * (dx * dx - dy * dy);
+      }
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c)
+#pragma unroll
+        for (int m = 0; m < DEG; ++m) {
+          const double v = rad[c] * ang[m];
+          accr[c][m] += v * tr;
+          acci[c][m] += v * ti;
+        }
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c)
+      if (c < sh.nctr) {
+#pragma unroll
+        for (int m = 0; m < DEG; ++m) {
+          const int64_t off = (int64_t)(sh.ao0 + c * DEG + m) * ld + g;
+          out_re[off] = accr[c][m] * pr - acci[c][m] * pi;
+          out_im[off] = accr[c][m] * pi + acci[c][m] * pr;
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void eval_ao_k_kernel(
+    const AtomDev* __restrict__ atoms, const ShellDev* __restrict__ shells,
+    const double* __restrict__ env, const double* __restrict__ Ls, const double* __restrict__ phT,
+    int nimgs, double kx, double ky, double kz, int periodic, const double* __restrict__ coords,
+    int64_t ngrids, double* __restrict__ out_re, double* __restrict__ out_im, int64_t ld) {
+  extern __shared__ int img_list[];
+  __shared__ double red[6][TPB / 64];
+  __shared__ int wcnt[TPB / 64];
+  const int tid = threadIdx.x;
+  const int64_t g = (int64_t)blockIdx.x * TPB + tid;
+  const bool valid = g < ngrids;
+  const int64_t gc = valid ? g : (int64_t)blockIdx.x * TPB;
+  const double px = coords[gc], py = coords[ngrids + gc], pz = coords[2 * ngrids + gc];
+  const AtomDev at = atoms[blockIdx.y];
+  double lo[3] = {wave_min(px), wave_min(py), wave_min(pz)};
+  double hi[3] = {wave_max(px), wave_max(py), wave_max(pz)};
+  const int w = tid >> 6;
+  if ((tid & 63) == 0) {
+    for (int k = 0; k < 3; ++k) { red[k][w] = lo[k]; red[3 + k][w] = hi[k]; }
+  }
+  __syncthreads();
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = red[k][0]; hi[k] = red[3 + k][0];
+    for (int ww = 1; ww < TPB / 64; ++ww) {
+      lo[k] = fmin(lo[k], red[k][ww]);
+      hi[k] = fmax(hi[k], red[3 + k][ww]);
+    }
+  }
+  const double rc2 = at.rcut_max * at.rcut_max;
+  const int lane = tid & 63;
+  int nlist = 0;
+  for (int base = 0; base < nimgs; base += TPB) {
+    const int i = base + tid;
+    bool keep = false;
+    if (i < nimgs) {
+      const double c[3] = {at.x + Ls[3 * i], at.y + Ls[3 * i + 1], at.z + Ls[3 * i + 2]};
+      double d2 = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        const double d = fmax(fmax(lo[k] - c[k], c[k] - hi[k]), 0.0);
+        d2 += d * d;
+      }
+      keep = d2 < rc2;
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) wcnt[w] = __popcll(mask);
+    __syncthreads();
+    int off = nlist;
+    for (int ww = 0; ww < w; ++ww) off += wcnt[ww];
+    if (keep) img_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    for (int ww = 0; ww < TPB / 64; ++ww) nlist += wcnt[ww];
+    __syncthreads();
+  }
+  // exp(-i k.r) for the periodic part (1 otherwise)
+  double pr = 1.0, pi = 0.0;
+  if (periodic) {
+    const double kr = kx * px + ky * py + kz * pz;
+    sincos(-kr, &pi, &pr);
+  }
+  for (int s = at.sh0; s < at.sh1; ++s) {
+    const ShellDev sh = shells[s];
+    switch (sh.l) {
+      case 0: shell_eval_k<0>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, g); break;
+      case 1: shell_eval_k<1>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, g); break;
+      default: shell_eval_k<2>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, g); break;
+    }
+  }
+}
+
 __global__ void gather_cols_kernel(const double* __restrict__ src, int64_t ld_src,
                                    const int64_t* __restrict__ idx, int64_t n,
                                    double* __restrict__ dst, int64_t ld_dst) {
@@ -176,13 +316,17 @@ __global__ void gather_cols_kernel(const double* __restrict__ src, int64_t ld_sr
 
 }  // namespace
 
-extern "C" int isdf_eval_ao(isdf_handle h, const int32_t* atm, int natm, const int32_t* bas, int nbas,
-                            const double* env, int nenv, const double* Ls, int nimgs,
-                            const double* rcut, const double* d_coords, int64_t ngrids,
-                            double* d_ao, int64_t ld) {
-  if (!h) return ISDF_ERR_ARG;
-  ARG_CHECK(h, atm && bas && env && Ls && rcut && d_coords && d_ao);
-  ARG_CHECK(h, natm > 0 && nbas > 0 && nimgs > 0 && ngrids > 0 && ld >= ngrids);
+namespace {
+struct AoTables {
+  AtomDev* d_atoms; ShellDev* d_shells; double* d_env; double* d_Ls; double* d_phT; int nao;
+};
+}  // namespace
+
+static int upload_ao_tables(isdf_handle h, const int32_t* atm, int natm, const int32_t* bas, int nbas,
+                            const double* env, int nenv, const double* Ls, int nimgs, const double* rcut,
+                            const double* phT /* (nimgs, 2) or null */, AoTables* out) {
+  ARG_CHECK(h, atm && bas && env && Ls && rcut);
+  ARG_CHECK(h, natm > 0 && nbas > 0 && nimgs > 0 && natm <= 65535);
   ARG_CHECK(h, (size_t)nimgs * sizeof(int) <= 64 * 1024);
   constexpr int ATM_SLOTS = 6, BAS_SLOTS = 8, PTR_COORD = 1;
   constexpr int ATOM_OF = 0, ANG_OF = 1, NPRIM_OF = 2, NCTR_OF = 3, PTR_EXP = 5, PTR_COEFF = 6;
@@ -216,27 +360,63 @@ extern "C" int isdf_eval_ao(isdf_handle h, const int32_t* atm, int natm, const i
   for (auto& a : atoms) if (a.sh0 < 0) { a.sh0 = a.sh1 = 0; }
 
   size_t b_atoms = sizeof(AtomDev) * natm, b_shells = sizeof(ShellDev) * nbas;
-  size_t b_env = sizeof(double) * nenv, b_Ls = sizeof(double) * 3 * nimgs;
+  size_t b_env = sizeof(double) * nenv, b_Ls = sizeof(double) * 3 * nimgs, b_ph = sizeof(double) * 2 * nimgs;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  char* tab = (char*)isdf_ws(h, "ao_tables", al(b_atoms) + al(b_shells) + al(b_env) + al(b_Ls));
+  char* tab = (char*)isdf_ws(h, "ao_tables", al(b_atoms) + al(b_shells) + al(b_env) + al(b_Ls) + al(b_ph));
   if (!tab) return ISDF_ERR_HIP;
-  AtomDev* d_atoms = (AtomDev*)tab;
-  ShellDev* d_shells = (ShellDev*)(tab + al(b_atoms));
-  double* d_env = (double*)(tab + al(b_atoms) + al(b_shells));
-  double* d_Ls = (double*)(tab + al(b_atoms) + al(b_shells) + al(b_env));
-  HIP_TRY(h, hipMemcpyAsync(d_atoms, atoms.data(), b_atoms, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(d_shells, shells.data(), b_shells, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(d_env, env, b_env, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(d_Ls, Ls, b_Ls, hipMemcpyHostToDevice, h->stream));
-  // host vectors die at return: the copies above are from pageable memory and complete
-  // (staged) before hipMemcpyAsync returns, but be explicit:
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  out->d_atoms = (AtomDev*)tab;
+  out->d_shells = (ShellDev*)(tab + al(b_atoms));
+  out->d_env = (double*)(tab + al(b_atoms) + al(b_shells));
+  out->d_Ls = (double*)(tab + al(b_atoms) + al(b_shells) + al(b_env));
+  out->d_phT = (double*)(tab + al(b_atoms) + al(b_shells) + al(b_env) + al(b_Ls));
+  out->nao = ao0;
+  HIP_TRY(h, hipMemcpyAsync(out->d_atoms, atoms.data(), b_atoms, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(out->d_shells, shells.data(), b_shells, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(out->d_env, env, b_env, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(out->d_Ls, Ls, b_Ls, hipMemcpyHostToDevice, h->stream));
+  if (phT) HIP_TRY(h, hipMemcpyAsync(out->d_phT, phT, b_ph, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));   // host staging vectors die at return
+  return ISDF_OK;
+}
 
+extern "C" int isdf_eval_ao(isdf_handle h, const int32_t* atm, int natm, const int32_t* bas, int nbas,
+                            const double* env, int nenv, const double* Ls, int nimgs,
+                            const double* rcut, const double* d_coords, int64_t ngrids,
+                            double* d_ao, int64_t ld) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_coords && d_ao && ngrids > 0 && ld >= ngrids);
+  AoTables t;
+  int rc = upload_ao_tables(h, atm, natm, bas, nbas, env, nenv, Ls, nimgs, rcut, nullptr, &t);
+  if (rc) return rc;
   dim3 grid((unsigned)cdiv(ngrids, TPB), (unsigned)natm);
-  ARG_CHECK(h, natm <= 65535);
-  ProfScope ps(h, "eval_ao_kernel[byte]", 8.0 * (double)ngrids * ao0);
+  ProfScope ps(h, "eval_ao_kernel[byte]", 8.0 * (double)ngrids * t.nao);
   hipLaunchKernelGGL(eval_ao_kernel, grid, dim3(TPB), (size_t)nimgs * sizeof(int), h->stream,
-                     d_atoms, d_shells, d_env, d_Ls, nimgs, d_coords, ngrids, d_ao, ld);
+                     t.d_atoms, t.d_shells, t.d_env, t.d_Ls, nimgs, d_coords, ngrids, d_ao, ld);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_eval_ao_k(isdf_handle h, const int32_t* atm, int natm, const int32_t* bas, int nbas,
+                              const double* env, int nenv, const double* Ls, int nimgs,
+                              const double* rcut, const double kpt[3], int periodic_part,
+                              const double* d_coords, int64_t ngrids, double* d_re, double* d_im,
+                              int64_t ld) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, kpt && d_coords && d_re && d_im && ngrids > 0 && ld >= ngrids);
+  std::vector<double> ph(2 * (size_t)nimgs);
+  for (int i = 0; i < nimgs; ++i) {
+    const double kl = kpt[0] * Ls[3 * i] + kpt[1] * Ls[3 * i + 1] + kpt[2] * Ls[3 * i + 2];
+    ph[2 * i] = cos(kl);
+    ph[2 * i + 1] = sin(kl);
+  }
+  AoTables t;
+  int rc = upload_ao_tables(h, atm, natm, bas, nbas, env, nenv, Ls, nimgs, rcut, ph.data(), &t);
+  if (rc) return rc;
+  dim3 grid((unsigned)cdiv(ngrids, TPB), (unsigned)natm);
+  ProfScope ps(h, "eval_ao_k_kernel[byte]", 16.0 * (double)ngrids * t.nao);
+  hipLaunchKernelGGL(eval_ao_k_kernel, grid, dim3(TPB), (size_t)nimgs * sizeof(int), h->stream,
+                     t.d_atoms, t.d_shells, t.d_env, t.d_Ls, t.d_phT, nimgs, kpt[0], kpt[1], kpt[2],
+                     periodic_part ? 1 : 0, d_coords, ngrids, d_re, d_im, ld);
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

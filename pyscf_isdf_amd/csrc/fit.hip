@@ -24,6 +24,24 @@ __global__ void square_kernel(double* __restrict__ x, int64_t rows, int64_t cols
   x[r * ld + c] = v * v;
 }
 
+// x = x^2 + y^2 (elementwise), x (rows, ld), y (rows, ldy)
+__global__ void square_add_kernel(double* __restrict__ x, int64_t ld, const double* __restrict__ y, int64_t ldy,
+                                  int64_t cols) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (c >= cols) return;
+  const double a = x[r * ld + c], b = y[r * ldy + c];
+  x[r * ld + c] = fma(b, b, a * a);
+}
+
+// rot[p, m] = (m < nh) ? aoP[p, nh + m] : -aoP[p, m - nh]     (aoP is (P, 2 nh))
+__global__ void rotate_kernel(const double* __restrict__ aoP, int P, int nh, double* __restrict__ rot) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (m >= 2 * nh) return;
+  rot[(int64_t)p * 2 * nh + m] = (m < nh) ? aoP[(int64_t)p * 2 * nh + nh + m] : -aoP[(int64_t)p * 2 * nh + m - nh];
+}
+
 __global__ void transpose_gather_kernel(const double* __restrict__ ao, int64_t ld,
                                         const int64_t* __restrict__ ip, int P, int nao,
                                         double* __restrict__ aoP) {
@@ -78,7 +96,14 @@ __global__ void max_diag_kernel(const double* __restrict__ A, int n, double* __r
 extern "C" int isdf_fit_prepare(isdf_handle h, const double* d_ao, int nao, int64_t ld,
                                 const int64_t* d_ip, int P, double reg_rel, double* d_aoP,
                                 double* d_chol, double* reg_used) {
+  return isdf_fit_prepare_cplx(h, d_ao, nao, 0, ld, d_ip, P, reg_rel, d_aoP, d_chol, reg_used);
+}
+
+extern "C" int isdf_fit_prepare_cplx(isdf_handle h, const double* d_ao, int nao, int nh, int64_t ld,
+                                     const int64_t* d_ip, int P, double reg_rel, double* d_aoP,
+                                     double* d_chol, double* reg_used) {
   if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, nh == 0 || 2 * nh == nao);
   ARG_CHECK(h, d_ao && d_ip && d_aoP && d_chol && nao > 0 && P > 0 && reg_rel >= 0.0);
   ARG_CHECK(h, nao <= 65535 && P <= 65535);
   hipLaunchKernelGGL(transpose_gather_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)nao), dim3(256), 0,
@@ -92,8 +117,20 @@ extern "C" int isdf_fit_prepare(isdf_handle h, const double* d_ao, int nao, int6
     // A_PP = (aoP aoP^T)^2 (+ reg * max diag * I), Cholesky A = U^T U in the column-major view
     int rc = gemm_rm(h, 'N', 'T', P, P, nao, 1.0, d_aoP, nao, d_aoP, nao, 0.0, d_chol, P);
     if (rc) return rc;
-    hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)P), dim3(256), 0, h->stream,
-                       d_chol, (int64_t)P, (int64_t)P, (int64_t)P);
+    if (nh > 0) {
+      // complex mode: A = (Re S)^2 + (Im S)^2, Im S = aoP_rot aoP^T
+      double* rot = (double*)isdf_ws(h, "fit_rot", sizeof(double) * (size_t)P * nao);
+      double* tmp = (double*)isdf_ws(h, "fit_tmp", sizeof(double) * (size_t)P * P);
+      if (!rot || !tmp) return ISDF_ERR_HIP;
+      hipLaunchKernelGGL(rotate_kernel, dim3((unsigned)cdiv(nao, 256), (unsigned)P), dim3(256), 0, h->stream, d_aoP, P, nh, rot);
+      rc = gemm_rm(h, 'N', 'T', P, P, nao, 1.0, rot, nao, d_aoP, nao, 0.0, tmp, P);
+      if (rc) return rc;
+      hipLaunchKernelGGL(square_add_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)P), dim3(256), 0, h->stream,
+                         d_chol, (int64_t)P, tmp, (int64_t)P, (int64_t)P);
+    } else {
+      hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)P), dim3(256), 0, h->stream,
+                         d_chol, (int64_t)P, (int64_t)P, (int64_t)P);
+    }
     if (reg > 0.0) {
       hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, h->stream, d_chol, P, maxdiag);
       hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, h->stream, d_chol, P,
@@ -119,15 +156,38 @@ extern "C" int isdf_fit_prepare(isdf_handle h, const double* d_ao, int nao, int6
 extern "C" int isdf_fit_apply(isdf_handle h, const double* d_chol, const double* d_aoP, int P, int nao,
                               const double* d_ao, int64_t ng, int64_t ld, int forward_only,
                               double* d_theta, int64_t ldt) {
+  return isdf_fit_apply_cplx(h, d_chol, d_aoP, P, nao, 0, d_ao, ng, ld, forward_only, d_theta, ldt);
+}
+
+extern "C" int isdf_fit_apply_cplx(isdf_handle h, const double* d_chol, const double* d_aoP, int P, int nao,
+                                   int nh, const double* d_ao, int64_t ng, int64_t ld, int forward_only,
+                                   double* d_theta, int64_t ldt) {
   if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, nh == 0 || 2 * nh == nao);
   ARG_CHECK(h, d_chol && d_aoP && d_ao && d_theta && P > 0 && nao > 0 && ng > 0 && ld >= ng && ldt >= ng);
   ARG_CHECK(h, P <= 65535 && ldt < (int64_t)2147483647 && ng < (int64_t)2147483647);
   // B = (aoP ao)^2 (P x ng, row-major) written straight into theta; then in the column-major view
   // X = B_cm U^-1 U^-T  (A = U^T U).
   int rc = gemm_rm(h, 'N', 'N', P, ng, nao, 1.0, d_aoP, nao, d_ao, ld, 0.0, d_theta, ldt);
   if (rc) return rc;
-  hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(ng, 256), (unsigned)P), dim3(256), 0, h->stream,
-                     d_theta, (int64_t)P, ng, ldt);
+  if (nh > 0) {
+    // complex mode: B = (aoP X)^2 + (aoP_rot X)^2, the second product in column chunks
+    const int64_t CH = 8192;
+    double* rot = (double*)isdf_ws(h, "fit_rot", sizeof(double) * (size_t)P * nao);
+    double* tmp = (double*)isdf_ws(h, "fit_tmpB", sizeof(double) * (size_t)P * CH);
+    if (!rot || !tmp) return ISDF_ERR_HIP;
+    hipLaunchKernelGGL(rotate_kernel, dim3((unsigned)cdiv(nao, 256), (unsigned)P), dim3(256), 0, h->stream, d_aoP, P, nh, rot);
+    for (int64_t c0 = 0; c0 < ng; c0 += CH) {
+      const int64_t nc = std::min(CH, ng - c0);
+      rc = gemm_rm(h, 'N', 'N', P, nc, nao, 1.0, rot, nao, d_ao + c0, ld, 0.0, tmp, CH);
+      if (rc) return rc;
+      hipLaunchKernelGGL(square_add_kernel, dim3((unsigned)cdiv(nc, 256), (unsigned)P), dim3(256), 0, h->stream,
+                         d_theta + c0, ldt, tmp, CH, nc);
+    }
+  } else {
+    hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(ng, 256), (unsigned)P), dim3(256), 0, h->stream,
+                       d_theta, (int64_t)P, ng, ldt);
+  }
   KERNEL_CHECK(h);
   // Theta = A^-1 B with A = Lr Lr^T (Lr = the factor read row-major, lower).  Blocked LEFT-looking
   // triangular solves: block row jb first receives the contribution of all finished block rows in

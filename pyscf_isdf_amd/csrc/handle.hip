@@ -57,7 +57,7 @@ int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out
 
 extern "C" {
 
-int isdf_abi_version(void) { return 5; }
+int isdf_abi_version(void) { return 6; }
 
 int isdf_create(int device_id, isdf_handle* out) {
   if (!out) return ISDF_ERR_ARG;
@@ -110,8 +110,8 @@ int isdf_set_stream(isdf_handle h, void* hip_stream) {
   h->stream = (hipStream_t)hip_stream;
   BLAS_TRY(h, rocblas_set_stream(h->blas, h->stream));
   for (auto& kv : h->plans) {
-    FFT_TRY(h, hipfftSetStream(kv.second.fwd, h->stream));
-    FFT_TRY(h, hipfftSetStream(kv.second.bwd, h->stream));
+    if (kv.second.fwd) FFT_TRY(h, hipfftSetStream(kv.second.fwd, h->stream));
+    if (kv.second.bwd) FFT_TRY(h, hipfftSetStream(kv.second.bwd, h->stream));
   }
   return ISDF_OK;
 }

@@ -129,8 +129,11 @@ __global__ __launch_bounds__(TPB) void update_kernel(
     const double* __restrict__ ao, int nao, int64_t ld, double* __restrict__ L, int64_t ldL,
     double* __restrict__ d, const int* __restrict__ wg_blk, const int64_t* __restrict__ wg_lo,
     const int64_t* __restrict__ blk_off, int j, int kmax, BlkState* __restrict__ st,
-    const double* __restrict__ pv, const double* __restrict__ pl) {
-  extern __shared__ double panel[];   // pv[nao] | pl[j]
+    const double* __restrict__ pv, const double* __restrict__ pl, int nh) {
+  // nh > 0: complex mode, rows [0,nh) = Re u, rows [nh,2nh) = Im u (nao = 2 nh):
+  //   S(p,i) = sum conj(u_p) u_i,  Re S = sum_m X[m,i] pv[m],  Im S = sum_m X[m,i] pvr[m],
+  //   pvr = [Im u_p ; -Re u_p];  Gram entry = Re^2 + Im^2.
+  extern __shared__ double panel[];   // pv[nao] | pl[j] (| pvr[nao] in complex mode)
   __shared__ double red[TPB / 64];
   const int b = wg_blk[blockIdx.x];
   if (st[b].done) return;
@@ -138,6 +141,10 @@ __global__ __launch_bounds__(TPB) void update_kernel(
   double* s_pl = panel + nao;
   for (int mu = threadIdx.x; mu < nao; mu += TPB) s_pv[mu] = pv[(int64_t)b * nao + mu];
   for (int t = threadIdx.x; t < j; t += TPB) s_pl[t] = pl[(int64_t)b * kmax + t];
+  double* s_pvr = panel + nao + j;
+  if (nh > 0)
+    for (int mu = threadIdx.x; mu < nao; mu += TPB)
+      s_pvr[mu] = (mu < nh) ? pv[(int64_t)b * nao + nh + mu] : -pv[(int64_t)b * nao + mu - nh];
   __syncthreads();
   const int64_t i = wg_lo[blockIdx.x] + threadIdx.x;
   const bool valid = i < blk_off[b + 1];
@@ -155,10 +162,19 @@ __global__ __launch_bounds__(TPB) void update_kernel(
       dnew = -1.0;
     } else {
       const double* __restrict__ pa = ao + i;
-      double s0 = 0.0;
+      double s0 = 0.0, s1 = 0.0;
+      if (nh > 0) {
 #pragma unroll 8
-      for (int mu = 0; mu < nao; ++mu) s0 = fma(pa[(int64_t)mu * ld], s_pv[mu], s0);
-      double col = s0 * s0;
+        for (int mu = 0; mu < nao; ++mu) {
+          const double x = pa[(int64_t)mu * ld];
+          s0 = fma(x, s_pv[mu], s0);
+          s1 = fma(x, s_pvr[mu], s1);
+        }
+      } else {
+#pragma unroll 8
+        for (int mu = 0; mu < nao; ++mu) s0 = fma(pa[(int64_t)mu * ld], s_pv[mu], s0);
+      }
+      double col = fma(s1, s1, s0 * s0);
       const double* __restrict__ pL = L + i;
 #pragma unroll 8
       for (int t = 0; t < j; ++t) col = fma(-pL[(int64_t)t * ldL], s_pl[t], col);
@@ -184,7 +200,15 @@ extern "C" int isdf_select_ip(isdf_handle h, const double* d_ao, int nao, int64_
                               const int64_t* blk_off, const int32_t* nip, double tol,
                               double tie_rtol, double* d_L, int64_t ldL, int64_t* d_piv,
                               int32_t* rank) {
+  return isdf_select_ip_cplx(h, d_ao, nao, 0, ld, nblk, blk_off, nip, tol, tie_rtol, d_L, ldL, d_piv, rank);
+}
+
+extern "C" int isdf_select_ip_cplx(isdf_handle h, const double* d_ao, int nao, int nh, int64_t ld, int nblk,
+                                   const int64_t* blk_off, const int32_t* nip, double tol,
+                                   double tie_rtol, double* d_L, int64_t ldL, int64_t* d_piv,
+                                   int32_t* rank) {
   if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, nh == 0 || 2 * nh == nao);
   ARG_CHECK(h, d_ao && blk_off && nip && d_L && d_piv && rank);
   ARG_CHECK(h, nao > 0 && nblk > 0 && tie_rtol >= 0.0 && tie_rtol < 1.0);
   const int64_t mtot = blk_off[nblk];
@@ -201,7 +225,7 @@ extern "C" int isdf_select_ip(isdf_handle h, const double* d_ao, int nao, int64_
     }
   }
   ARG_CHECK(h, kmax > 0);
-  const size_t panel_bytes = sizeof(double) * ((size_t)nao + kmax);
+  const size_t panel_bytes = sizeof(double) * ((size_t)nao * (nh > 0 ? 2 : 1) + kmax);
   ARG_CHECK(h, panel_bytes <= 150 * 1024);
   const int nwg = (int)h_wg_blk.size();
 
@@ -241,8 +265,8 @@ extern "C" int isdf_select_ip(isdf_handle h, const double* d_ao, int nao, int64_
                        d_d, d_off, d_nip, j, tol, kmax, d_st, d_piv, d_pv, d_pl);
     if (j == kmax) break;   // the last take_pivot only marks every block done
     ProfScope ps(h, "select_update_kernel[byte]", 8.0 * (double)mtot * (nao + j + 3));
-    hipLaunchKernelGGL(update_kernel, dim3(nwg), dim3(TPB), sizeof(double) * ((size_t)nao + j), h->stream,
-                       d_ao, nao, ld, d_L, ldL, d_d, d_wg_blk, d_wg_lo, d_off, j, kmax, d_st, d_pv, d_pl);
+    hipLaunchKernelGGL(update_kernel, dim3(nwg), dim3(TPB), sizeof(double) * ((size_t)nao * (nh > 0 ? 2 : 1) + j),
+                       h->stream, d_ao, nao, ld, d_L, ldL, d_d, d_wg_blk, d_wg_lo, d_off, j, kmax, d_st, d_pv, d_pl, nh);
   }
   KERNEL_CHECK(h);
   HIP_TRY(h, hipMemcpyAsync(h_st.data(), d_st, sizeof(BlkState) * nblk, hipMemcpyDeviceToHost, h->stream));

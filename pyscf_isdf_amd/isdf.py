@@ -72,6 +72,7 @@ class ISDF:
         self.tie_rtol = 1e-10
         self.reg_rel = 1e-12             # relative diagonal shift of A_PP in the global fit
         self.reg_used = 0.0
+        self.k_ip_factor = None           # k-points: points = c_isdf * nao * k_ip_factor (default nk)
         self.force_sharded = False       # run the multi-GPU code path even on one rank (tests)
         self.explicit_theta = False      # True: form Theta itself (second O(P^2 G) solve); same W in exact arithmetic
         self.fft_batch = None             # rows per FFT batch (None: sized from free memory)
@@ -132,8 +133,6 @@ class ISDF:
     def check_sanity(self):
         if getattr(self.cell, 'dimension', 3) != 3:
             raise RuntimeError('ISDF is implemented for 3-D periodic cells only')
-        if not self._is_gamma(self.kpts):
-            raise NotImplementedError('ISDF on MI355X: only the Gamma point is implemented in this round')
         return self
 
     @staticmethod
@@ -181,6 +180,8 @@ class ISDF:
 
     def build(self):
         self.check_sanity()
+        if not self._is_gamma(self.kpts):
+            return self._build_kpts()
         if self.comm.size > 1 or self.force_sharded:
             return self._build_sharded()
         cell, be = self.cell, self.backend
@@ -280,9 +281,11 @@ class ISDF:
         if omega is not None:
             raise NotImplementedError('range-separated Coulomb kernel (omega) is not implemented for ISDF')
         if kpts is None:
-            kpts = self.kpts if self._is_gamma(self.kpts) else self.kpts
-        if not self._is_gamma(kpts) or not self._is_gamma(kpts_band):
-            raise NotImplementedError('ISDF on MI355X: only the Gamma point is implemented in this round')
+            kpts = self.kpts
+        if not self._is_gamma(kpts) or not self._is_gamma(self.kpts):
+            return self._get_jk_kpts(dm, hermi, kpts, kpts_band, with_j, with_k, exxdiv)
+        if not self._is_gamma(kpts_band):
+            raise NotImplementedError('band k-points on a Gamma-point ISDF object are not implemented')
         if exxdiv is None:
             exxdiv = self.exxdiv
         if exxdiv not in (None, 'None', 'ewald'):
@@ -492,6 +495,169 @@ class ISDF:
                 self._add_ewald_exxdiv(d_dm, d_vk)
             t0 = self._tick('S7_get_k', t0)
             vk = be.to_host(d_vk).reshape(out_shape)
+        return vj, vk
+
+
+    # ---- k-points (BASELINE configs[3]); DESIGN.md "k-points" -----------------------------------------
+    def _build_kpts(self):
+        """Periodic parts u^k of all Bloch AOs -> real points/Theta (complex-mode S2/S3) -> one complex
+        W^q per difference vector q = k2 - k1.  The q list is split over the ranks (each rank holds the
+        fit, builds its share of the W^q and later the K terms that use them)."""
+        from . import pbc_tools
+        cell, be, comm = self.cell, self.backend, self.comm
+        self.timings = {}
+        t0 = time.perf_counter()
+        kpts = np.asarray(self.kpts, dtype=float).reshape(-1, 3)
+        nk = len(kpts)
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        nao = cell.nao_nr()
+        nh = nk * nao
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        coords = self.grids.coords
+        rcut = gto.estimate_rcut_per_shell(cell)
+        Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+        ao_args = (np.asarray(cell._atm), np.asarray(cell._bas), np.asarray(cell._env), Ls, rcut)
+        t0 = self._tick('host_setup', t0)
+
+        coords_soa = be.to_device(np.ascontiguousarray(coords.T))
+        X = self._buffer('aok', (2 * nh, G))
+        for k in range(nk):
+            be.eval_ao_k(*ao_args, kpts[k], True, coords_soa, X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao])
+        del coords_soa
+        self.ao = X
+        t0 = self._tick('S1_eval_ao', t0)
+
+        # S2 selection (complex mode); the number of points scales with the number of distinct pair
+        # families: c_isdf * nao * nk by default (capped by the grid)
+        P_target = int(min(self.c_isdf * nao * (self.k_ip_factor or nk), G))
+        if self.select == 'global':
+            theta = self._buffer('theta', (P_target, G))
+            piv = be.empty((1, P_target), dtype=torch.int64)
+            rank = be.select_ip_cplx(X, nh, [0, G], [P_target], -1.0, self.tie_rtol, theta, piv)
+            ip_dev = piv[0, :int(rank[0])].contiguous()
+            self.ip = be.to_host(ip_dev).astype(np.int64)
+        else:
+            owner = partition_grid_by_atom(coords, cell.atom_coords(), a)
+            perm = np.argsort(owner, kind='stable').astype(np.int64)
+            counts = np.bincount(owner, minlength=cell.natm)
+            blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)
+            nip = np.minimum(self.nip_per_atom() * (self.k_ip_factor or nk), counts).astype(np.int32)
+            kmax = int(nip.max())
+            Xs = be.empty((2 * nh, G))
+            be.gather_cols(X, be.to_device(perm), Xs)
+            L = be.empty((kmax, G))
+            piv = be.empty((cell.natm, kmax), dtype=torch.int64)
+            rank = be.select_ip_cplx(Xs, nh, blk_off, nip, -1.0, self.tie_rtol, L, piv)
+            del Xs, L
+            piv_h = be.to_host(piv)
+            self.ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(cell.natm)]).astype(np.int64)
+            ip_dev = be.to_device(self.ip)
+        P = len(self.ip)
+        t0 = self._tick('S2_select_ip', t0)
+
+        # S3 global fit, forward solve only (Y); the factor is applied to the (P, P) matrices
+        Y = self._buffer('theta', (max(P, P_target), G))[:P]
+        aoP_X = self._buffer('aoP', (P, 2 * nh))
+        chol = self._buffer('factor', (P, P))
+        self.reg_used = be.fit_prepare_cplx(X, nh, ip_dev, self.reg_rel, aoP_X, chol)
+        be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=True)
+        t0 = self._tick('S3_fit', t0)
+
+        # Bloch AOs at the points: phi^k(r_P) = exp(i k.r_P) u^k(r_P), (P, nao) complex per k
+        uP = be.to_host(aoP_X)                                   # (P, 2 nh)
+        r_ip = coords[self.ip]
+        self._aoP_k = []
+        for k in range(nk):
+            u = uP[:, k * nao:(k + 1) * nao] + 1j * uP[:, nh + k * nao:nh + (k + 1) * nao]
+            self._aoP_k.append(be.to_device(np.ascontiguousarray(u * np.exp(1j * r_ip.dot(kpts[k]))[:, None])))
+
+        # S4 + S5 per q (this rank's share)
+        self._qs, self._qindex = pbc_tools.unique_q(kpts)
+        nq = len(self._qs)
+        self._q_owner = np.arange(nq) % comm.size
+        w = cell.vol / G
+        batch = self.fft_batch or max(1, min(P, int((3 << 30) // (8 * G)) // 128 * 128 or 64))
+        self._Wq = {}
+        Wre = self._buffer('Wre', (P, P))
+        Wim = self._buffer('Wim', (P, P))
+        for iq in range(nq):
+            if self._q_owner[iq] != comm.rank:
+                continue
+            q = self._qs[iq]
+            coulG = be.to_device(pbc_tools.get_coulG(cell, q, mesh))
+            be.coulomb_Wq(Y, mesh, coulG, w, 0, P, batch, Wre, Wim, upper_only=True)
+            be.symmetrize_hermitian(Wre, Wim)
+            be.W_from_factor(chol, 0, Wre)
+            be.W_from_factor(chol, 0, Wim)
+            Wc = be.empty((P, P), dtype=torch.complex128)
+            be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * r_ip.dot(q))), Wc)
+            self._Wq[iq] = Wc
+        t0 = self._tick('S4S5_coulomb_W', t0)
+        self._built = True
+        self._k_built = kpts.copy()
+        return self
+
+    def _get_jk_kpts(self, dm, hermi, kpts, kpts_band, with_j, with_k, exxdiv):
+        if kpts_band is not None:
+            raise NotImplementedError('kpts_band for the k-point ISDF path is not implemented in this round')
+        ex = exxdiv if exxdiv is not None else self.exxdiv
+        if ex not in (None, 'None'):
+            raise NotImplementedError("k-point ISDF: only exxdiv=None is implemented")
+        cell, be, comm = self.cell, self.backend, self.comm
+        kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
+        if not self._built or getattr(self, '_k_built', None) is None or kpts.shape != self._k_built.shape \
+                or abs(kpts - self._k_built).max() > 1e-9:
+            self.kpts = kpts
+            self.build()
+        nk = len(kpts)
+        nao = cell.nao_nr()
+        nh = nk * nao
+        dm_in = np.asarray(dm)
+        dms = np.asarray(dm_in, dtype=np.complex128).reshape(-1, nk, nao, nao)
+        nset = dms.shape[0]
+        if hermi != 1 and with_j:
+            if abs(dms - dms.conj().transpose(0, 1, 3, 2)).max() > 1e-10:
+                raise NotImplementedError('non-Hermitian density matrices (complex density) are not implemented for J')
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        X = self.ao
+        vj = vk = None
+        t0 = time.perf_counter()
+        if with_j:
+            vj = np.zeros((nset, nk, nao, nao), dtype=np.complex128)
+            for s in range(nset):
+                rho = be.zeros((1, G))
+                for k in range(nk):
+                    dT = dms[s, k].T
+                    be.rho_k(X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao], G,
+                             be.to_device(np.ascontiguousarray(dT.real)), be.to_device(np.ascontiguousarray(dT.imag)),
+                             1.0 / nk, rho)
+                be.coulomb_potential(rho, mesh, a)
+                for k in range(nk):
+                    vre = be.empty((nao, nao))
+                    vim = be.empty((nao, nao))
+                    be.vj_k(X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao], G, rho, vre, vim)
+                    vj[s, k] = be.to_host(vre) + 1j * be.to_host(vim)
+            t0 = self._tick('S6_get_j', t0)
+            vj = vj.reshape(dm_in.shape)
+        if with_k:
+            P = len(self.ip)
+            d_vk = be.zeros((nset, nk, nao, nao), dtype=torch.complex128)
+            for s in range(nset):
+                d_dm = [be.to_device(np.ascontiguousarray(dms[s, k])) for k in range(nk)]
+                for k1 in range(nk):
+                    for k2 in range(nk):
+                        iq = self._qindex[k1, k2]
+                        if self._q_owner[iq] != comm.rank:
+                            continue
+                        be.get_k_pair(self._aoP_k[k1], self._aoP_k[k2], d_dm[k2], self._Wq[iq], 1.0 / nk, d_vk[s, k1])
+            if comm.size > 1:
+                flat = torch.view_as_real(d_vk)
+                comm.all_reduce_sum(flat)
+            t0 = self._tick('S7_get_k', t0)
+            vk = be.to_host(d_vk).reshape(dm_in.shape)
         return vj, vk
 
     # ---- ERIs from the factorisation (small systems; reached from SCF.get_jk's incore branch,

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -44,6 +44,16 @@ SIGNATURES = {
     'isdf_rho': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_i64]),
     'isdf_coulomb_potential': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),
     'isdf_vj_from_vR': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_i64, c_vp]),
+    'isdf_eval_ao_k': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_i64]),
+    'isdf_select_ip_cplx': (c_int, [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_i64, c_vp, c_vp]),
+    'isdf_fit_prepare_cplx': (c_int, [c_vp, c_vp, c_int, c_int, c_i64, c_vp, c_int, c_dbl, c_vp, c_vp, ctypes.POINTER(c_dbl)]),
+    'isdf_fit_apply_cplx': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_int, c_vp, c_i64]),
+    'isdf_coulomb_Wq': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_dbl, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64]),
+    'isdf_symmetrize_hermitian': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64]),
+    'isdf_finish_Wq': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),
+    'isdf_get_k_pair': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_dbl, c_vp]),
+    'isdf_rho_k': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_dbl, c_vp]),
+    'isdf_vj_k': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'isdf_gemm_nt': (c_int, [c_vp, c_int, c_int, c_i64, c_dbl, c_vp, c_i64, c_vp, c_i64, c_vp, c_dbl, c_vp, c_i64]),
     'isdf_get_k': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]),
 }

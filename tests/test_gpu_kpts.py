@@ -1,0 +1,124 @@
+"""GPU parity of the k-point path (through the C ABI) against oracle/kisdf.py and the reference's exact
+k-point exchange (oracle/fftdf.get_jk_kpts, pinned to test_fft.py:670-676)."""
+import numpy as np
+import pytest
+import torch
+import cells
+from pyscf_isdf_amd import gto, pbc_tools
+from oracle import ao as oao, fftdf, kisdf, c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def be():
+    from pyscf_isdf_amd.backend import HipBackend
+    return HipBackend(0)
+
+
+def _setup(nk=2, seed=11):
+    cell = cells.cell_he2_triclinic()
+    coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    rng = np.random.default_rng(seed)
+    kpts = rng.random((nk, 3)) * 0.6
+    kpts[0] = 0.0
+    aos = [np.asarray(x, dtype=complex) for x in
+           oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpts=kpts, rule='point')]
+    nao = cell.nao_nr()
+    c = rng.standard_normal((nk, nao, nao)) + 1j * rng.standard_normal((nk, nao, nao))
+    dms = np.einsum('kpi,kqi->kpq', c[:, :, :3], c[:, :, :3].conj())
+    return cell, coords, Ls, rcut, kpts, aos, dms
+
+
+def _gpu_X(be, cell, coords, Ls, rcut, kpts, periodic=True):
+    nk, nao, G = len(kpts), cell.nao_nr(), len(coords)
+    nh = nk * nao
+    X = be.empty((2 * nh, G))
+    cs = be.to_device(np.ascontiguousarray(coords.T))
+    for k in range(nk):
+        be.eval_ao_k(cell._atm, cell._bas, cell._env, Ls, rcut, kpts[k], periodic, cs,
+                     X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao])
+    return X
+
+
+def test_eval_ao_k(be):
+    """Bloch AOs and their periodic parts at Gamma and a generic k: 1e-12."""
+    cell, coords, Ls, rcut, kpts, aos, dms = _setup()
+    nk, nao = len(kpts), cell.nao_nr()
+    nh = nk * nao
+    for periodic in (False, True):
+        X = be.to_host(_gpu_X(be, cell, coords, Ls, rcut, kpts, periodic))
+        for k in range(nk):
+            ref = aos[k].T * (np.exp(-1j * coords.dot(kpts[k])) if periodic else 1.0)
+            got = X[k * nao:(k + 1) * nao] + 1j * X[nh + k * nao:nh + (k + 1) * nao]
+            assert abs(got - ref).max() < 1e-12
+    assert abs(kisdf.periodic_stack(aos, coords, kpts) - X).max() < 1e-12
+
+
+def test_select_and_fit_complex_mode(be):
+    """Complex-mode S2 (identical pivots vs the plain-C oracle on the same input) and S3."""
+    cell, coords, Ls, rcut, kpts, aos, dms = _setup()
+    X = kisdf.periodic_stack(aos, coords, kpts)
+    nh = X.shape[0] // 2
+    G = X.shape[1]
+    k = 60
+    piv_ref, L_ref = c_oracle.select_ip_cplx(X, k)
+    piv_np, _ = kisdf.select_ip(X, k)
+    assert np.array_equal(piv_ref, piv_np)
+    dX = be.to_device(X)
+    L = be.zeros((k, G))
+    piv = be.empty((1, k), dtype=torch.int64)
+    rank = be.select_ip_cplx(dX, nh, [0, G], [k], -1.0, 1e-10, L, piv)
+    assert rank[0] == k and np.array_equal(be.to_host(piv)[0], piv_ref)
+    assert abs(be.to_host(L) - L_ref).max() < 1e-9 * abs(L_ref).max()
+    # fit (explicit Theta) vs numpy
+    ip = np.sort(piv_ref)
+    aoP = be.empty((k, 2 * nh)); chol = be.empty((k, k)); theta = be.empty((k, G))
+    reg = be.fit_prepare_cplx(dX, nh, be.to_device(ip), 0.0, aoP, chol)
+    be.fit_apply_cplx(chol, aoP, nh, dX, G, theta)
+    ref = kisdf.fit_theta(X, ip, reg)
+    assert abs(be.to_host(theta) - ref).max() < 1e-7 * abs(ref).max()
+
+
+def test_coulomb_Wq(be):
+    """M^q and W^q for q = 0 and a generic q against the oracle's complex FFT construction."""
+    cell, coords, Ls, rcut, kpts, aos, dms = _setup()
+    X = kisdf.periodic_stack(aos, coords, kpts)
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    G = X.shape[1]
+    piv, _ = kisdf.select_ip(X, 24)
+    theta = kisdf.fit_theta(X, piv)
+    P = len(piv)
+    w = cell.vol / G
+    for q in (np.zeros(3), kpts[1] - kpts[0], kpts[0] - kpts[1]):
+        ref = kisdf.build_Wq(theta, a, mesh, q, coords[piv])
+        Wre = be.empty((P, P)); Wim = be.empty((P, P)); Wc = be.empty((P, P), dtype=torch.complex128)
+        be.coulomb_Wq(be.to_device(theta), mesh, be.to_device(pbc_tools.get_coulG(cell, q)), w, 0, P, 7, Wre, Wim, upper_only=True)
+        be.symmetrize_hermitian(Wre, Wim)
+        be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * coords[piv].dot(q))), Wc)
+        assert abs(be.to_host(Wc) - ref).max() < 1e-10 * abs(ref).max()
+
+
+@pytest.mark.parametrize('select', ['global', 'local'])
+def test_isdf_kpts_end_to_end(select):
+    """ISDF(cell, kpts).get_jk: J exact (vs the reference formula), K converging to the exact k-point
+    exchange; and equal to the oracle's k-ISDF on the same points."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell, coords, Ls, rcut, kpts, aos, dms = _setup()
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    vj_ref, vk_ref = fftdf.get_jk_kpts(aos, dms, a, mesh, coords, kpts)
+    df = ISDF(cell, kpts=kpts, c_isdf=20, select=select)
+    df.k_ip_factor = 2
+    vj, vk = df.get_jk(dms, kpts=kpts)
+    assert vj.shape == dms.shape and vj.dtype == np.complex128 and vk.dtype == np.complex128
+    assert abs(vj - vj_ref).max() < 1e-10
+    assert abs(vk - vk_ref).max() < 2e-5 * abs(vk_ref).max()
+    # same points through the oracle's k-ISDF formulas (explicit Theta, regularised like the product)
+    X = kisdf.periodic_stack(aos, coords, kpts)
+    theta = kisdf.fit_theta(X, df.ip, df.reg_used)
+    qs, qidx = kisdf.unique_q(kpts)
+    Ws = [kisdf.build_Wq(theta, a, mesh, q, coords[df.ip]) for q in qs]
+    vk_or = kisdf.get_k_kpts([ao[df.ip] for ao in aos], Ws, qidx, dms)
+    assert abs(vk - vk_or).max() < 1e-8 * abs(vk_or).max()

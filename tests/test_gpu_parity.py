@@ -374,4 +374,3 @@ def test_exxdiv_ewald_adds_madelung_SDS():
     S = aoT.dot(aoT.T) * cell.vol / aoT.shape[1]
     ref = gto.madelung(cell) * S.dot(dm).dot(S)
     assert abs((vk1 - vk0) - ref).max() < 1e-10
-    assert abs(S - np.eye(nao)).max() < 1.0 and abs(np.diag(S) - 1).max() < 1e-3   # normalised AOs

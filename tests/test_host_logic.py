@@ -55,14 +55,27 @@ def test_isdf_surface_and_errors():
     assert list(df.mesh) == [21, 21, 21] and df.grids.weights.shape == (9261,)
     assert abs(df.grids.weights.sum() - cell.vol) < 1e-9
     with pytest.raises(NotImplementedError):
-        df.get_jk(np.eye(6), kpts=np.array([0.1, 0.2, 0.3]))
+        df.get_jk(np.eye(6), kpts_band=np.array([0.1, 0.2, 0.3]))
     with pytest.raises(NotImplementedError):
         df.get_jk(np.eye(6), omega=0.3)
     with pytest.raises(NotImplementedError):
         df.get_jk(np.eye(6), exxdiv='vcut_sph')
-    df.kpts = np.array([[0.1, 0., 0.]])
     with pytest.raises(NotImplementedError):
-        df.check_sanity()
+        ISDF(cell, kpts=np.array([[0.1, 0., 0.], [0., 0., 0.]])).get_jk(np.zeros((2, 6, 6)), kpts_band=np.zeros(3))
+
+
+def test_coulG_q_matches_oracle_and_unique_q():
+    from pyscf_isdf_amd import pbc_tools
+    from oracle import pbc_tools as otools
+    cell = cells.cell_he2_triclinic()
+    for q in (np.zeros(3), np.array([0.13, -0.2, 0.31]), cell.make_kpts([2, 2, 2])[5]):
+        assert np.array_equal(pbc_tools.get_coulG(cell, q), otools.get_coulG(cell.lattice_vectors(), cell.mesh, q))
+    kpts = cell.make_kpts([2, 2, 1])
+    qs, idx = pbc_tools.unique_q(kpts)
+    assert idx.shape == (4, 4) and len(qs) == 9
+    for i1 in range(4):
+        for i2 in range(4):
+            assert abs(qs[idx[i1, i2]] - (kpts[i2] - kpts[i1])).max() < 1e-12
 
 
 def test_madelung_simple_cubic_textbook_value():
