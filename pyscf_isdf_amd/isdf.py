@@ -72,7 +72,7 @@ class ISDF:
         self.tie_rtol = 1e-10
         self.reg_rel = 1e-12             # relative diagonal shift of A_PP in the global fit
         self.reg_used = 0.0
-        self.k_ip_factor = None           # k-points: points = c_isdf * nao * k_ip_factor (default nk)
+        self.k_ip_factor = None           # k-points: points = c_isdf * nao * k_ip_factor (default min(nk, 2))
         self.force_sharded = False       # run the multi-GPU code path even on one rank (tests)
         self.explicit_theta = False      # True: form Theta itself (second O(P^2 G) solve); same W in exact arithmetic
         self.fft_batch = None             # rows per FFT batch (None: sized from free memory)
@@ -530,7 +530,8 @@ class ISDF:
 
         # S2 selection (complex mode); the number of points scales with the number of distinct pair
         # families: c_isdf * nao * nk by default (capped by the grid)
-        P_target = int(min(self.c_isdf * nao * (self.k_ip_factor or nk), G))
+        kfac = self.k_ip_factor or min(nk, 2)
+        P_target = int(min(self.c_isdf * nao * kfac, G))
         if self.select == 'global':
             theta = self._buffer('theta', (P_target, G))
             piv = be.empty((1, P_target), dtype=torch.int64)
@@ -542,7 +543,7 @@ class ISDF:
             perm = np.argsort(owner, kind='stable').astype(np.int64)
             counts = np.bincount(owner, minlength=cell.natm)
             blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)
-            nip = np.minimum(self.nip_per_atom() * (self.k_ip_factor or nk), counts).astype(np.int32)
+            nip = np.minimum(self.nip_per_atom() * kfac, counts).astype(np.int32)
             kmax = int(nip.max())
             Xs = be.empty((2 * nh, G))
             be.gather_cols(X, be.to_device(perm), Xs)
@@ -575,13 +576,24 @@ class ISDF:
         # S4 + S5 per q (this rank's share)
         self._qs, self._qindex = pbc_tools.unique_q(kpts)
         nq = len(self._qs)
-        self._q_owner = np.arange(nq) % comm.size
         w = cell.vol / G
         batch = self.fft_batch or max(1, min(P, int((3 << 30) // (8 * G)) // 128 * 128 or 64))
+        # W^{-q} = conj(W^q) (Theta is real, coulG_{-q}[-G] = coulG_q[G]): build one of each +-q pair
+        partner = -np.ones(nq, dtype=int)
+        for iq in range(nq):
+            for jq in range(nq):
+                if abs(self._qs[iq] + self._qs[jq]).max() < 1e-9:
+                    partner[iq] = jq
+        primary = [iq for iq in range(nq) if partner[iq] < 0 or partner[iq] >= iq]
+        self._q_owner = np.zeros(nq, dtype=int)
+        for n, iq in enumerate(primary):
+            self._q_owner[iq] = n % comm.size
+            if partner[iq] >= 0:
+                self._q_owner[partner[iq]] = n % comm.size
         self._Wq = {}
         Wre = self._buffer('Wre', (P, P))
         Wim = self._buffer('Wim', (P, P))
-        for iq in range(nq):
+        for iq in primary:
             if self._q_owner[iq] != comm.rank:
                 continue
             q = self._qs[iq]
@@ -593,6 +605,7 @@ class ISDF:
             Wc = be.empty((P, P), dtype=torch.complex128)
             be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * r_ip.dot(q))), Wc)
             self._Wq[iq] = Wc
+        self._q_partner = partner
         t0 = self._tick('S4S5_coulomb_W', t0)
         self._built = True
         self._k_built = kpts.copy()
@@ -652,7 +665,11 @@ class ISDF:
                         iq = self._qindex[k1, k2]
                         if self._q_owner[iq] != comm.rank:
                             continue
-                        be.get_k_pair(self._aoP_k[k1], self._aoP_k[k2], d_dm[k2], self._Wq[iq], 1.0 / nk, d_vk[s, k1])
+                        if iq in self._Wq:
+                            Wq = self._Wq[iq]
+                        else:                      # stored as its time-reversal partner: W^{-q} = conj(W^q)
+                            Wq = torch.conj_physical(self._Wq[self._q_partner[iq]])
+                        be.get_k_pair(self._aoP_k[k1], self._aoP_k[k2], d_dm[k2], Wq, 1.0 / nk, d_vk[s, k1])
             if comm.size > 1:
                 flat = torch.view_as_real(d_vk)
                 comm.all_reduce_sum(flat)

@@ -4,7 +4,7 @@ multi-rank sharding logic be exercised without a GPU (gloo, world_size 2).  The 
 import numpy as np
 import scipy.linalg
 import torch
-from oracle import ao as oao, isdf as oisdf, pbc_tools as tools
+from oracle import ao as oao, isdf as oisdf, kisdf as okisdf, pbc_tools as tools
 
 
 class OracleBackend:
@@ -134,3 +134,77 @@ class OracleBackend:
         for i in range(dm.shape[0]):
             M = ap[row0:row0 + nrows].dot(dm[i].numpy()).dot(ap.T) * w[row0:row0 + nrows]
             vk[i] = torch.from_numpy(ap[row0:row0 + nrows].T.dot(M).dot(ap))
+
+    # ---- k-points ----
+    def eval_ao_k(self, atm, bas, env, Ls, rcut, kpt, periodic_part, coords_soa, out_re, out_im):
+        c = coords_soa.numpy().T
+        v = np.asarray(oao.eval_ao(atm, bas, env, c, Ls, rcut, kpts=np.reshape(kpt, (1, 3)), rule='point')[0], dtype=complex)
+        if periodic_part:
+            v = v * np.exp(-1j * c.dot(kpt))[:, None]
+        out_re[:, :len(c)] = torch.from_numpy(np.ascontiguousarray(v.real.T))
+        out_im[:, :len(c)] = torch.from_numpy(np.ascontiguousarray(v.imag.T))
+
+    def select_ip_cplx(self, X, nh, blk_off, nip, tol, tie_rtol, L, piv):
+        rank = np.zeros(len(nip), dtype=np.int32)
+        A = X.numpy()
+        for b in range(len(nip)):
+            if nip[b] == 0:
+                continue
+            p, Lb = okisdf.select_ip(A[:, blk_off[b]:blk_off[b + 1]], int(nip[b]), tol=tol, tie_rtol=tie_rtol)
+            rank[b] = len(p)
+            piv[b, :len(p)] = torch.from_numpy(p)
+            L[:len(p), blk_off[b]:blk_off[b + 1]] = torch.from_numpy(Lb)
+        return rank
+
+    def fit_prepare_cplx(self, X, nh, ip, reg_rel, aoP, chol):
+        x = X.numpy()
+        xp = x[:, ip.numpy()]
+        xr = np.vstack([x[nh:], -x[:nh]])
+        aoP.copy_(torch.from_numpy(np.ascontiguousarray(xp.T)))
+        A = xp.T.dot(xp) ** 2 + xr[:, ip.numpy()].T.dot(xp) ** 2
+        A[np.diag_indices(len(A))] += reg_rel * A.diagonal().max()
+        chol.copy_(torch.from_numpy(np.linalg.cholesky(A)))
+        return reg_rel
+
+    def fit_apply_cplx(self, chol, aoP, nh, X, ng, theta, forward_only=False):
+        x = X.numpy()[:, :ng]
+        xr = np.vstack([x[nh:], -x[:nh]])
+        ap = aoP.numpy()
+        B = ap.dot(x) ** 2 + ap.dot(xr) ** 2
+        if forward_only:
+            theta[:, :ng] = torch.from_numpy(scipy.linalg.solve_triangular(chol.numpy(), B, lower=True))
+        else:
+            theta[:, :ng] = torch.from_numpy(scipy.linalg.cho_solve((chol.numpy(), True), B))
+
+    def coulomb_Wq(self, theta, mesh, coulG, weight, row0, nrows, batch, Wre, Wim, upper_only=False):
+        th = theta.numpy()
+        V = tools.ifft(tools.fft(th[row0:row0 + nrows], mesh) * coulG.numpy(), mesh)
+        M = weight * V.dot(th.T)
+        Wre[row0:row0 + nrows] = torch.from_numpy(np.ascontiguousarray(M.real))
+        Wim[row0:row0 + nrows] = torch.from_numpy(np.ascontiguousarray(M.imag))
+
+    def symmetrize_hermitian(self, Wre, Wim):
+        a, b = Wre.numpy(), Wim.numpy()
+        iu = np.triu_indices(len(a), 1)
+        a.T[iu] = a[iu]
+        b.T[iu] = -b[iu]
+
+    def finish_Wq(self, Wre, Wim, phase, Wc):
+        ph = phase.numpy()
+        Wc.copy_(torch.from_numpy((Wre.numpy() + 1j * Wim.numpy()) * ph[:, None] * ph.conj()[None, :]))
+
+    def get_k_pair(self, A1, A2, D2, Wq, scale, vk):
+        a1, a2 = A1.numpy(), A2.numpy()
+        X = a2.dot(D2.numpy()).dot(a2.conj().T) * Wq.numpy()
+        vk += torch.from_numpy(scale * a1.conj().T.dot(X).dot(a1))
+
+    def rho_k(self, ur, ui, ng, DTr, DTi, scale, rho):
+        u = ur.numpy()[:, :ng] + 1j * ui.numpy()[:, :ng]
+        T = (DTr.numpy() + 1j * DTi.numpy()).dot(u)
+        rho[0, :ng] += torch.from_numpy(scale * np.einsum('jg,jg->g', T, u.conj()).real)
+
+    def vj_k(self, ur, ui, ng, vR, vj_re, vj_im):
+        u = ur.numpy()[:, :ng] + 1j * ui.numpy()[:, :ng]
+        v = (u.conj() * vR.numpy().reshape(-1)[:ng]).dot(u.T)
+        vj_re.copy_(torch.from_numpy(np.ascontiguousarray(v.real)))
+        vj_im.copy_(torch.from_numpy(np.ascontiguousarray(v.imag)))

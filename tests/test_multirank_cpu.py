@@ -68,6 +68,58 @@ def test_two_ranks_match_one_rank():
     assert abs(vj1 - vj2).max() < 1e-10 and abs(vk1 - vk2).max() < 1e-8 * abs(vk1).max()
 
 
+def _run_kcase(comm):
+    _setup_path()
+    import cells
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he2_triclinic()
+    cell.mesh = np.array([9, 9, 9])
+    kpts = cell.make_kpts([2, 1, 1])
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(2)
+    c = rng.standard_normal((2, nao, nao)) + 1j * rng.standard_normal((2, nao, nao))
+    dms = np.einsum('kpi,kqi->kpq', c[:, :, :2], c[:, :, :2].conj())
+    df = ISDF(cell, kpts=kpts, c_isdf=4, select='local', backend=OracleBackend(), comm=comm)
+    vj, vk = df.get_jk(dms, kpts=kpts)
+    return df.ip.copy(), vj, vk
+
+
+def _kworker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _setup_path()
+    from pyscf_isdf_amd.parallel import Comm
+    out = _run_kcase(Comm.from_env())
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_kpoints_two_ranks_share_the_q_list():
+    """k-point path: the W^q builds and the K pair terms are split over the ranks by q; two gloo ranks
+    must reproduce the one-rank J and K (all-reduce of the K partial sums)."""
+    _setup_path()
+    from pyscf_isdf_amd.parallel import Comm
+    ip1, vj1, vk1 = _run_kcase(Comm())
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_kworker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ip2, vj2, vk2 = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(ip1, ip2)
+    assert abs(vj1 - vj2).max() < 1e-10 and abs(vk1 - vk2).max() < 1e-9 * abs(vk1).max()
+    assert abs(vk1 - vk1.conj().transpose(0, 2, 1)).max() < 1e-8 * abs(vk1).max()
+
+
 def test_split_range_covers_everything():
     _setup_path()
     from pyscf_isdf_amd.parallel import Comm
