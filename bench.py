@@ -137,8 +137,22 @@ def main():
     comm = Comm.from_env()
 
     cell = workloads.make_cell(args.workload)
-    dm, mo_coeff, mo_occ = workloads.make_dm(cell)
-    df = ISDF(cell, c_isdf=args.c_isdf, select=args.select, comm=comm)
+    kpts = workloads.make_kpts(args.workload, cell)
+    if kpts is None:
+        dm, mo_coeff, mo_occ = workloads.make_dm(cell)
+        df = ISDF(cell, c_isdf=args.c_isdf, select=args.select, comm=comm)
+    else:
+        # k-point workload (configs[3]): Hermitian D^k = C^k occ C^k^H with random unitary C^k
+        nao = cell.nao_nr()
+        rng = np.random.default_rng(20240203)
+        occ = np.zeros(nao)
+        occ[:cell.nelectron // 2] = 2
+        dm = []
+        for _ in range(len(kpts)):
+            c = np.linalg.qr(rng.standard_normal((nao, nao)) + 1j * rng.standard_normal((nao, nao)))[0]
+            dm.append((c * occ).dot(c.conj().T))
+        dm = np.array(dm)
+        df = ISDF(cell, kpts=kpts, c_isdf=args.c_isdf, select=args.select, comm=comm)
     be = df.backend
 
     def barrier():
@@ -149,7 +163,7 @@ def main():
 
     def step():
         df.build()
-        return df.get_jk(dm)
+        return df.get_jk(dm) if kpts is None else df.get_jk(dm, kpts=kpts)
 
     for _ in range(args.warmup):
         step()
@@ -214,13 +228,16 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(sec_per_step * 1e3, 2),
             'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': workloads.WORKLOADS[args.workload][1], 'natm': cell.natm, 'nao': nao, 'ngrids': G,
-                       'nip': P, 'c_isdf': args.c_isdf, 'select': args.select, 'parallelism': 'grid-shard x%d' % world},
+                       'nip': P, 'c_isdf': args.c_isdf, 'select': args.select, 'parallelism': ('grid-shard x%d' if kpts is None else 'q-shard x%d') % world,
+                       'nkpts': (1 if kpts is None else len(kpts))},
             'whole_path_algorithmic_GBps': round(alg_bytes / sec_per_step / 1e9, 1),
             'stage_seconds_last_step': {k: round(v, 4) for k, v in df.timings.items()},
-            'energies': {'EJ': float(np.einsum('ij,ji', vj, dm) / 2), 'EK': float(np.einsum('ij,ji', vk, dm) / 4)},
+            'energies': ({'EJ': float(np.einsum('ij,ji', vj, dm) / 2), 'EK': float(np.einsum('ij,ji', vk, dm) / 4)} if kpts is None else
+                         {'EJ': float(np.einsum('kij,kji', vj, dm).real / 2 / len(kpts)),
+                          'EK': float(np.einsum('kij,kji', vk, dm).real / 4 / len(kpts))}),
             'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and kpts is None:
             ncores = os.cpu_count() or 1
             val, sample = cpu_baseline(cell, args.c_isdf, dict(P=P))
             out['cpu_baseline'] = {'value': round(val, 1), 'unit': 's', 'cores': ncores, 'kind': 'port', 'sample': sample}
