@@ -97,7 +97,7 @@ __global__ __launch_bounds__(TPB) void take_pivot_kernel(
     const double* __restrict__ ao, int nao, int64_t ld, const double* __restrict__ L, int64_t ldL,
     const double* __restrict__ d, const int64_t* __restrict__ blk_off, const int* __restrict__ nip,
     int j, double tol_in, int kmax, BlkState* __restrict__ st, int64_t* __restrict__ piv,
-    double* __restrict__ pv, double* __restrict__ pl) {
+    double* __restrict__ pv, double* __restrict__ pl, int nh, double* __restrict__ pvr) {
   const int b = blockIdx.x;
   BlkState s = st[b];
   if (s.done) return;
@@ -113,6 +113,9 @@ __global__ __launch_bounds__(TPB) void take_pivot_kernel(
   }
   const int64_t p = blk_off[b] + s.cand;
   for (int mu = threadIdx.x; mu < nao; mu += TPB) pv[(int64_t)b * nao + mu] = ao[(int64_t)mu * ld + p];
+  if (nh > 0)   // rotated pivot vector [Im u_p ; -Re u_p] for the imaginary part of S
+    for (int mu = threadIdx.x; mu < nao; mu += TPB)
+      pvr[(int64_t)b * nao + mu] = (mu < nh) ? ao[(int64_t)(nh + mu) * ld + p] : -ao[(int64_t)(mu - nh) * ld + p];
   for (int t = threadIdx.x; t < j; t += TPB) pl[(int64_t)b * kmax + t] = L[(int64_t)t * ldL + p];
   if (threadIdx.x == 0) {
     piv[(int64_t)b * kmax + j] = s.cand;
@@ -125,11 +128,12 @@ __global__ __launch_bounds__(TPB) void take_pivot_kernel(
   }
 }
 
+template <bool LDS_PANEL>
 __global__ __launch_bounds__(TPB) void update_kernel(
     const double* __restrict__ ao, int nao, int64_t ld, double* __restrict__ L, int64_t ldL,
     double* __restrict__ d, const int* __restrict__ wg_blk, const int64_t* __restrict__ wg_lo,
     const int64_t* __restrict__ blk_off, int j, int kmax, BlkState* __restrict__ st,
-    const double* __restrict__ pv, const double* __restrict__ pl, int nh) {
+    const double* __restrict__ pv, const double* __restrict__ pl, int nh, const double* __restrict__ pvr) {
   // nh > 0: complex mode, rows [0,nh) = Re u, rows [nh,2nh) = Im u (nao = 2 nh):
   //   S(p,i) = sum conj(u_p) u_i,  Re S = sum_m X[m,i] pv[m],  Im S = sum_m X[m,i] pvr[m],
   //   pvr = [Im u_p ; -Re u_p];  Gram entry = Re^2 + Im^2.
@@ -137,15 +141,26 @@ __global__ __launch_bounds__(TPB) void update_kernel(
   __shared__ double red[TPB / 64];
   const int b = wg_blk[blockIdx.x];
   if (st[b].done) return;
-  double* s_pv = panel;
-  double* s_pl = panel + nao;
-  for (int mu = threadIdx.x; mu < nao; mu += TPB) s_pv[mu] = pv[(int64_t)b * nao + mu];
-  for (int t = threadIdx.x; t < j; t += TPB) s_pl[t] = pl[(int64_t)b * kmax + t];
-  double* s_pvr = panel + nao + j;
-  if (nh > 0)
-    for (int mu = threadIdx.x; mu < nao; mu += TPB)
-      s_pvr[mu] = (mu < nh) ? pv[(int64_t)b * nao + nh + mu] : -pv[(int64_t)b * nao + mu - nh];
-  __syncthreads();
+  // the pivot panel (pv | pl | pvr) is broadcast to all lanes: from LDS when it fits, otherwise straight
+  // from global memory (wave-uniform addresses, L2 resident) — the k-point mode with many AOs
+  const double* s_pv;
+  const double* s_pl;
+  const double* s_pvr;
+  if (LDS_PANEL) {
+    double* w_pv = panel;
+    double* w_pl = panel + nao;
+    double* w_pvr = panel + nao + j;
+    for (int mu = threadIdx.x; mu < nao; mu += TPB) w_pv[mu] = pv[(int64_t)b * nao + mu];
+    for (int t = threadIdx.x; t < j; t += TPB) w_pl[t] = pl[(int64_t)b * kmax + t];
+    if (nh > 0)
+      for (int mu = threadIdx.x; mu < nao; mu += TPB) w_pvr[mu] = pvr[(int64_t)b * nao + mu];
+    __syncthreads();
+    s_pv = w_pv; s_pl = w_pl; s_pvr = w_pvr;
+  } else {
+    s_pv = pv + (int64_t)b * nao;
+    s_pl = pl + (int64_t)b * kmax;
+    s_pvr = pvr + (int64_t)b * nao;
+  }
   const int64_t i = wg_lo[blockIdx.x] + threadIdx.x;
   const bool valid = i < blk_off[b + 1];
   double dnew = 0.0;
@@ -226,14 +241,14 @@ extern "C" int isdf_select_ip_cplx(isdf_handle h, const double* d_ao, int nao, i
   }
   ARG_CHECK(h, kmax > 0);
   const size_t panel_bytes = sizeof(double) * ((size_t)nao * (nh > 0 ? 2 : 1) + kmax);
-  ARG_CHECK(h, panel_bytes <= 150 * 1024);
+  const bool lds_panel = panel_bytes <= 64 * 1024;
   const int nwg = (int)h_wg_blk.size();
 
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t b_d = al(sizeof(double) * mtot), b_st = al(sizeof(BlkState) * nblk);
   const size_t b_wb = al(sizeof(int) * nwg), b_wl = al(sizeof(int64_t) * nwg);
   const size_t b_off = al(sizeof(int64_t) * (nblk + 1)), b_nip = al(sizeof(int) * nblk);
-  const size_t b_pv = al(sizeof(double) * (size_t)nblk * nao), b_pl = al(sizeof(double) * (size_t)nblk * kmax);
+  const size_t b_pv = al(sizeof(double) * (size_t)nblk * nao) * 2, b_pl = al(sizeof(double) * (size_t)nblk * kmax);
   char* ws = (char*)isdf_ws(h, "select", b_d + b_st + b_wb + b_wl + b_off + b_nip + b_pv + b_pl);
   if (!ws) return ISDF_ERR_HIP;
   double* d_d = (double*)ws; ws += b_d;
@@ -243,6 +258,7 @@ extern "C" int isdf_select_ip_cplx(isdf_handle h, const double* d_ao, int nao, i
   int64_t* d_off = (int64_t*)ws; ws += b_off;
   int* d_nip = (int*)ws; ws += b_nip;
   double* d_pv = (double*)ws; ws += b_pv;
+  double* d_pvr = d_pv + (size_t)nblk * nao;
   double* d_pl = (double*)ws;
 
   std::vector<BlkState> h_st(nblk);
@@ -262,11 +278,15 @@ extern "C" int isdf_select_ip_cplx(isdf_handle h, const double* d_ao, int nao, i
     hipLaunchKernelGGL(find_first_kernel, dim3(nwg), dim3(TPB), 0, h->stream, d_d, d_wg_blk, d_wg_lo,
                        d_off, d_st, tie_rtol);
     hipLaunchKernelGGL(take_pivot_kernel, dim3(nblk), dim3(TPB), 0, h->stream, d_ao, nao, ld, d_L, ldL,
-                       d_d, d_off, d_nip, j, tol, kmax, d_st, d_piv, d_pv, d_pl);
+                       d_d, d_off, d_nip, j, tol, kmax, d_st, d_piv, d_pv, d_pl, nh, d_pvr);
     if (j == kmax) break;   // the last take_pivot only marks every block done
     ProfScope ps(h, "select_update_kernel[byte]", 8.0 * (double)mtot * (nao + j + 3));
-    hipLaunchKernelGGL(update_kernel, dim3(nwg), dim3(TPB), sizeof(double) * ((size_t)nao * (nh > 0 ? 2 : 1) + j),
-                       h->stream, d_ao, nao, ld, d_L, ldL, d_d, d_wg_blk, d_wg_lo, d_off, j, kmax, d_st, d_pv, d_pl, nh);
+    if (lds_panel)
+      hipLaunchKernelGGL(update_kernel<true>, dim3(nwg), dim3(TPB), sizeof(double) * ((size_t)nao * (nh > 0 ? 2 : 1) + j),
+                         h->stream, d_ao, nao, ld, d_L, ldL, d_d, d_wg_blk, d_wg_lo, d_off, j, kmax, d_st, d_pv, d_pl, nh, d_pvr);
+    else
+      hipLaunchKernelGGL(update_kernel<false>, dim3(nwg), dim3(TPB), 0, h->stream, d_ao, nao, ld, d_L, ldL, d_d,
+                         d_wg_blk, d_wg_lo, d_off, j, kmax, d_st, d_pv, d_pl, nh, d_pvr);
   }
   KERNEL_CHECK(h);
   HIP_TRY(h, hipMemcpyAsync(h_st.data(), d_st, sizeof(BlkState) * nblk, hipMemcpyDeviceToHost, h->stream));

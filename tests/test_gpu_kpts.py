@@ -122,3 +122,17 @@ def test_isdf_kpts_end_to_end(select):
     Ws = [kisdf.build_Wq(theta, a, mesh, q, coords[df.ip]) for q in qs]
     vk_or = kisdf.get_k_kpts([ao[df.ip] for ao in aos], Ws, qidx, dms)
     assert abs(vk - vk_or).max() < 1e-8 * abs(vk_or).max()
+
+
+def test_select_complex_mode_panel_from_global_memory(be):
+    """Many AOs x k-points: the pivot panel (2 x 9000 doubles) no longer fits the LDS staging budget and
+    is broadcast from global memory; pivots must still equal the plain-C oracle's."""
+    rng = np.random.default_rng(8)
+    nh, m, k = 4500, 1500, 12
+    X = rng.standard_normal((2 * nh, m)) * np.exp(-2.0 * rng.random(m))
+    piv_ref, L_ref = c_oracle.select_ip_cplx(X, k)
+    L = be.zeros((k, m))
+    piv = be.empty((1, k), dtype=torch.int64)
+    rank = be.select_ip_cplx(be.to_device(X), nh, [0, m], [k], -1.0, 1e-10, L, piv)
+    assert rank[0] == k and np.array_equal(be.to_host(piv)[0], piv_ref)
+    assert abs(be.to_host(L) - L_ref).max() < 1e-9 * abs(L_ref).max()

@@ -374,3 +374,33 @@ def test_exxdiv_ewald_adds_madelung_SDS():
     S = aoT.dot(aoT.T) * cell.vol / aoT.shape[1]
     ref = gto.madelung(cell) * S.dot(dm).dot(S)
     assert abs((vk1 - vk0) - ref).max() < 1e-10
+
+
+def test_full_size_properties_diamond222():
+    """BASELINE configs[1] at full size (diamond 2x2x2, gth-dzvp, 80^3, c=10: N=208, G=512000, P=2080),
+    checked through size-independent properties: J and K symmetric, linear in D, both fit routes
+    (explicit Theta vs factor) give the same K energy, W symmetric, exact J energy positive, and the
+    ISDF K energy within the c=10 fitting error of what the global-selection yardstick gives."""
+    from pyscf_isdf_amd import workloads
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = workloads.make_cell('diamond-222-dzvp-80')
+    dm, c, occ = workloads.make_dm(cell)
+    nao = cell.nao_nr()
+    assert nao == 208 and int(np.prod(cell.mesh)) == 512000
+    df = ISDF(cell, c_isdf=10, select='local')
+    vj, vk = df.get_jk(dm)
+    assert len(df.ip) == 2080 and len(np.unique(df.ip)) == 2080
+    assert abs(vj - vj.T).max() < 1e-9 and abs(vk - vk.T).max() < 1e-8
+    W = df.backend.to_host(df.W)
+    assert abs(W - W.T).max() < 1e-8 * abs(W).max()
+    vj2, vk2 = df.get_jk(np.stack([dm, -0.5 * dm]))
+    assert abs(vj2[1] + 0.5 * vj).max() < 1e-9 and abs(vk2[1] + 0.5 * vk).max() < 1e-8
+    ej, ek = np.einsum('ij,ji', vj, dm) / 2, np.einsum('ij,ji', vk, dm) / 4
+    assert ej > 0 and ek > 0
+    df2 = ISDF(cell, c_isdf=10, select='local')
+    df2.explicit_theta = True
+    ek2 = np.einsum('ij,ji', df2.get_jk(dm, with_j=False)[1], dm) / 4
+    assert abs(ek - ek2) < 1e-8                     # same W through the two fit routes (1e-6 Eh target)
+    df3 = ISDF(cell, c_isdf=10, select='global')
+    ek3 = np.einsum('ij,ji', df3.get_jk(dm, with_j=False)[1], dm) / 4
+    assert abs(ek - ek3) < 2e-3                     # local vs global selection: both within the c=10 fitting error
