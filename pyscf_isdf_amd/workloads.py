@@ -12,6 +12,8 @@ WORKLOADS = {
                              'configs[2]: diamond 4x4x4, gth-dzvp, 120^3, c_isdf=10'),
     'diamond-333-dzvp-96': (lambda: gto.diamond_supercell(3, 'gth-dzvp', (96, 96, 96)),
                             'intermediate: diamond 3x3x3, gth-dzvp, 96^3'),
+    'water64-dzvp-160': (lambda: water64('gth-dzvp', (160, 160, 160)),
+                         'configs[4]: 64 H2O box, gth-dzvp, 160^3 (needs >= 4 GPUs: Theta is 482 GB)'),
     'mgo-333-dzvp-k222': (lambda: mgo_supercell(3, 'gth-dzvp', (96, 96, 96)),
                           'configs[3]: MgO 3x3x3, gth-dzvp, 96^3, 2x2x2 k-mesh'),
     'mgo-222-dzvp-k222': (lambda: mgo_supercell(2, 'gth-dzvp', (64, 64, 64)),
@@ -27,6 +29,17 @@ def mgo_supercell(n, basis, mesh):
     prim = gto.Cell(atom=[('Mg', (0., 0., 0.)), ('O', (a0 / 2, a0 / 2, a0 / 2))], a=a, basis=basis, mesh=(8, 8, 8),
                     pseudo='gth-pade')
     return gto.super_cell(prim, [n, n, n], mesh=mesh)
+
+
+def water64(basis, mesh):
+    """64-molecule liquid-water box, L = 12.4138 A (geometry: pyscf_isdf_amd/data/water64.xyz, the
+    coordinates listed in examples/2-benchmark/fock_multigrid.py:10-205 of the reference)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'water64.xyz')
+    with open(path) as f:
+        rows = [ln.split() for ln in f.read().splitlines()[2:] if ln.strip()]
+    atoms = [(r[0], (float(r[1]), float(r[2]), float(r[3]))) for r in rows]
+    return gto.Cell(atom=atoms, a=np.eye(3) * 12.4138, basis=basis, mesh=mesh, pseudo='gth-pade')
 
 
 def make_kpts(name, cell):

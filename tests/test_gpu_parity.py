@@ -270,7 +270,9 @@ def test_isdf_object_vs_oracle_pipeline_diamond():
 
 
 @pytest.mark.parametrize('M,N,K,scaled', [(128, 128, 4096, False), (130, 257, 4112, True), (7, 300, 9261, True),
-                                          (384, 520, 65536, False), (64, 64, 17, False), (1, 1, 1, True)])
+                                          (384, 520, 65536, False), (64, 64, 17, False), (1, 1, 1, True),
+                                          # 256-row tile variant (aligned, K % 32 == 0, M fills the tile)
+                                          (512, 300, 8192, False), (1000, 130, 65536, True), (256, 128, 32, False)])
 def test_gemm_nt_mfma(be, M, N, K, scaled):
     """The FP64 MFMA kernel behind W and vj: C = alpha A (B.*s)^T + beta C against numpy, incl. ragged
     tiles, odd K / unaligned rows (generic path) and multi-slab reduction.  1e-12 relative to |A||B|."""
