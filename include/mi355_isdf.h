@@ -198,6 +198,16 @@ int isdf_coulomb_potential(isdf_handle h, double* d_rho_inout, int nset, int64_t
 int isdf_vj_from_vR(isdf_handle h, const double* d_ao, int nao, int64_t ng, int64_t ld,
                     const double* d_vR, int nset, int64_t ldv, double* d_vj);
 
+/* The reference's EXACT exchange on the device (pyscf/pbc/df/fft_jk.py:177-302, Gamma point, occupied-
+ * orbital form :235-238,256-259): for AO rows i in [i0, i0+ni)
+ *   vk[i, l] = (vol/G) sum_g [ sum_j ifft(coulG fft(ao_i mo_j))(g) mo_j(g) ] ao_l(g),   mo = C^T ao,
+ * d_C (nao, nocc) = occupied MO coefficients times sqrt(occupation).  N*nocc FFT pairs — the cost
+ * ISDF removes; provided to MEASURE the fitting error of the ISDF K at full size, not as the fast path.
+ * max_rows = pair-density rows convolved per pass (memory: 24 * max_rows * G bytes). */
+int isdf_get_k_exact(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, int64_t ld,
+                     const double* d_C, int nocc, const int32_t mesh[3], const double a[9],
+                     int i0, int ni, int max_rows, double* d_vk);
+
 /* S7. K from the interpolation factorisation:
  *   vk = aoP^T [ (aoP dm aoP^T) .* W ] aoP   for rows [row0,row0+nrows) of the Hadamard matrix
  * (row-sharded partial sums for multi-GPU; pass row0=0,nrows=P for the whole thing). */

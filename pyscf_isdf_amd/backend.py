@@ -201,6 +201,14 @@ class HipBackend:
         self.handle.call('isdf_get_k', self._p(aoP), aoP.shape[0], aoP.shape[1], self._p(W), W.stride(0), int(row0),
                          int(nrows), self._p(dm), dm.shape[0], self._p(vk))
 
+    def get_k_exact(self, ao, ngrids, C, mesh, a, i0, ni, max_rows, vk):
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert C.is_contiguous() and vk.is_contiguous()
+        self.handle.call('isdf_get_k_exact', self._p(ao), ao.shape[0], int(ngrids), ao.stride(0), self._p(C), C.shape[1],
+                         _np_ptr(mesh), _np_ptr(a), int(i0), int(ni), int(max_rows), self._p(vk))
+
     def gemm_nt(self, A, B, C, alpha=1.0, beta=0.0, kscale=None):
         """C = alpha * A (B .* kscale)^T + beta * C; A (M,K), B (N,K) row-major, K contiguous."""
         self._stream()

@@ -28,6 +28,27 @@ __global__ void hadamard_kernel(double* __restrict__ M, int64_t ldm, const doubl
   M[r * ldm + c] *= W[r * ldw + c];
 }
 
+// rho[(i,j), g] = ao[i0+i, g] * mo[j, g]
+__global__ void pair_rows_kernel(const double* __restrict__ ao, int64_t ld, const double* __restrict__ mo, int64_t ldmo,
+                                 int nocc, int64_t ng, double* __restrict__ R) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  const int row = blockIdx.y;               // i * nocc + j
+  const int i = row / nocc, jj = row % nocc;
+  R[(int64_t)row * ng + g] = ao[(int64_t)i * ld + g] * mo[(int64_t)jj * ldmo + g];
+}
+
+// vdm[i, g] = sum_j R[(i,j), g] * mo[j, g]
+__global__ void pair_reduce_kernel(const double* __restrict__ R, const double* __restrict__ mo, int64_t ldmo, int nocc,
+                                   int64_t ng, double* __restrict__ vdm) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  const int i = blockIdx.y;
+  double s = 0.0;
+  for (int jj = 0; jj < nocc; ++jj) s = fma(R[((int64_t)i * nocc + jj) * ng + g], mo[(int64_t)jj * ldmo + g], s);
+  vdm[(int64_t)i * ng + g] = s;
+}
+
 }  // namespace
 
 extern "C" int isdf_rho(isdf_handle h, const double* d_ao, int nao, int64_t ng, int64_t ld,
@@ -112,6 +133,43 @@ extern "C" int isdf_get_k(isdf_handle h, const double* d_aoP, int P, int nao, co
       rc = gemm_rm(h, 'T', 'N', nao, nao, nr, 1.0, d_aoP + (int64_t)r * nao, nao, Y, nao, r == row0 ? 0.0 : 1.0, vk, nao);
       if (rc) return rc;
     }
+  }
+  return ISDF_OK;
+}
+
+extern "C" int isdf_get_k_exact(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, int64_t ld,
+                                const double* d_C, int nocc, const int32_t mesh[3], const double a[9],
+                                int i0, int ni, int max_rows, double* d_vk) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_ao && d_C && mesh && a && d_vk && nao > 0 && nocc > 0 && max_rows >= nocc);
+  ARG_CHECK(h, ngrids == (int64_t)mesh[0] * mesh[1] * mesh[2] && ld >= ngrids);
+  ARG_CHECK(h, i0 >= 0 && ni >= 0 && i0 + ni <= nao && nocc <= 65535);
+  if (ni == 0) return ISDF_OK;
+  const int64_t G = ngrids;
+  const int bi = std::max(1, std::min(ni, max_rows / nocc));        // AO rows per pass
+  double* mo = (double*)isdf_ws(h, "kx_mo", sizeof(double) * (size_t)nocc * G);
+  double* R = (double*)isdf_ws(h, "kx_R", sizeof(double) * (size_t)bi * nocc * G);
+  double* vdm = (double*)isdf_ws(h, "kx_vdm", sizeof(double) * (size_t)bi * G);
+  if (!mo || !R || !vdm) return ISDF_ERR_HIP;
+  // occupied orbitals on the grid: mo = C^T ao  (C is (nao, nocc), already scaled by sqrt(occ))
+  int rc = gemm_rm(h, 'T', 'N', nocc, G, nao, 1.0, d_C, nocc, d_ao, ld, 0.0, mo, G);
+  if (rc) return rc;
+  const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) +
+                     a[2] * (a[3] * a[7] - a[4] * a[6]);
+  const double w = fabs(det) / (double)G;
+  for (int r = i0; r < i0 + ni; r += bi) {
+    const int nb = std::min(bi, i0 + ni - r);
+    ARG_CHECK(h, nb * nocc <= 65535);
+    hipLaunchKernelGGL(pair_rows_kernel, dim3((unsigned)cdiv(G, 256), (unsigned)(nb * nocc)), dim3(256), 0, h->stream,
+                       d_ao + (int64_t)r * ld, ld, mo, G, nocc, G, R);
+    KERNEL_CHECK(h);
+    rc = isdf_coulomb_rows(h, R, nb * nocc, G, mesh, a, nb * nocc, R, G);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)cdiv(G, 256), (unsigned)nb), dim3(256), 0, h->stream, R, mo, G,
+                       nocc, G, vdm);
+    KERNEL_CHECK(h);
+    rc = gemm_nt_f64(h, nb, nao, G, w, vdm, G, d_ao, ld, 0.0, d_vk + (int64_t)r * nao, nao);
+    if (rc) return rc;
   }
   return ISDF_OK;
 }

@@ -324,6 +324,41 @@ class ISDF:
             vk = be.to_host(d_vk).reshape(dm_in.shape)
         return vj, vk
 
+    def get_k_exact(self, dm=None, mo_coeff=None, mo_occ=None, max_rows=None):
+        """The reference's exact exchange (FFTDF.get_jk's K, fft_jk.py:177-302) evaluated on the GPU with
+        the same device primitives — N*nocc FFT pairs.  Used to measure the ISDF fitting error at full
+        size.  Needs the occupied orbitals (mo_coeff, mo_occ) or a positive semidefinite dm."""
+        if not self._is_gamma(self.kpts):
+            raise NotImplementedError
+        if self.ao is None:
+            self.build()
+        be = self.backend
+        nao = self.cell.nao_nr()
+        if mo_coeff is None:
+            mo_coeff = getattr(dm, 'mo_coeff', None)
+            mo_occ = getattr(dm, 'mo_occ', None)
+        if mo_coeff is None:
+            s, u = np.linalg.eigh(np.asarray(dm, dtype=float))
+            if s.min() < -1e-10 * abs(s).max():
+                raise ValueError('get_k_exact needs occupied orbitals or a positive semidefinite density matrix')
+            keep = s > 1e-12 * s.max()
+            c = u[:, keep] * np.sqrt(s[keep])
+        else:
+            occ = np.asarray(mo_occ, dtype=float)
+            c = np.asarray(mo_coeff, dtype=float)[:, occ > 0] * np.sqrt(occ[occ > 0])
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(self.cell.lattice_vectors(), dtype=float)
+        nocc = c.shape[1]
+        if max_rows is None:
+            max_rows = max(nocc, int((4 << 30) // (8 * G)) // nocc * nocc)
+        vk = be.empty((nao, nao))
+        lo, hi = self.comm.split_range(nao)
+        if self.comm.size > 1 or self.force_sharded:
+            raise NotImplementedError('get_k_exact is a single-GPU verification path')
+        be.get_k_exact(self.ao, G, be.to_device(np.ascontiguousarray(c)), mesh, a, 0, nao, max_rows, vk)
+        return be.to_host(vk)
+
     def overlap(self):
         """AO overlap by quadrature on the FFT grid, S = (vol/G) ao ao^T (device, cached).  The
         reference takes the analytic lattice-sum overlap (df_jk.py:1447); on the meshes this path

@@ -406,3 +406,22 @@ def test_full_size_properties_diamond222():
     df3 = ISDF(cell, c_isdf=10, select='global')
     ek3 = np.einsum('ij,ji', df3.get_jk(dm, with_j=False)[1], dm) / 4
     assert abs(ek - ek3) < 2e-3                     # local vs global selection: both within the c=10 fitting error
+
+
+def test_exact_exchange_on_gpu_matches_reference_pin():
+    """isdf_get_k_exact = the reference's FFTDF K (occupied-orbital form): reproduces the reference's
+    fp(vk) for dm = I (test_fft.py:645) and the oracle's exact K for a rank-deficient random dm."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    nao = cell.nao_nr()
+    df = ISDF(cell, c_isdf=2, select='global')
+    vk = df.get_k_exact(np.eye(nao))
+    assert abs(tools.fp(vk) - 4.290076429522121) < 1e-8
+    rng = np.random.default_rng(6)
+    c = rng.standard_normal((nao, 2))
+    occ = np.array([2.0, 1.0])
+    dm = (c * occ).dot(c.T)
+    aoT = _oracle_ao(cell)[0]
+    ref = fftdf.get_k(aoT.T, dm, cell.lattice_vectors(), cell.mesh, mo_coeff=c, mo_occ=occ)
+    assert abs(df.get_k_exact(mo_coeff=c, mo_occ=occ, max_rows=3) - ref).max() < 1e-10
+    assert abs(df.get_k_exact(dm) - ref).max() < 1e-10

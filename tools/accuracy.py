@@ -1,0 +1,30 @@
+"""ISDF fitting error at full size: ISDF K vs the reference's exact exchange (both on the GPU)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pyscf_isdf_amd import workloads
+from pyscf_isdf_amd.isdf import ISDF
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'diamond-222-dzvp-80'
+cs = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [10]
+selects = sys.argv[3].split(',') if len(sys.argv) > 3 else ['local']
+cell = workloads.make_cell(name)
+dm, c, occ = workloads.make_dm(cell)
+nocc = int((occ > 0).sum())
+print(name, 'nao', cell.nao_nr(), 'nocc', nocc, 'ngrids', int(np.prod(cell.mesh)), flush=True)
+ref = None
+for sel in selects:
+    for cc in cs:
+        df = ISDF(cell, c_isdf=cc, select=sel)
+        t0 = time.perf_counter()
+        vk = df.get_jk(dm, with_j=False)[1]
+        t1 = time.perf_counter()
+        if ref is None:
+            ref = df.get_k_exact(mo_coeff=c, mo_occ=occ)
+            df.backend.synchronize()
+            print('exact K (N*nocc = %d FFT pairs) on the GPU: %.1f s' % (cell.nao_nr() * nocc, time.perf_counter() - t1), flush=True)
+        ek, ek0 = np.einsum('ij,ji', vk, dm) / 4, np.einsum('ij,ji', ref, dm) / 4
+        print('select=%-6s c=%2d P=%6d  build+K %.2f s   E_K(ISDF) %.8f  E_K(exact) %.8f  dE_K %.2e Eh (%.1e rel)  max|dK| %.2e'
+              % (sel, cc, len(df.ip), t1 - t0, ek, ek0, ek - ek0, abs(ek - ek0) / ek0, abs(vk - ref).max()), flush=True)
+        df.reset()
+        del df
