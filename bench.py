@@ -204,7 +204,8 @@ def main():
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_bench_cfg3_fetch_write.json')) as f:
                 pmc = json.load(f)
             for k, v in pmc.items():
-                if k.strip().startswith('void') and args.workload == 'diamond-444-dzvp-120' and world == 1:
+                if k.startswith('gemm_nt_mfma_kernel') and 'FETCH_SIZE_KB_per_launch' in v and v['launches'] > 4 \
+                        and args.workload == 'diamond-444-dzvp-120' and world == 1:
                     traffic = dict(bytes_per_launch=round((2 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024),
                                    algorithmic_bytes_per_launch=round(8.0 * (512 + 8320 + 256) * 1728000),
                                    source='profiles/r01_pmc_bench_cfg3_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
