@@ -214,7 +214,7 @@ class HipBackend:
         self._stream()
         M, K = A.shape
         N = B.shape[0]
-        assert B.shape[1] == K and C.shape == (M, N) and A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1
+        assert B.shape[1] == K and tuple(C.shape) == (M, N) and A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1
         ks = self._p(kscale) if kscale is not None else _vp(0)
         self.handle.call('isdf_gemm_nt', M, N, K, float(alpha), self._p(A), A.stride(0), self._p(B), B.stride(0), ks,
                          float(beta), self._p(C), C.stride(0))

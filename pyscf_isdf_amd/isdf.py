@@ -485,11 +485,15 @@ class ISDF:
             del full, send
             for q in range(R):
                 if nrow[q]:
-                    # W[bat_q, :] += w V[bat_q, S_r] Theta[:, S_r]^T   (partial over this rank's slice)
-                    be.gemm_nt(recv[q], theta, self.W[bat[q][0]:bat[q][1]], alpha=w, beta=0.0)
+                    # W[bat_q, c0:] = w V[bat_q, S_r] Theta[c0:, S_r]^T  (partial over this rank's slice).
+                    # W is symmetric: only the columns from the batch's first row on are computed and
+                    # the lower part is mirrored after the all-reduce (half the flops).
+                    c0 = bat[q][0]
+                    be.gemm_nt(recv[q], theta[c0:], self.W[bat[q][0]:bat[q][1], c0:], alpha=w, beta=0.0)
             del recv
         del theta
         comm.all_reduce_sum(self.W)
+        be.symmetrize_upper(self.W)
         if not self.explicit_theta:
             be.W_from_factor(chol, 0, self.W)
         t0 = self._tick('S4S5_coulomb_W', t0)
