@@ -53,7 +53,6 @@ struct GemmArgs {
   int64_t nunits, nunits_pad;    // nunits_pad: rounded up to a multiple of 8 (XCD remap)
   double alpha, beta;            // used only when direct
   int direct;
-  int debug_nomem;               // experiment only: skip operand reloads after the first chunk (wrong results)
 };
 
 // FAST: lda, ldb even (16-byte aligned rows given 16-byte aligned bases) and no K tail handling
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_nt_mfma_kernel(GemmArgs g) {
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    if (c + 1 < nchunks && !g.debug_nomem) ISDF_LOAD_CHUNK(c + 1)
+    if (c + 1 < nchunks) ISDF_LOAD_CHUNK(c + 1)
     const double* pa = &sA[buf][(wm * 64 + frow) * LDT + fk];
     const double* pb = &sB[buf][(wn * 64 + frow) * LDT + fk];
     // fragments of k-step kk+1 are fetched from LDS while the 16 MFMAs of k-step kk run
@@ -367,7 +366,6 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
   g.nunits = ntiles * g.nslab;
   g.nunits_pad = cdiv(g.nunits, 8) * 8;
   g.alpha = alpha; g.beta = beta;
-  g.debug_nomem = getenv("ISDF_GEMM_NOMEM") ? 1 : 0;
   if (g.nslab == 1) {
     g.direct = 1; g.P = C; g.ldp = ldc; g.slab_stride = 0;
   } else {

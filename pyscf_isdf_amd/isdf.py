@@ -736,10 +736,50 @@ class ISDF:
     get_eri = get_ao_eri
 
     def get_pp(self, kpts=None):
-        raise NotImplementedError('hcore terms are outside the ISDF hot path; use FFTDF.get_pp')
+        raise NotImplementedError('GTH pseudopotential matrix elements are outside the ISDF hot path; use FFTDF.get_pp')
 
     def get_nuc(self, kpts=None):
-        raise NotImplementedError('hcore terms are outside the ISDF hot path; use FFTDF.get_nuc')
+        """Nuclear-attraction AO matrix with the G=0 term removed, pyscf/pbc/df/fft.py:39-62:
+        vne^k = ao_k^H (vneR ao_k),  vneR = ifft(coulG * sum_a (-Z_a) exp(-i G.R_a)).real.
+        The potential is assembled on the host (O(G natm)); the contraction runs on the device with the
+        J kernels (isdf_vj_from_vR / isdf_vj_k).  Returns (nao,nao) for a single k-point (or Gamma),
+        else (nk,nao,nao), like the reference."""
+        from . import pbc_tools
+        cell, be = self.cell, self.backend
+        if kpts is None:
+            kpts_lst, single = np.zeros((1, 3)), True
+        else:
+            kpts_lst = np.reshape(kpts, (-1, 3))
+            single = np.ndim(kpts) == 1
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        nao = cell.nao_nr()
+        Gv = cell.get_Gv(mesh)
+        charge = -np.asarray(cell.atom_charges(), dtype=float)
+        SI = np.exp(-1j * np.dot(cell.atom_coords(), Gv.T))
+        rhoG = charge.dot(SI)
+        vneG = rhoG * pbc_tools.get_coulG(cell, np.zeros(3), mesh)
+        vneR = np.fft.ifftn(vneG.reshape(*mesh)).real.ravel()
+        d_v = be.to_device(vneR.reshape(1, G))
+        rcut = gto.estimate_rcut_per_shell(cell)
+        Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+        ao_args = (np.asarray(cell._atm), np.asarray(cell._bas), np.asarray(cell._env), Ls, rcut)
+        coords_soa = be.to_device(np.ascontiguousarray(self.grids.coords.T))
+        out = []
+        ur = be.empty((nao, G))
+        ui = be.empty((nao, G))
+        for k in kpts_lst:
+            if abs(k).sum() < 1e-9:
+                be.eval_ao(*ao_args, coords_soa, ur)
+                v = be.empty((1, nao, nao))
+                be.vj_from_vR(ur, G, d_v, v)
+                out.append(be.to_host(v)[0])
+            else:
+                be.eval_ao_k(*ao_args, k, True, coords_soa, ur, ui)
+                vre, vim = be.empty((nao, nao)), be.empty((nao, nao))
+                be.vj_k(ur, ui, G, d_v, vre, vim)
+                out.append(be.to_host(vre) + 1j * be.to_host(vim))
+        return out[0] if single else np.asarray(out)
 
 
 def _aoslice_by_atom(cell):

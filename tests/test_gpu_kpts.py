@@ -136,3 +136,23 @@ def test_select_complex_mode_panel_from_global_memory(be):
     rank = be.select_ip_cplx(be.to_device(X), nh, [0, m], [k], -1.0, 1e-10, L, piv)
     assert rank[0] == k and np.array_equal(be.to_host(piv)[0], piv_ref)
     assert abs(be.to_host(L) - L_ref).max() < 1e-9 * abs(L_ref).max()
+
+
+def test_get_nuc_reference_pins():
+    """ISDF.get_nuc against the reference's known answers for four random k-points
+    (pyscf/pbc/df/test/test_fft.py:555-557,589-599): pins the k-point collocation kernel and the
+    phi^H v phi contraction directly to reference constants."""
+    from pyscf_isdf_amd.isdf import ISDF
+    from oracle import pbc_tools as otools
+    cell = cells.cell_he_c()
+    np.random.seed(1)
+    kpts = np.random.random((4, 3))
+    kpts[3] = kpts[0] - kpts[1] + kpts[2]
+    v1 = ISDF(cell).get_nuc(kpts)
+    assert v1.shape == (4, 6, 6) and v1.dtype == np.complex128
+    assert abs(otools.fp(v1[0]) - (-5.7646608099493841 + 0.19126294430138713j)) < 1e-8
+    assert abs(otools.fp(v1[1]) - (-5.6567258309199193 + 0.86813371243952175j)) < 1e-8
+    assert abs(otools.fp(v1[2]) - (-6.1528952645454895 + 0.09517054428060109j)) < 1e-8
+    assert abs(otools.fp(v1[3]) - (-5.7445962879770942 + 0.24611951427601772j)) < 1e-8
+    v0 = ISDF(cell).get_nuc()
+    assert v0.shape == (6, 6) and v0.dtype == np.float64 and abs(v0 - v0.T).max() < 1e-12
