@@ -425,3 +425,25 @@ def test_exact_exchange_on_gpu_matches_reference_pin():
     ref = fftdf.get_k(aoT.T, dm, cell.lattice_vectors(), cell.mesh, mo_coeff=c, mo_occ=occ)
     assert abs(df.get_k_exact(mo_coeff=c, mo_occ=occ, max_rows=3) - ref).max() < 1e-10
     assert abs(df.get_k_exact(dm) - ref).max() < 1e-10
+
+
+def test_headline_config_regression_diamond444():
+    """BASELINE configs[2] at full size (N=1664, G=1728000, P=16640; ~256 GiB of HBM, ~25 s): size-independent
+    properties plus a regression pin of the energies recorded in profiles/r01_bench_cfg3.json (the exact-
+    exchange comparison at this size is in profiles/r01_accuracy_isdf_vs_exact_k.log)."""
+    import torch
+    from pyscf_isdf_amd import workloads
+    from pyscf_isdf_amd.isdf import ISDF
+    if torch.cuda.get_device_properties(0).total_memory < 270 * 2 ** 30:
+        pytest.skip('needs a 288 GB device')
+    cell = workloads.make_cell('diamond-444-dzvp-120')
+    dm, c, occ = workloads.make_dm(cell)
+    df = ISDF(cell, c_isdf=10, select='local')
+    vj, vk = df.get_jk(dm)
+    assert len(df.ip) == 16640 and len(np.unique(df.ip)) == 16640
+    assert abs(vj - vj.T).max() < 1e-8 and abs(vk - vk.T).max() < 1e-7
+    ej, ek = np.einsum('ij,ji', vj, dm) / 2, np.einsum('ij,ji', vk, dm) / 4
+    assert abs(ej - 12.140270972643) < 1e-7
+    assert abs(ek - 123.180049312) < 1e-6
+    assert abs(ek - 123.18058922) < 1e-3           # exact exchange (GPU, 426k FFT pairs): c=10 fitting error 5.4e-4 Eh
+    df.reset()
