@@ -246,6 +246,22 @@ int isdf_rho_k(isdf_handle h, const double* d_ur, const double* d_ui, int nao, i
 int isdf_vj_k(isdf_handle h, const double* d_ur, const double* d_ui, int nao, int64_t ng, int64_t ld,
               const double* d_vR, double* d_vj_re, double* d_vj_im);
 
+/* ---- GTH pseudopotential pieces of FFTDF.get_pp (pyscf/pbc/df/fft.py:64-152) -----------
+ * isdf_pp_local_potential:  d_vlocR (G) = ifft( -sum_a exp(-i G.R_a) vloc_a(G) ).real with the GTH local
+ *     form of pyscf/pbc/gto/pseudo/pp.py:58-93 + pp_int.py:51-71; atoms without a pseudopotential enter as
+ *     bare nuclei.  coords (natm,3) Bohr; pp_par (natm,8) = [has_pp, Z, rloc, nexp, C1, C2, C3, C4] (host).
+ *     The matrix elements follow with isdf_vj_from_vR / isdf_vj_k.
+ * isdf_pp_projector_overlaps:  d_out (nrows, nao) complex = sum_G conj(SI_a(G)) p_j(G+k) aoG_mu(G+k), the
+ *     non-local projector/AO overlaps of fft.py:88-131 with the analytic AO Fourier transform; proj_tab
+ *     (nproj,3) = [atom, l, i], proj_rl (nproj) = r_l; rows are (projector j, m = -l..l) in order.
+ *     The caller finishes with vnl = 1/vol sum conj(SPG_i) h_ij SPG_j (fft.py:132-140). */
+int isdf_pp_local_potential(isdf_handle h, int natm, const double* coords, const double* pp_par,
+                            const int32_t mesh[3], const double a[9], double* d_vlocR);
+int isdf_pp_projector_overlaps(isdf_handle h, const int32_t* atm, int natm, const int32_t* bas, int nbas,
+                               const double* env, int nenv, const double* coords, const double kpt[3],
+                               const int32_t* proj_tab, const double* proj_rl, int nproj,
+                               const int32_t mesh[3], const double a[9], double* d_out);
+
 /* Dense helper behind S5/S6 (exposed for tests and micro-benchmarks):
  *   C (M, ldc) = alpha * A (M, lda) * (B (N, ldb) .* kscale[None, :])^T + beta * C,
  * K contiguous in both operands (the W = V Theta^T / vj = ao (v.ao)^T shape); d_kscale may be NULL.

@@ -289,3 +289,29 @@ class HipBackend:
         self._stream()
         self.handle.call('isdf_vj_k', self._p(ur), self._p(ui), ur.shape[0], int(ng), ur.stride(0), self._p(vR),
                          self._p(vj_re), self._p(vj_im))
+
+    # ---- GTH pseudopotential pieces -----------------------------------------------------------------
+    def pp_local_potential(self, coords, pp_par, mesh, a, vlocR):
+        self._stream()
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        pp_par = np.ascontiguousarray(pp_par, dtype=np.float64)
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self.handle.call('isdf_pp_local_potential', len(coords), _np_ptr(coords), _np_ptr(pp_par), _np_ptr(mesh), _np_ptr(a),
+                         self._p(vlocR))
+
+    def pp_projector_overlaps(self, atm, bas, env, coords, kpt, proj_tab, proj_rl, mesh, a, out):
+        self._stream()
+        atm = np.ascontiguousarray(atm, dtype=np.int32)
+        bas = np.ascontiguousarray(bas, dtype=np.int32)
+        env = np.ascontiguousarray(env, dtype=np.float64)
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        kpt = np.ascontiguousarray(kpt, dtype=np.float64)
+        proj_tab = np.ascontiguousarray(proj_tab, dtype=np.int32)
+        proj_rl = np.ascontiguousarray(proj_rl, dtype=np.float64)
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert out.dtype == torch.complex128 and out.is_contiguous()
+        self.handle.call('isdf_pp_projector_overlaps', _np_ptr(atm), len(atm), _np_ptr(bas), len(bas), _np_ptr(env), len(env),
+                         _np_ptr(coords), _np_ptr(kpt), _np_ptr(proj_tab), _np_ptr(proj_rl), len(proj_rl), _np_ptr(mesh),
+                         _np_ptr(a), self._p(out))

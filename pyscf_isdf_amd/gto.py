@@ -97,6 +97,42 @@ def load_basis(name, symb):
         return parse_cp2k_basis(f.read(), symb, _BASIS_ALIAS[key])
 
 
+def load_pseudo(name, symb):
+    """GTH pseudopotential parameters of one element in PySCF's internal layout
+    ``[nelec_per_l, rloc, nexp, cexp, nproj_types, [r_l, n_l, h_l], ...]`` (pyscf/pbc/gto/pseudo/parse_cp2k.py)."""
+    key = re.sub(r'[-_ ]', '', name).lower()
+    if key not in ('gthpade', 'gthlda'):
+        raise KeyError('pseudopotential %r is not bundled (bundled: gth-pade)' % name)
+    with open(os.path.join(_BASIS_DIR, 'gth_pade_pp.dat')) as f:
+        lines = [ln.split('#')[0].strip() for ln in f.read().splitlines()]
+    lines = [ln for ln in lines if ln]
+    for i, ln in enumerate(lines):
+        tok = ln.split()
+        if tok[0] == symb and any(t.upper().startswith('GTH-PADE') for t in tok[1:]):
+            it = iter(lines[i + 1:])
+            break
+    else:
+        raise KeyError('no bundled GTH-PADE pseudopotential for %s' % symb)
+    nelec = [int(x) for x in next(it).split()]
+    row = next(it).split()
+    rloc, nexp = float(row[0]), int(row[1])
+    cexp = [float(x) for x in row[2:2 + nexp]]
+    nproj_types = int(next(it))
+    out = [nelec, rloc, nexp, cexp, nproj_types]
+    for _ in range(nproj_types):
+        row = next(it).split()
+        rl, nl = float(row[0]), int(row[1])
+        vals = [float(x) for x in row[2:]]
+        while len(vals) < nl * (nl + 1) // 2:
+            vals += [float(x) for x in next(it).split()]
+        h = np.zeros((nl, nl))
+        if nl:
+            h[np.triu_indices(nl)] = vals
+            h = h + h.T - np.diag(h.diagonal())
+        out.append([rl, nl, h.tolist()])
+    return out
+
+
 def gaussian_int(n, alpha):
     """int_0^inf x^n exp(-alpha x^2) dx (mole.py:116-119)."""
     n1 = (n + 1) * .5
@@ -176,6 +212,17 @@ class Cell:
                 b = sorted(b, key=lambda x: x[0])
             self._basis[s] = b
 
+        self._pseudo = {}
+        for s in symbols:
+            std = _std_symbol(s)
+            if self._has_pseudo(std):
+                p = self.pseudo
+                pname = p.get(s, p.get(std)) if isinstance(p, dict) else p
+                try:
+                    self._pseudo[s] = load_pseudo(pname, std)
+                except KeyError:
+                    pass        # charge table still applies; get_pp will complain if the parameters are needed
+
         # libcint tables (mole.py:1025-1100)
         env = [np.zeros(PTR_ENV_START)]
         ptr = PTR_ENV_START
@@ -184,7 +231,7 @@ class Cell:
             std = _std_symbol(s)
             z = _Z.get(std, 0)
             if self._has_pseudo(std):
-                z = GTH_PADE_Q[std]
+                z = sum(self._pseudo[s][0]) if s in self._pseudo else GTH_PADE_Q[std]
             atm.append([z, ptr, 1, ptr + 3, 0, 0])
             env.append(np.append(c, 0.))
             ptr += 4

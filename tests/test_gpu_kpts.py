@@ -156,3 +156,31 @@ def test_get_nuc_reference_pins():
     assert abs(otools.fp(v1[3]) - (-5.7445962879770942 + 0.24611951427601772j)) < 1e-8
     v0 = ISDF(cell).get_nuc()
     assert v0.shape == (6, 6) and v0.dtype == np.float64 and abs(v0 - v0.T).max() < 1e-12
+
+
+def test_get_pp_reference_pins():
+    """ISDF.get_pp (GTH local + non-local on the device) against the reference's known answers for four
+    random k-points (pyscf/pbc/df/test/test_fft.py:601-611) and the oracle at Gamma."""
+    from pyscf_isdf_amd.isdf import ISDF
+    from oracle import pbc_tools as otools, pp as opp
+    cell = cells.cell_he_c()
+    np.random.seed(1)
+    kpts = np.random.random((4, 3))
+    kpts[3] = kpts[0] - kpts[1] + kpts[2]
+    v1 = ISDF(cell).get_pp(kpts)
+    assert v1.shape == (4, 6, 6)
+    assert abs(otools.fp(v1[0]) - (-5.6240249083785869 + 0.22094834302524968j)) < 1e-8
+    assert abs(otools.fp(v1[1]) - (-5.5387702576467603 + 1.0439333717227581j)) < 1e-8
+    assert abs(otools.fp(v1[2]) - (-6.0530899866313366 + 0.2817289667029651j)) < 1e-8
+    assert abs(otools.fp(v1[3]) - (-5.6011543542444446 + 0.27597306418805201j)) < 1e-8
+    # Gamma point, d shells, two pseudo-atoms: vs the oracle
+    cell = cells.cell_diamond_prim('gth-dzvp', (12, 12, 12))
+    v0 = ISDF(cell).get_pp()
+    coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    ao = oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, rule='point')
+    ps = [cell._pseudo.get(cell.atom_symbol(i)) for i in range(cell.natm)]
+    ref = opp.get_pp(cell._atm, cell._bas, cell._env, cell.atom_coords(), cell.atom_charges(), ps, cell.lattice_vectors(),
+                     cell.mesh, coords, [ao], np.zeros((1, 3)))[0]
+    assert v0.dtype == np.float64 and abs(v0 - ref).max() < 1e-10

@@ -88,3 +88,21 @@ def test_fft_roundtrip_and_numpy_convention():
     ref = np.fft.fftn(f.reshape(3, *mesh), axes=(1, 2, 3)).reshape(3, -1)
     assert abs(g - ref).max() < 1e-12
     assert abs(tools.ifft(g, mesh) - f).max() < 1e-13
+
+
+def test_get_pp_pins():
+    # pyscf/pbc/df/test/test_fft.py:555-557,601-611: GTH pseudopotential matrices at 4 random k-points
+    from oracle import pp as opp
+    cell = cells.cell_he_c()
+    np.random.seed(1)
+    kpts = np.random.random((4, 3))
+    kpts[3] = kpts[0] - kpts[1] + kpts[2]
+    ao_k, coords = _aoR(cell, kpts=kpts)
+    pseudo_of_atom = [cell._pseudo.get(cell.atom_symbol(i)) for i in range(cell.natm)]
+    assert pseudo_of_atom[0] is None and pseudo_of_atom[1][1] == 0.34883045
+    v = opp.get_pp(cell._atm, cell._bas, cell._env, cell.atom_coords(), cell.atom_charges(), pseudo_of_atom,
+                   cell.lattice_vectors(), cell.mesh, coords, ao_k, kpts)
+    assert abs(tools.fp(v[0]) - (-5.6240249083785869 + 0.22094834302524968j)) < 1e-8
+    assert abs(tools.fp(v[1]) - (-5.5387702576467603 + 1.0439333717227581j)) < 1e-8
+    assert abs(tools.fp(v[2]) - (-6.0530899866313366 + 0.2817289667029651j)) < 1e-8
+    assert abs(tools.fp(v[3]) - (-5.6011543542444446 + 0.27597306418805201j)) < 1e-8
