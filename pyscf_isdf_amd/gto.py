@@ -20,7 +20,6 @@ Reference conventions followed (nothing is imported from it):
 """
 import os
 import re
-import itertools
 import numpy as np
 from scipy.special import gamma as _gamma
 
