@@ -1,0 +1,78 @@
+"""Test-side helpers for an SCF-level known-answer test (TEST INFRASTRUCTURE): analytic periodic overlap and
+kinetic matrices for s-type Gaussians (the reference takes them from libcint lattice sums,
+pyscf/pbc/scf/hf.py:76-95), the Ewald nuclear repulsion (pyscf/pbc/gto/cell.py:692-768) and a plain
+Roothaan RHF loop (pyscf/scf/hf.py:46-215 reduced to its essentials)."""
+import numpy as np
+import scipy.linalg
+from scipy.special import erfc
+from pyscf_isdf_amd import gto
+
+FAC_S = 0.282094791773878143
+
+
+def s_type_overlap_kinetic(cell, nimg=6):
+    """Gamma-point S and T for a cell whose shells are all single-primitive s functions."""
+    a = cell.lattice_vectors()
+    Ts = gto.cartesian_prod([np.arange(-nimg, nimg + 1)] * 3).dot(a)
+    nao = cell.nao_nr()
+    assert cell.nbas == nao
+    ex = np.array([cell.bas_exp(i)[0] for i in range(nao)])
+    cf = np.array([cell._libcint_ctr_coeff(i)[0, 0] for i in range(nao)]) * FAC_S
+    R = np.array([cell.atom_coords()[cell.bas_atom(i)] for i in range(nao)])
+    S = np.zeros((nao, nao))
+    T = np.zeros((nao, nao))
+    for i in range(nao):
+        for j in range(nao):
+            p = ex[i] + ex[j]
+            xi = ex[i] * ex[j] / p
+            d2 = ((R[i] - R[j])[None, :] + Ts) ** 2
+            r2 = d2.sum(axis=1)
+            s = cf[i] * cf[j] * (np.pi / p) ** 1.5 * np.exp(-xi * r2)
+            S[i, j] = s.sum()
+            T[i, j] = (xi * (3 - 2 * xi * r2) * s).sum()
+    return S, T
+
+
+def ewald_energy(cell):
+    """Nuclear repulsion of the periodic point charges with neutralising background (Martin, App. F2)."""
+    a = cell.lattice_vectors()
+    vol = cell.vol
+    b = 2 * np.pi * np.linalg.inv(a.T)
+    Z = np.asarray(cell.atom_charges(), dtype=float)
+    R = cell.atom_coords()
+    eta = np.sqrt(np.pi) / vol ** (1. / 3)
+    rmax, gmax = 7.0 / eta, 14.0 * eta
+    nr = np.ceil(rmax * np.linalg.norm(b, axis=1) / (2 * np.pi)).astype(int) + 1
+    Ts = gto.cartesian_prod([np.arange(-n, n + 1) for n in nr]).dot(a)
+    e = 0.0
+    for i in range(len(Z)):
+        for j in range(len(Z)):
+            r = np.linalg.norm(R[i] - R[j] + Ts, axis=1)
+            r = r[r > 1e-12]
+            e += .5 * Z[i] * Z[j] * (erfc(eta * r) / r).sum()
+    e += -.5 * (Z ** 2).sum() * 2 * eta / np.sqrt(np.pi) - .5 * Z.sum() ** 2 * np.pi / (eta ** 2 * vol)
+    ng = np.ceil(gmax * np.linalg.norm(a, axis=1) / (2 * np.pi)).astype(int) + 1
+    Gs = gto.cartesian_prod([np.arange(-n, n + 1) for n in ng]).dot(b)
+    g2 = np.einsum('gi,gi->g', Gs, Gs)
+    keep = g2 > 1e-12
+    Gs, g2 = Gs[keep], g2[keep]
+    ZS = (Z[:, None] * np.exp(1j * R.dot(Gs.T))).sum(axis=0)
+    e += .5 * (4 * np.pi / vol) * (abs(ZS) ** 2 * np.exp(-g2 / (4 * eta * eta)) / g2).sum()
+    return e
+
+
+def rhf(hcore, S, get_jk, nocc, e_nuc, max_cycle=50, conv=1e-10):
+    """Closed-shell Roothaan iterations with DIIS-free damping (tiny systems); returns (e_tot, dm)."""
+    e, c = scipy.linalg.eigh(hcore, S)
+    dm = 2 * c[:, :nocc].dot(c[:, :nocc].T)
+    e_last = 0.0
+    for it in range(max_cycle):
+        vj, vk = get_jk(dm)
+        f = hcore + vj - .5 * vk
+        e_tot = .5 * np.einsum('ij,ji', hcore + f, dm) + e_nuc
+        if abs(e_tot - e_last) < conv:
+            break
+        e_last = e_tot
+        e, c = scipy.linalg.eigh(f, S)
+        dm = 2 * c[:, :nocc].dot(c[:, :nocc].T)
+    return e_tot, dm

@@ -1,0 +1,34 @@
+"""SCF-level known answers (pyscf/pbc/scf/test/test_hf.py:30-46,94-132): a Gamma-point RHF
+whose J/K come from ``mf.with_df = ISDF(cell)`` and whose nuclear attraction comes from ``ISDF.get_nuc`` must
+reproduce the reference's total energies for exxdiv=None and exxdiv='ewald'."""
+import numpy as np
+import pytest
+from pyscf_isdf_amd import gto
+import scf_helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _he2_cell():
+    L = 4.0
+    return gto.Cell(unit='B', a=np.eye(3) * L, mesh=[21] * 3,
+                    atom=[['He', (L / 2. - .5, L / 2., L / 2. - .5)], ['He', (L / 2., L / 2., L / 2. + .5)]],
+                    basis={'He': [[0, (0.8, 1.0)], [0, (1.0, 1.0)], [0, (1.2, 1.0)]]})
+
+
+def test_rhf_total_energy_matches_reference():
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = _he2_cell()
+    assert cell.nao_nr() == 6 and cell.nelectron == 4
+    S, T = scf_helpers.s_type_overlap_kinetic(cell)
+    df = ISDF(cell, c_isdf=4, select='global')          # 21 points = all pair products: ISDF is exact here
+    hcore = T + df.get_nuc()
+    # pyscf/pbc/scf/test/test_hf.py:55-58: fp(hcore) = 0.14116483012673137
+    from oracle import pbc_tools as otools
+    assert abs(otools.fp(hcore) - 0.14116483012673137) < 1e-7
+    e_nuc = scf_helpers.ewald_energy(cell)
+    e_none, dm = scf_helpers.rhf(hcore, S, lambda d: df.get_jk(d, exxdiv=None), 2, e_nuc)
+    assert len(df.ip) == 21
+    assert abs(e_none - (-2.9325094887283196)) < 2e-7          # test_hf.py:128-131 (places=7)
+    e_ewald, dm = scf_helpers.rhf(hcore, S, lambda d: df.get_jk(d, exxdiv='ewald'), 2, e_nuc)
+    assert abs(e_ewald - (-4.3511582284698633)) < 2e-7         # test_hf.py:94-95 (places=7)
