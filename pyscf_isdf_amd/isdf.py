@@ -735,6 +735,26 @@ class ISDF:
 
     get_eri = get_ao_eri
 
+    def ao2mo(self, mo_coeffs, kpts=None, compact=False):
+        """(ij|kl) in the MO basis from the factorisation (FFTDF.ao2mo surface, pyscf/pbc/df/fft.py:319):
+        sum_PQ X_ij,P W_PQ X_kl,Q with X_ij,P = (aoP C_i)_P (aoP C_j)_P.  Gamma point, s1 layout."""
+        if not self._is_gamma(kpts) or not self._is_gamma(self.kpts):
+            raise NotImplementedError
+        if compact:
+            raise NotImplementedError('compact MO integrals are not implemented; use compact=False')
+        if not self._built:
+            self.build()
+        if isinstance(mo_coeffs, np.ndarray) and mo_coeffs.ndim == 2:
+            mo_coeffs = (mo_coeffs,) * 4
+        aoP = self.backend.to_host(self.aoP)
+        W = self.backend.to_host(self.W)
+        ci, cj, ck, cl = [aoP.dot(np.asarray(c)) for c in mo_coeffs]
+        Xij = np.einsum('pi,pj->pij', ci, cj).reshape(len(aoP), -1)
+        Xkl = np.einsum('pk,pl->pkl', ck, cl).reshape(len(aoP), -1)
+        return Xij.T.dot(W).dot(Xkl)
+
+    get_mo_eri = ao2mo
+
     def get_pp(self, kpts=None):
         """GTH pseudopotential AO matrix (G=0 removed), pyscf/pbc/df/fft.py:64-152: local part on the FFT
         grid, non-local part from projector/AO overlaps in reciprocal space — both on the device

@@ -447,3 +447,19 @@ def test_headline_config_regression_diamond444():
     assert abs(ek - 123.180049312) < 1e-6
     assert abs(ek - 123.18058922) < 1e-3           # exact exchange (GPU, 426k FFT pairs): c=10 fitting error 5.4e-4 Eh
     df.reset()
+
+
+def test_ao_eri_and_ao2mo_from_the_factorisation():
+    """get_ao_eri at full rank reproduces the reference's fp(eri) (test_fft.py:692-695); ao2mo is the same
+    tensor transformed."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    nao = cell.nao_nr()
+    df = ISDF(cell, c_isdf=4, select='global')
+    eri = df.get_ao_eri(compact=True)
+    assert eri.shape == (21, 21) and abs(tools.fp(eri) - 0.80425358275734926) < 1e-7
+    rng = np.random.default_rng(0)
+    c = rng.standard_normal((nao, 3))
+    full = df.get_ao_eri(compact=False).reshape(nao, nao, nao, nao)
+    ref = np.einsum('pqrs,pi,qj,rk,sl->ijkl', full, c, c, c, c).reshape(9, 9)
+    assert abs(df.ao2mo(c) - ref).max() < 1e-10
