@@ -654,8 +654,8 @@ class ISDF:
         if kpts_band is not None:
             raise NotImplementedError('kpts_band for the k-point ISDF path is not implemented in this round')
         ex = exxdiv if exxdiv is not None else self.exxdiv
-        if ex not in (None, 'None'):
-            raise NotImplementedError("k-point ISDF: only exxdiv=None is implemented")
+        if ex not in (None, 'None', 'ewald'):
+            raise NotImplementedError("k-point ISDF: only exxdiv=None and 'ewald' are implemented")
         cell, be, comm = self.cell, self.backend, self.comm
         kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
         if not self._built or getattr(self, '_k_built', None) is None or kpts.shape != self._k_built.shape \
@@ -712,8 +712,20 @@ class ISDF:
             if comm.size > 1:
                 flat = torch.view_as_real(d_vk)
                 comm.all_reduce_sum(flat)
+            vk = be.to_host(d_vk)
+            if ex == 'ewald':
+                # vk[k] += madelung * S^k D^k S^k (pyscf/pbc/df/df_jk.py:1446-1465); S^k by quadrature on the
+                # grid from the periodic parts (the Bloch phases cancel)
+                mad = gto.madelung(cell, _monkhorst_pack_size(cell, kpts))
+                w_const = be.to_device(np.full((1, G), cell.vol / G))
+                for k in range(nk):
+                    sre, sim = be.empty((nao, nao)), be.empty((nao, nao))
+                    be.vj_k(X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao], G, w_const, sre, sim)
+                    Sk = be.to_host(sre) + 1j * be.to_host(sim)
+                    for s in range(nset):
+                        vk[s, k] += mad * Sk.dot(dms[s, k]).dot(Sk)
             t0 = self._tick('S7_get_k', t0)
-            vk = be.to_host(d_vk).reshape(dm_in.shape)
+            vk = vk.reshape(dm_in.shape)
         return vj, vk
 
     # ---- ERIs from the factorisation (small systems; reached from SCF.get_jk's incore branch,
@@ -870,6 +882,12 @@ class ISDF:
                 be.vj_k(ur, ui, G, d_v, vre, vim)
                 out.append(be.to_host(vre) + 1j * be.to_host(vim))
         return out[0] if single else np.asarray(out)
+
+
+def _monkhorst_pack_size(cell, kpts, tol=1e-5):
+    """Number of distinct k-point fractions per reciprocal axis (pyscf/pbc/tools/pbc.py:get_monkhorst_pack_size)."""
+    skpts = np.linalg.solve(cell.reciprocal_vectors().T, np.reshape(kpts, (-1, 3)).T).T.round(decimals=6)
+    return tuple(len(np.unique(np.round(skpts[:, i] / tol).astype(int))) for i in range(3))
 
 
 def _aoslice_by_atom(cell):

@@ -32,3 +32,21 @@ def test_rhf_total_energy_matches_reference():
     assert abs(e_none - (-2.9325094887283196)) < 2e-7          # test_hf.py:128-131 (places=7)
     e_ewald, dm = scf_helpers.rhf(hcore, S, lambda d: df.get_jk(d, exxdiv='ewald'), 2, e_nuc)
     assert abs(e_ewald - (-4.3511582284698633)) < 2e-7         # test_hf.py:94-95 (places=7)
+
+
+def test_rhf_single_kpoint_total_energy_matches_reference():
+    """Complex single-k RHF (pyscf/pbc/scf/test/test_hf.py:109-115): exxdiv='ewald', k = random(3) after seed(1):
+    e_tot = -4.2048655827967139.  Runs the k-point ISDF path (periodic parts, complex W^q with q = 0, zgemm K)."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = _he2_cell()
+    np.random.seed(1)
+    k = np.random.random(3)
+    S, T = scf_helpers.s_type_overlap_kinetic(cell, kpt=k)
+    df = ISDF(cell, kpts=k.reshape(1, 3), c_isdf=8, select='global')
+    df.k_ip_factor = 1
+    hcore = T + df.get_nuc(k)
+    assert abs(hcore - hcore.conj().T).max() < 1e-9 and abs(S - S.conj().T).max() < 1e-12
+    e_nuc = scf_helpers.ewald_energy(cell)
+    e_tot, dm = scf_helpers.rhf(hcore, S, lambda d: df.get_jk(d, kpts=k, exxdiv='ewald'), 2, e_nuc)
+    assert dm.dtype == np.complex128
+    assert abs(e_tot - (-4.2048655827967139)) < 2e-7
