@@ -70,6 +70,7 @@ class ISDF:
         self.c_isdf = c_isdf
         self.select = select              # 'local': per-atom Voronoi blocks + global fit; 'global': one block
         self.tie_rtol = 1e-10
+        self.select_tol = -1.0           # stop when the largest residual diagonal <= tol; < 0: m*eps*max diag (scipy_helper.py:88-90)
         self.reg_rel = 1e-12             # relative diagonal shift of A_PP in the global fit
         self.reg_used = 0.0
         self.k_ip_factor = None           # k-points: points = c_isdf * nao * k_ip_factor (default min(nk, 2))
@@ -209,7 +210,7 @@ class ISDF:
             P = int(min(self.c_isdf * nao, G))
             theta = self._buffer('theta', (P, G))
             piv = be.empty((1, P), dtype=torch.int64)
-            rank = be.select_ip(self.ao, [0, G], [P], -1.0, self.tie_rtol, theta, piv)
+            rank = be.select_ip(self.ao, [0, G], [P], self.select_tol, self.tie_rtol, theta, piv)
             P = int(rank[0])
             t0 = self._tick('S2_select_ip', t0)
             theta = theta[:P]
@@ -245,7 +246,7 @@ class ISDF:
             L = scratch[nao:nao + kmax]
             be.gather_cols(self.ao, d_perm, ao_sel)
             piv = be.empty((cell.natm, kmax), dtype=torch.int64)
-            rank = be.select_ip(ao_sel, blk_off, nip, -1.0, self.tie_rtol, L, piv)
+            rank = be.select_ip(ao_sel, blk_off, nip, self.select_tol, self.tie_rtol, L, piv)
             del ao_sel, L, scratch
             piv_h = be.to_host(piv)
             ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(cell.natm)])
@@ -433,7 +434,7 @@ class ISDF:
             kmax = int(max(nip[b] for b in mine))
             L = be.empty((kmax, len(idx)))
             piv = be.empty((len(mine), kmax), dtype=torch.int64)
-            rank = be.select_ip(ao_sel, loc_off, [nip[b] for b in mine], -1.0, self.tie_rtol, L, piv)
+            rank = be.select_ip(ao_sel, loc_off, [nip[b] for b in mine], self.select_tol, self.tie_rtol, L, piv)
             piv_h = be.to_host(piv)
             for k, b in enumerate(mine):
                 my_ips[b] = idx[loc_off[k] + piv_h[k, :rank[k]]]
@@ -574,7 +575,7 @@ class ISDF:
         if self.select == 'global':
             theta = self._buffer('theta', (P_target, G))
             piv = be.empty((1, P_target), dtype=torch.int64)
-            rank = be.select_ip_cplx(X, nh, [0, G], [P_target], -1.0, self.tie_rtol, theta, piv)
+            rank = be.select_ip_cplx(X, nh, [0, G], [P_target], self.select_tol, self.tie_rtol, theta, piv)
             ip_dev = piv[0, :int(rank[0])].contiguous()
             self.ip = be.to_host(ip_dev).astype(np.int64)
         else:
@@ -588,7 +589,7 @@ class ISDF:
             be.gather_cols(X, be.to_device(perm), Xs)
             L = be.empty((kmax, G))
             piv = be.empty((cell.natm, kmax), dtype=torch.int64)
-            rank = be.select_ip_cplx(Xs, nh, blk_off, nip, -1.0, self.tie_rtol, L, piv)
+            rank = be.select_ip_cplx(Xs, nh, blk_off, nip, self.select_tol, self.tie_rtol, L, piv)
             del Xs, L
             piv_h = be.to_host(piv)
             self.ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(cell.natm)]).astype(np.int64)
@@ -601,7 +602,7 @@ class ISDF:
         aoP_X = self._buffer('aoP', (P, 2 * nh))
         chol = self._buffer('factor', (P, P))
         self.reg_used = be.fit_prepare_cplx(X, nh, ip_dev, self.reg_rel, aoP_X, chol)
-        be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=True)
+        be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=not self.explicit_theta)
         t0 = self._tick('S3_fit', t0)
 
         # Bloch AOs at the points: phi^k(r_P) = exp(i k.r_P) u^k(r_P), (P, nao) complex per k
@@ -639,8 +640,9 @@ class ISDF:
             coulG = be.to_device(pbc_tools.get_coulG(cell, q, mesh))
             be.coulomb_Wq(Y, mesh, coulG, w, 0, P, batch, Wre, Wim, upper_only=True)
             be.symmetrize_hermitian(Wre, Wim)
-            be.W_from_factor(chol, 0, Wre)
-            be.W_from_factor(chol, 0, Wim)
+            if not self.explicit_theta:
+                be.W_from_factor(chol, 0, Wre)
+                be.W_from_factor(chol, 0, Wim)
             Wc = be.empty((P, P), dtype=torch.complex128)
             be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * r_ip.dot(q))), Wc)
             self._Wq[iq] = Wc

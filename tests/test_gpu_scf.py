@@ -42,11 +42,15 @@ def test_rhf_single_kpoint_total_energy_matches_reference():
     np.random.seed(1)
     k = np.random.random(3)
     S, T = scf_helpers.s_type_overlap_kinetic(cell, kpt=k)
-    df = ISDF(cell, kpts=k.reshape(1, 3), c_isdf=8, select='global')
+    # 6 AOs -> 36 real-independent pair functions conj(u_i) u_j: take exactly 36 points, do not stop at the
+    # rank tolerance (the 36th direction carries 2e-12 of the Gram weight but 3e-4 Eh) and do not regularise
+    df = ISDF(cell, kpts=k.reshape(1, 3), c_isdf=6, select='global')
     df.k_ip_factor = 1
+    df.select_tol = 0.0
+    df.reg_rel = 0.0
     hcore = T + df.get_nuc(k)
     assert abs(hcore - hcore.conj().T).max() < 1e-9 and abs(S - S.conj().T).max() < 1e-12
     e_nuc = scf_helpers.ewald_energy(cell)
     e_tot, dm = scf_helpers.rhf(hcore, S, lambda d: df.get_jk(d, kpts=k, exxdiv='ewald'), 2, e_nuc)
-    assert dm.dtype == np.complex128
+    assert dm.dtype == np.complex128 and len(df.ip) == 36
     assert abs(e_tot - (-4.2048655827967139)) < 2e-7
