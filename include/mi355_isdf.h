@@ -153,6 +153,30 @@ int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, 
                     const int64_t* d_ip, int P, double reg_rel, double* d_theta, int64_t ldt,
                     double* d_aoP, double* reg_used);
 
+/* S3c. Block-Jacobi route — no triangular solve over the grid.  With A = A_PP, B = A_P and
+ * D = blockdiag(chol(A_bb)) over the per-atom blocks of points [blk_off[b], blk_off[b+1]):
+ *   Y' = D^-1 B,  M' = w conv(Y') Y'^T (isdf_coulomb_W),  A' = D^-1 A D^-T,
+ *   W  = D^-T [A'^-1 M' A'^-1] D^-1     ( = A^-1 [w conv(B) B^T] A^-1, the same W as S3a/S3b ).
+ * Building blocks (nh > 0 selects the complex k-point mode of the Gram products):
+ *   isdf_gather_aoP      d_aoP (P, nao) = ao[:, ip]^T
+ *   isdf_gram_sq         d_A (P, P) = (aoP aoP^T)^2
+ *   isdf_pair_gram_rows  d_B (P, ldb) = (aoP ao)^2 on ng grid columns
+ *   isdf_block_chol      d_D (P, P): zero except the diagonal blocks, which hold the row-major lower Cholesky
+ *                        factors D_b of A_bb + shift_rel*max(diag A)*I
+ *   isdf_block_solve     side 0: X (P, n) <- op(D)^-1 X;  side 1: X (n, P) <- X op(D)^-1;  op = D (trans 0) | D^T (trans 1)
+ *   isdf_chol_inplace    d_A <- Cholesky factor (same storage convention as isdf_fit_prepare's d_chol)
+ *   isdf_W_from_factor   kind 2: M <- U^-T M U^-1 ; followed by kind 0 gives A^-1 M A^-1. */
+int isdf_gather_aoP(isdf_handle h, const double* d_ao, int nao, int64_t ld, const int64_t* d_ip, int P,
+                    double* d_aoP);
+int isdf_gram_sq(isdf_handle h, const double* d_aoP, int P, int nao, int nh, double* d_A);
+int isdf_pair_gram_rows(isdf_handle h, const double* d_aoP, int P, int nao, int nh, const double* d_ao,
+                        int64_t ng, int64_t ld, double* d_B, int64_t ldb);
+int isdf_block_chol(isdf_handle h, const double* d_A, int P, int nblk, const int32_t* blk_off,
+                    double shift_rel, double* d_D);
+int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nblk, const int32_t* blk_off, int side,
+                     int trans, double* d_X, int64_t n, int64_t ldx);
+int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel);
+
 /* T (k, k) row-major upper triangular, T[t][s] = L[t][piv[s]] for s >= t: the triangular factor that
  * turns the selection's Cholesky rows into interpolation vectors (Theta = T^-1 L). */
 int isdf_gather_T(isdf_handle h, const double* d_L, int k, int64_t ldL, const int64_t* d_piv,
@@ -160,6 +184,7 @@ int isdf_gather_T(isdf_handle h, const double* d_L, int k, int64_t ldL, const in
 /* W = S^-1 M S^-T in place on d_M (P, ldm), where Theta = S^-1 Y and M = w conv(Y) Y^T:
  *   kind 0: d_F = Cholesky factor written by isdf_fit_prepare (S = Lr^T),  Y from isdf_fit_apply(forward_only)
  *   kind 1: d_F = T from isdf_gather_T (S = T),                           Y = L, the selection's rows.
+ *   kind 2: d_F as kind 0, M <- U^-T M U^-1 (first half of A^-1 M A^-1, see S3c).
  * Replaces the second O(P^2 G) triangular solve by two O(P^3) ones. */
 int isdf_W_from_factor(isdf_handle h, const double* d_F, int P, int kind, double* d_M, int64_t ldm);
 

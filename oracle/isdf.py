@@ -193,6 +193,28 @@ def build_local_select_global_fit(aoT, a, mesh, owner, nip_per_block, reg_rel=1e
     return dict(ip=ip, theta=theta, W=W, aoP=np.ascontiguousarray(aoT[:, ip].T))
 
 
+def build_W_blockjacobi(aoT, ip, blk_off, a, mesh, reg_rel=1e-12, block_shift=0.0):
+    """W without any triangular solve over the grid (include/mi355_isdf.h S3c):
+    D = blockdiag(chol(A_bb)), Y' = D^-1 B, M' = w conv(Y') Y'^T, A' = D^-1 A D^-T (+ reg),
+    W = D^-T [A'^-1 M' A'^-1] D^-1."""
+    aoP = aoT[:, ip]
+    A = aoP.T.dot(aoP) ** 2
+    B = aoP.T.dot(aoT) ** 2
+    P = len(ip)
+    D = np.zeros((P, P))
+    for b in range(len(blk_off) - 1):
+        s = slice(blk_off[b], blk_off[b + 1])
+        if s.stop > s.start:
+            D[s, s] = np.linalg.cholesky(A[s, s] + block_shift * A.diagonal().max() * np.eye(s.stop - s.start))
+    Yp = scipy.linalg.solve_triangular(D, B, lower=True)
+    Mp = build_W(Yp, a, mesh)
+    Ap = scipy.linalg.solve_triangular(D, scipy.linalg.solve_triangular(D, A, lower=True).T, lower=True).T
+    Ap = Ap + reg_rel * Ap.diagonal().max() * np.eye(P)
+    cf = scipy.linalg.cho_factor(Ap)
+    Wp = scipy.linalg.cho_solve(cf, scipy.linalg.cho_solve(cf, Mp).T).T
+    return scipy.linalg.solve_triangular(D, scipy.linalg.solve_triangular(D, Wp, lower=True, trans='T').T, lower=True, trans='T').T
+
+
 def theta_dense_from_blocks(blocks, G):
     P = sum(len(b['ip_local']) for b in blocks)
     th = np.zeros((P, G))

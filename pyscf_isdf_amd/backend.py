@@ -132,6 +132,38 @@ class HipBackend:
         self.handle.call('isdf_fit_apply', self._p(chol), self._p(aoP), aoP.shape[0], aoP.shape[1], self._p(ao),
                          int(ng), ao.stride(0), int(bool(forward_only)), self._p(theta), theta.stride(0))
 
+    # ---- block-Jacobi route (S3c) ----
+    def gather_aoP(self, ao, ip, aoP):
+        self._stream()
+        self.handle.call('isdf_gather_aoP', self._p(ao), ao.shape[0], ao.stride(0), self._p(ip), ip.numel(), self._p(aoP))
+
+    def gram_sq(self, aoP, A, nh=0):
+        self._stream()
+        self.handle.call('isdf_gram_sq', self._p(aoP), aoP.shape[0], aoP.shape[1], int(nh), self._p(A))
+
+    def pair_gram_rows(self, aoP, ao, ng, B, nh=0):
+        self._stream()
+        self.handle.call('isdf_pair_gram_rows', self._p(aoP), aoP.shape[0], aoP.shape[1], int(nh), self._p(ao), int(ng),
+                         ao.stride(0), self._p(B), B.stride(0))
+
+    def block_chol(self, A, blk_off, shift_rel, D):
+        self._stream()
+        blk_off = np.ascontiguousarray(blk_off, dtype=np.int32)
+        self.handle.call('isdf_block_chol', self._p(A), A.shape[0], len(blk_off) - 1, _np_ptr(blk_off), float(shift_rel),
+                         self._p(D))
+
+    def block_solve(self, D, blk_off, side, trans, X):
+        """side 0: X (P, n) <- op(D)^-1 X; side 1: X (n, P) <- X op(D)^-1."""
+        self._stream()
+        blk_off = np.ascontiguousarray(blk_off, dtype=np.int32)
+        n = X.shape[1] if side == 0 else X.shape[0]
+        self.handle.call('isdf_block_solve', self._p(D), D.shape[0], len(blk_off) - 1, _np_ptr(blk_off), int(side), int(trans),
+                         self._p(X), int(n), X.stride(0))
+
+    def chol_inplace(self, A, shift_rel):
+        self._stream()
+        self.handle.call('isdf_chol_inplace', self._p(A), A.shape[0], float(shift_rel))
+
     def gather_T(self, L, k, piv, T):
         self._stream()
         assert T.is_contiguous() and T.shape == (k, k)

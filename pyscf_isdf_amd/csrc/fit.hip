@@ -259,10 +259,16 @@ extern "C" int isdf_gather_T(isdf_handle h, const double* d_L, int k, int64_t ld
 extern "C" int isdf_W_from_factor(isdf_handle h, const double* d_F, int P, int kind, double* d_M,
                                   int64_t ldm) {
   if (!h) return ISDF_ERR_ARG;
-  ARG_CHECK(h, d_F && d_M && P > 0 && ldm >= P && (kind == 0 || kind == 1));
+  ARG_CHECK(h, d_F && d_M && P > 0 && ldm >= P && (kind == 0 || kind == 1 || kind == 2));
   const double one = 1.0;
   ProfScope ps(h, "rocblas_dtrsm[flop]", 2.0 * (double)P * P * P, 2);
-  if (kind == 0) {
+  if (kind == 2) {
+    // F as kind 0 (A = U^T U):  M <- U^-T M U^-1  (the other half of A^-1 M A^-1; follow with kind 0)
+    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose,
+                              rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
+    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
+                              rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
+  } else if (kind == 0) {
     // F = Cholesky factor of A_PP as stored by isdf_fit_prepare: column-major upper U, A = U^T U,
     // Theta = U^-1 Y  =>  W = U^-1 M U^-T
     BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none,
@@ -277,5 +283,179 @@ extern "C" int isdf_W_from_factor(isdf_handle h, const double* d_F, int P, int k
     BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none,
                               rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
   }
+  return ISDF_OK;
+}
+
+
+// ---- block-Jacobi route: no triangular solve over the grid at all ------------------------------------
+// With A = A_PP, B = A_P and D = blockdiag(chol(A_bb)) over the per-atom point blocks:
+//   Y' = D^-1 B (cheap, block by block),  M' = w conv(Y') Y'^T,  A' = D^-1 A D^-T,
+//   W  = A^-1 [w conv(B) B^T] A^-1 = D^-T [A'^-1 M' A'^-1] D^-1.
+// Same W as the Cholesky routes in exact arithmetic; the block scaling keeps the small components of
+// M' resolved and lowers the condition number that the two-sided inverse squares.
+
+extern "C" int isdf_gram_sq(isdf_handle h, const double* d_aoP, int P, int nao, int nh, double* d_A) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_aoP && d_A && P > 0 && nao > 0 && P <= 65535 && (nh == 0 || 2 * nh == nao));
+  int rc = gemm_rm(h, 'N', 'T', P, P, nao, 1.0, d_aoP, nao, d_aoP, nao, 0.0, d_A, P);
+  if (rc) return rc;
+  if (nh > 0) {
+    double* rot = (double*)isdf_ws(h, "fit_rot", sizeof(double) * (size_t)P * nao);
+    double* tmp = (double*)isdf_ws(h, "fit_tmp", sizeof(double) * (size_t)P * P);
+    if (!rot || !tmp) return ISDF_ERR_HIP;
+    hipLaunchKernelGGL(rotate_kernel, dim3((unsigned)cdiv(nao, 256), (unsigned)P), dim3(256), 0, h->stream, d_aoP, P, nh, rot);
+    rc = gemm_rm(h, 'N', 'T', P, P, nao, 1.0, rot, nao, d_aoP, nao, 0.0, tmp, P);
+    if (rc) return rc;
+    hipLaunchKernelGGL(square_add_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)P), dim3(256), 0, h->stream, d_A,
+                       (int64_t)P, tmp, (int64_t)P, (int64_t)P);
+  } else {
+    hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)P), dim3(256), 0, h->stream, d_A,
+                       (int64_t)P, (int64_t)P, (int64_t)P);
+  }
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_pair_gram_rows(isdf_handle h, const double* d_aoP, int P, int nao, int nh, const double* d_ao,
+                                   int64_t ng, int64_t ld, double* d_B, int64_t ldb) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_aoP && d_ao && d_B && P > 0 && P <= 65535 && nao > 0 && ng > 0 && ld >= ng && ldb >= ng);
+  ARG_CHECK(h, nh == 0 || 2 * nh == nao);
+  int rc = gemm_rm(h, 'N', 'N', P, ng, nao, 1.0, d_aoP, nao, d_ao, ld, 0.0, d_B, ldb);
+  if (rc) return rc;
+  if (nh > 0) {
+    const int64_t CH = 8192;
+    double* rot = (double*)isdf_ws(h, "fit_rot", sizeof(double) * (size_t)P * nao);
+    double* tmp = (double*)isdf_ws(h, "fit_tmpB", sizeof(double) * (size_t)P * CH);
+    if (!rot || !tmp) return ISDF_ERR_HIP;
+    hipLaunchKernelGGL(rotate_kernel, dim3((unsigned)cdiv(nao, 256), (unsigned)P), dim3(256), 0, h->stream, d_aoP, P, nh, rot);
+    for (int64_t c0 = 0; c0 < ng; c0 += CH) {
+      const int64_t nc = std::min(CH, ng - c0);
+      rc = gemm_rm(h, 'N', 'N', P, nc, nao, 1.0, rot, nao, d_ao + c0, ld, 0.0, tmp, CH);
+      if (rc) return rc;
+      hipLaunchKernelGGL(square_add_kernel, dim3((unsigned)cdiv(nc, 256), (unsigned)P), dim3(256), 0, h->stream,
+                         d_B + c0, ldb, tmp, CH, nc);
+    }
+  } else {
+    hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(ng, 256), (unsigned)P), dim3(256), 0, h->stream, d_B,
+                       (int64_t)P, ng, ldb);
+  }
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+namespace {
+__global__ void copy_block_kernel(const double* __restrict__ A, int P, int off, int nb, double* __restrict__ D) {
+  // D (P x P, zero elsewhere) diagonal block <- A diagonal block
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c >= nb) return;
+  D[(int64_t)(off + r) * P + off + c] = A[(int64_t)(off + r) * P + off + c];
+}
+__global__ void add_diag_const_kernel(double* __restrict__ A, int n, int64_t ld, double v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[(int64_t)i * ld + i] += v;
+}
+}  // namespace
+
+extern "C" int isdf_block_chol(isdf_handle h, const double* d_A, int P, int nblk, const int32_t* blk_off,
+                               double shift_rel, double* d_D) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_A && d_D && blk_off && P > 0 && nblk > 0 && blk_off[0] == 0 && blk_off[nblk] == P && shift_rel >= 0);
+  int* info = (int*)isdf_ws(h, "fit_info", 256);
+  if (!info) return ISDF_ERR_HIP;
+  double* maxdiag = (double*)(info + 16);
+  HIP_TRY(h, hipMemsetAsync(d_D, 0, sizeof(double) * (size_t)P * P, h->stream));
+  hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, h->stream, d_A, P, maxdiag);
+  for (int b = 0; b < nblk; ++b) {
+    const int off = blk_off[b], nb = blk_off[b + 1] - off;
+    if (nb <= 0) continue;
+    ARG_CHECK(h, nb <= 65535);
+    hipLaunchKernelGGL(copy_block_kernel, dim3((unsigned)cdiv(nb, 128), (unsigned)nb), dim3(128), 0, h->stream, d_A, P, off,
+                       nb, d_D);
+    KERNEL_CHECK(h);
+  }
+  // the shift needs the strided diagonal of each block: do it for the whole D diagonal at once
+  if (shift_rel > 0) {
+    double md = 0.0;
+    HIP_TRY(h, hipMemcpyAsync(&md, maxdiag, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(add_diag_const_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, h->stream, d_D, P, (int64_t)P,
+                       shift_rel * md);
+    KERNEL_CHECK(h);
+  }
+  for (int b = 0; b < nblk; ++b) {
+    const int off = blk_off[b], nb = blk_off[b + 1] - off;
+    if (nb <= 0) continue;
+    // column-major upper factor of the block == row-major lower D_b (A_bb = D_b D_b^T)
+    BLAS_TRY(h, rocsolver_dpotrf(h->blas, rocblas_fill_upper, nb, d_D + (int64_t)off * P + off, P, info));
+    int h_info = 0;
+    HIP_TRY(h, hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h_info != 0)
+      return isdf_fail(h, ISDF_ERR_NUM, "diagonal block %d of A_PP is not positive definite (minor %d of %d)", b, h_info, nb);
+  }
+  return ISDF_OK;
+}
+
+extern "C" int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nblk, const int32_t* blk_off, int side,
+                                int trans, double* d_X, int64_t n, int64_t ldx) {
+  // side 0: rows   X (P, n)  <- op(D)^-1 X          (per block of rows)
+  // side 1: cols   X (n, P)  <- X op(D)^-1          (per block of columns)
+  // op(D) = D (trans 0) or D^T (trans 1); D_b row-major lower = column-major upper U_b = D_b^T
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_D && d_X && blk_off && P > 0 && nblk > 0 && n > 0 && (side == 0 || side == 1) && (trans == 0 || trans == 1));
+  ARG_CHECK(h, n < 2147483647LL && ldx < 2147483647LL);
+  const double one = 1.0;
+  for (int b = 0; b < nblk; ++b) {
+    const int off = blk_off[b], nb = blk_off[b + 1] - off;
+    if (nb <= 0) continue;
+    const double* U = d_D + (int64_t)off * P + off;
+    ProfScope ps(h, "rocblas_dtrsm[flop]", (double)n * nb * nb);
+    if (side == 0) {
+      // column-major view: X_cm (n x P, ld = ldx); rows blk of X == columns blk of X_cm: X_cm[:, blk] <- X_cm[:, blk] op(D)^-T
+      // D^-1 X  <->  X_cm D^-T = X_cm U^-1  (trans 0);   D^-T X  <->  X_cm D^-1 = X_cm U^-T (trans 1)
+      BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper,
+                                trans == 0 ? rocblas_operation_none : rocblas_operation_transpose,
+                                rocblas_diagonal_non_unit, (rocblas_int)n, nb, &one, U, P, d_X + (int64_t)off * ldx,
+                                (rocblas_int)ldx));
+    } else {
+      // X (n x P row-major) column block == rows blk of X_cm (P x n, ld = ldx): X_cm[blk, :] <- op(D)^-T X_cm[blk, :]
+      // X D^-1  <->  D^-T X_cm = U^-1 X_cm (trans 0);   X D^-T  <->  D^-1 X_cm = U^-T X_cm (trans 1)
+      BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper,
+                                trans == 0 ? rocblas_operation_none : rocblas_operation_transpose,
+                                rocblas_diagonal_non_unit, nb, (rocblas_int)n, &one, U, P, d_X + off, (rocblas_int)ldx));
+    }
+  }
+  return ISDF_OK;
+}
+
+extern "C" int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_A && P > 0 && shift_rel >= 0);
+  int* info = (int*)isdf_ws(h, "fit_info", 256);
+  if (!info) return ISDF_ERR_HIP;
+  double* maxdiag = (double*)(info + 16);
+  if (shift_rel > 0) {
+    hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, h->stream, d_A, P, maxdiag);
+    hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, h->stream, d_A, P, maxdiag, shift_rel);
+    KERNEL_CHECK(h);
+  }
+  { ProfScope ps(h, "rocsolver_dpotrf[flop]", (double)P * P * P / 3.0);
+    BLAS_TRY(h, rocsolver_dpotrf(h->blas, rocblas_fill_upper, P, d_A, P, info)); }
+  int h_info = 0;
+  HIP_TRY(h, hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h_info != 0) return isdf_fail(h, ISDF_ERR_NUM, "matrix is not numerically positive definite (minor %d of %d)", h_info, P);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_gather_aoP(isdf_handle h, const double* d_ao, int nao, int64_t ld, const int64_t* d_ip, int P,
+                               double* d_aoP) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_ao && d_ip && d_aoP && nao > 0 && nao <= 65535 && P > 0);
+  hipLaunchKernelGGL(transpose_gather_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)nao), dim3(256), 0, h->stream, d_ao,
+                     ld, d_ip, P, nao, d_aoP);
+  KERNEL_CHECK(h);
   return ISDF_OK;
 }

@@ -75,6 +75,8 @@ class ISDF:
         self.reg_used = 0.0
         self.k_ip_factor = None           # k-points: points = c_isdf * nao * k_ip_factor (default min(nk, 2))
         self.force_sharded = False       # run the multi-GPU code path even on one rank (tests)
+        self.fit_route = 'cholesky'      # 'cholesky': forward solve over the grid (S3b); 'blockjacobi': none at all (S3c)
+        self.block_shift = 0.0           # relative diagonal shift of the per-atom blocks in the S3c route
         self.explicit_theta = False      # True: form Theta itself (second O(P^2 G) solve); same W in exact arithmetic
         self.fft_batch = None             # rows per FFT batch (None: sized from free memory)
         self._backend = backend
@@ -256,10 +258,22 @@ class ISDF:
             theta = self._buffer('theta', (max(Pmax, nao + kmax), G))[:P]
             self.aoP = self._buffer('aoP', (P, nao))
             chol = self._buffer('factor', (P, P))
-            self.reg_used = be.fit_prepare(self.ao, be.to_device(self.ip), self.reg_rel, self.aoP, chol)
-            # forward solve only (Y = Lr^-1 B); the backward solve is applied to the (P, P) matrix below
-            be.fit_apply(chol, self.aoP, self.ao, G, theta, forward_only=not self.explicit_theta)
-            factor = None if self.explicit_theta else (chol, 0)
+            d_ip = be.to_device(self.ip)
+            if self.fit_route == 'blockjacobi' and not self.explicit_theta:
+                # S3c: no triangular solve over the grid.  theta <- Y' = D^-1 (aoP ao)^2, chol <- A (for A')
+                ip_off = np.append(0, np.cumsum(rank)).astype(np.int32)
+                be.gather_aoP(self.ao, d_ip, self.aoP)
+                be.gram_sq(self.aoP, chol)
+                Dblk = self._buffer('Dblk', (P, P))
+                be.block_chol(chol, ip_off, self.block_shift, Dblk)
+                be.pair_gram_rows(self.aoP, self.ao, G, theta)
+                be.block_solve(Dblk, ip_off, 0, 0, theta)
+                factor = ('blockjacobi', chol, Dblk, ip_off)
+            else:
+                self.reg_used = be.fit_prepare(self.ao, d_ip, self.reg_rel, self.aoP, chol)
+                # forward solve only (Y = Lr^-1 B); the backward solve is applied to the (P, P) matrix below
+                be.fit_apply(chol, self.aoP, self.ao, G, theta, forward_only=not self.explicit_theta)
+                factor = None if self.explicit_theta else (chol, 0)
             t0 = self._tick('S3_fit', t0)
         else:
             raise ValueError("select must be 'local' or 'global'")
@@ -269,7 +283,17 @@ class ISDF:
         batch = self.fft_batch or _default_fft_batch(G, P)
         be.coulomb_W(theta, mesh, a, 0, P, batch, self.W, upper_only=True)
         be.symmetrize_upper(self.W)
-        if factor is not None:
+        if factor is not None and factor[0] == 'blockjacobi':
+            _, A, Dblk, ip_off = factor
+            be.block_solve(Dblk, ip_off, 0, 0, A)            # A' = D^-1 A D^-T
+            be.block_solve(Dblk, ip_off, 1, 1, A)
+            be.chol_inplace(A, self.reg_rel)
+            self.reg_used = self.reg_rel
+            be.W_from_factor(A, 2, self.W)                   # W' = A'^-1 M' A'^-1
+            be.W_from_factor(A, 0, self.W)
+            be.block_solve(Dblk, ip_off, 0, 1, self.W)       # W = D^-T W' D^-1
+            be.block_solve(Dblk, ip_off, 1, 0, self.W)
+        elif factor is not None:
             be.W_from_factor(factor[0], factor[1], self.W)
         del theta
         t0 = self._tick('S4S5_coulomb_W', t0)

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 
@@ -34,6 +34,12 @@ SIGNATURES = {
     'isdf_fit_from_chol': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp]),
     'isdf_fit_prepare': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_dbl, c_vp, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_fit_apply': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_i64, c_int, c_vp, c_i64]),
+    'isdf_gather_aoP': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp]),
+    'isdf_gram_sq': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    'isdf_pair_gram_rows': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64]),
+    'isdf_block_chol': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_dbl, c_vp]),
+    'isdf_block_solve': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_i64, c_i64]),
+    'isdf_chol_inplace': (c_int, [c_vp, c_vp, c_int, c_dbl]),
     'isdf_gather_T': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),
     'isdf_W_from_factor': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64]),
     'isdf_fit_global': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_vp, c_i64, c_vp, ctypes.POINTER(c_dbl)]),

@@ -77,10 +77,50 @@ class OracleBackend:
         else:
             theta[:, :ng] = torch.from_numpy(scipy.linalg.cho_solve((chol.numpy(), True), B))
 
+    def gather_aoP(self, ao, ip, aoP):
+        aoP.copy_(torch.from_numpy(np.ascontiguousarray(ao.numpy()[:, ip.numpy()].T)))
+
+    def gram_sq(self, aoP, A, nh=0):
+        A.copy_(torch.from_numpy(aoP.numpy().dot(aoP.numpy().T) ** 2))
+
+    def pair_gram_rows(self, aoP, ao, ng, B, nh=0):
+        B[:, :ng] = torch.from_numpy(aoP.numpy().dot(ao.numpy()[:, :ng]) ** 2)
+
+    def block_chol(self, A, blk_off, shift_rel, D):
+        a = A.numpy()
+        d = np.zeros_like(a)
+        for b in range(len(blk_off) - 1):
+            s = slice(blk_off[b], blk_off[b + 1])
+            if s.stop > s.start:
+                d[s, s] = np.linalg.cholesky(a[s, s] + shift_rel * a.diagonal().max() * np.eye(s.stop - s.start))
+        D.copy_(torch.from_numpy(d))
+
+    def block_solve(self, D, blk_off, side, trans, X):
+        d, x = D.numpy(), X.numpy()
+        for b in range(len(blk_off) - 1):
+            s = slice(blk_off[b], blk_off[b + 1])
+            if s.stop == s.start:
+                continue
+            if side == 0:
+                x[s] = scipy.linalg.solve_triangular(d[s, s], x[s], lower=True, trans='T' if trans else 'N')
+            else:
+                # X op(D)^-1 = (op(D)^-T X^T)^T
+                x[:, s] = scipy.linalg.solve_triangular(d[s, s], x[:, s].T, lower=True, trans='N' if trans else 'T').T
+
+    def chol_inplace(self, A, shift_rel):
+        a = A.numpy()
+        a[np.diag_indices(len(a))] += shift_rel * a.diagonal().max()
+        A.copy_(torch.from_numpy(np.linalg.cholesky(a)))
+
     def gather_T(self, L, k, piv, T):
         T.copy_(torch.from_numpy(np.triu(L.numpy()[:k][:, piv.numpy()[:k]])))
 
     def W_from_factor(self, F, kind, M):
+        if kind == 2:                                          # M <- U^-T M U^-1 with A = U^T U, U = F^T
+            Lr = F.numpy()
+            Z = scipy.linalg.solve_triangular(Lr, M.numpy(), lower=True)
+            M.copy_(torch.from_numpy(scipy.linalg.solve_triangular(Lr, Z.T, lower=True).T))
+            return
         S = F.numpy().T if kind == 0 else F.numpy()          # upper triangular S, Theta = S^-1 Y
         Z = scipy.linalg.solve_triangular(S, M.numpy(), lower=False)
         M.copy_(torch.from_numpy(scipy.linalg.solve_triangular(S, Z.T, lower=False).T))
