@@ -164,7 +164,9 @@ int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, 
  *   isdf_block_chol      d_D (P, P): zero except the diagonal blocks, which hold the row-major lower Cholesky
  *                        factors D_b of A_bb + shift_rel*max(diag A)*I
  *   isdf_block_solve     side 0: X (P, n) <- op(D)^-1 X;  side 1: X (n, P) <- X op(D)^-1;  op = D (trans 0) | D^T (trans 1)
- *   isdf_chol_inplace    d_A <- Cholesky factor (same storage convention as isdf_fit_prepare's d_chol)
+ *   isdf_chol_inplace    d_A <- Cholesky factor (same storage convention and the same shift ladder as
+ *                        isdf_fit_prepare's d_chol; *reg_used = the relative shift that succeeded; d_scratch:
+ *                        P*P doubles for the retries, NULL = library workspace)
  *   isdf_W_from_factor   kind 2: M <- U^-T M U^-1 ; followed by kind 0 gives A^-1 M A^-1. */
 int isdf_gather_aoP(isdf_handle h, const double* d_ao, int nao, int64_t ld, const int64_t* d_ip, int P,
                     double* d_aoP);
@@ -175,7 +177,14 @@ int isdf_block_chol(isdf_handle h, const double* d_A, int P, int nblk, const int
                     double shift_rel, double* d_D);
 int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nblk, const int32_t* blk_off, int side,
                      int trans, double* d_X, int64_t n, int64_t ldx);
-int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel);
+int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel, double* d_scratch, double* reg_used);
+
+/* A-posteriori check of the block-Jacobi route (it amplifies rounding in M' by cond(A')):
+ * for probe vectors t_j (rows of d_T, values of a density at the points) the fitted density Theta^T t_j on ng grid
+ * columns,   d_T (n, P) <- e_j = A'^-1 D^-1 t_j  (in place),   d_F (n, ldf) <- E Y'.
+ * The caller compares  t^T W t  with  w * sum_g F conv(F)  (isdf_coulomb_rows + isdf_gemm_nt). */
+int isdf_bj_probe_rows(isdf_handle h, double* d_T, int n, const double* d_fac, const double* d_D, int P, int nblk,
+                       const int32_t* blk_off, const double* d_Yp, int64_t ng, int64_t ldy, double* d_F, int64_t ldf);
 
 /* T (k, k) row-major upper triangular, T[t][s] = L[t][piv[s]] for s >= t: the triangular factor that
  * turns the selection's Cholesky rows into interpolation vectors (Theta = T^-1 L). */
@@ -206,6 +215,9 @@ int isdf_coulomb_rows(isdf_handle h, const double* d_in, int nrows, int64_t ld,
                       const int32_t mesh[3], const double a[9], int batch, double* d_out, int64_t ldo);
 /* W[q][p] = W[p][q] for q > p. */
 int isdf_symmetrize_upper(isdf_handle h, double* d_W, int P, int64_t ldw);
+/* W <- (W + W^T) / 2 (after the two-sided solves of the block-Jacobi route, whose rounding along null(A_PP) is not
+ * symmetric; the mean keeps that noise inside null(A_PP) x null(A_PP), mirroring one triangle would not). */
+int isdf_symmetrize_mean(isdf_handle h, double* d_W, int P, int64_t ldw);
 
 /* S6. J exactly as pyscf/pbc/df/fft_jk.py:63-107 (Γ, real dm):
  *   rho = sum_mn dm_mn ao_m ao_n;  v = (vol/G) ifft(coulG fft rho).real;  vj = ao (v .* ao)^T.

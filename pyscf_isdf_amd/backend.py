@@ -43,6 +43,11 @@ class HipBackend:
     def to_host(self, t):
         return t.detach().cpu().numpy()
 
+    def free_bytes(self):
+        """Device memory obtainable right now: free on the device + free inside torch's cache."""
+        free, _ = torch.cuda.mem_get_info(self.device)
+        return int(free + torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device))
+
     def empty_cache(self):
         torch.cuda.empty_cache()
 
@@ -160,9 +165,20 @@ class HipBackend:
         self.handle.call('isdf_block_solve', self._p(D), D.shape[0], len(blk_off) - 1, _np_ptr(blk_off), int(side), int(trans),
                          self._p(X), int(n), X.stride(0))
 
-    def chol_inplace(self, A, shift_rel):
+    def chol_inplace(self, A, shift_rel, scratch=None):
         self._stream()
-        self.handle.call('isdf_chol_inplace', self._p(A), A.shape[0], float(shift_rel))
+        reg = ctypes.c_double(0.0)
+        assert scratch is None or scratch.numel() >= A.numel()
+        self.handle.call('isdf_chol_inplace', self._p(A), A.shape[0], float(shift_rel),
+                         self._p(scratch) if scratch is not None else None, ctypes.byref(reg))
+        return reg.value
+
+    def bj_probe_rows(self, T, fac, D, blk_off, Yp, ng, F):
+        """T (n, P) <- A'^-1 D^-1 t_j in place; F (n, ng) <- T Yp."""
+        self._stream()
+        blk_off = np.ascontiguousarray(blk_off, dtype=np.int32)
+        self.handle.call('isdf_bj_probe_rows', self._p(T), T.shape[0], self._p(fac), self._p(D), D.shape[0],
+                         len(blk_off) - 1, _np_ptr(blk_off), self._p(Yp), int(ng), Yp.stride(0), self._p(F), F.stride(0))
 
     def gather_T(self, L, k, piv, T):
         self._stream()
@@ -202,6 +218,10 @@ class HipBackend:
     def symmetrize_upper(self, W):
         self._stream()
         self.handle.call('isdf_symmetrize_upper', self._p(W), W.shape[0], W.stride(0))
+
+    def symmetrize_mean(self, W):
+        self._stream()
+        self.handle.call('isdf_symmetrize_mean', self._p(W), W.shape[0], W.stride(0))
 
     def get_j(self, ao, ngrids, mesh, a, dm, vj):
         self._stream()

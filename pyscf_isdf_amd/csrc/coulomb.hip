@@ -119,7 +119,36 @@ __global__ void mirror_upper_kernel(double* __restrict__ W, int P, int64_t ldw) 
     if (r < P && cc < P && r > cc) W[(int64_t)r * ldw + cc] = tile[tx][i];
   }
 }
+// W <- (W + W^T) / 2, tile pairs (by, bx) / (bx, by) with bx >= by
+__global__ void mean_symmetric_kernel(double* __restrict__ W, int P, int64_t ldw) {
+  __shared__ double up[32][33], lo[32][33];
+  const int bx = blockIdx.x, by = blockIdx.y;
+  if (bx < by) return;
+  const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = by * 32 + i, cc = bx * 32 + tx;
+    up[i][tx] = (r < P && cc < P) ? W[(int64_t)r * ldw + cc] : 0.0;
+    const int r2 = bx * 32 + i, c2 = by * 32 + tx;
+    lo[i][tx] = (r2 < P && c2 < P) ? W[(int64_t)r2 * ldw + c2] : 0.0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int r = by * 32 + i, cc = bx * 32 + tx;
+    if (r < P && cc < P) W[(int64_t)r * ldw + cc] = 0.5 * (up[i][tx] + lo[tx][i]);
+    const int r2 = bx * 32 + i, c2 = by * 32 + tx;
+    if (bx != by && r2 < P && c2 < P) W[(int64_t)r2 * ldw + c2] = 0.5 * (lo[i][tx] + up[tx][i]);
+  }
+}
 }  // namespace
+
+extern "C" int isdf_symmetrize_mean(isdf_handle h, double* d_W, int P, int64_t ldw) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_W && P > 0 && ldw >= P);
+  const unsigned nt = (unsigned)cdiv(P, 32);
+  hipLaunchKernelGGL(mean_symmetric_kernel, dim3(nt, nt), dim3(32, 8), 0, h->stream, d_W, P, ldw);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
 
 extern "C" int isdf_symmetrize_upper(isdf_handle h, double* d_W, int P, int64_t ldw) {
   if (!h) return ISDF_ERR_ARG;

@@ -430,24 +430,56 @@ extern "C" int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nbl
   return ISDF_OK;
 }
 
-extern "C" int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel) {
+extern "C" int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel, double* d_scratch,
+                                 double* reg_used) {
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_A && P > 0 && shift_rel >= 0);
   int* info = (int*)isdf_ws(h, "fit_info", 256);
-  if (!info) return ISDF_ERR_HIP;
+  // the unshifted matrix is kept for the retries: in the caller's scratch (P*P doubles) when given
+  double* keep = d_scratch ? d_scratch : (double*)isdf_ws(h, "chol_keep", sizeof(double) * (size_t)P * P);
+  if (!info || !keep) return ISDF_ERR_HIP;
   double* maxdiag = (double*)(info + 16);
-  if (shift_rel > 0) {
-    hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, h->stream, d_A, P, maxdiag);
-    hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, h->stream, d_A, P, maxdiag, shift_rel);
-    KERNEL_CHECK(h);
+  HIP_TRY(h, hipMemcpyAsync(keep, d_A, sizeof(double) * (size_t)P * P, hipMemcpyDeviceToDevice, h->stream));
+  // same ladder as isdf_fit_prepare: an over-complete point set makes the matrix numerically singular
+  double reg = shift_rel;
+  for (int attempt = 0; attempt < 5; ++attempt) {
+    if (attempt > 0)
+      HIP_TRY(h, hipMemcpyAsync(d_A, keep, sizeof(double) * (size_t)P * P, hipMemcpyDeviceToDevice, h->stream));
+    if (reg > 0) {
+      hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, h->stream, d_A, P, maxdiag);
+      hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, h->stream, d_A, P, maxdiag, reg);
+      KERNEL_CHECK(h);
+    }
+    { ProfScope ps(h, "rocsolver_dpotrf[flop]", (double)P * P * P / 3.0);
+      BLAS_TRY(h, rocsolver_dpotrf(h->blas, rocblas_fill_upper, P, d_A, P, info)); }
+    int h_info = 0;
+    HIP_TRY(h, hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h_info == 0) {
+      if (reg_used) *reg_used = reg;
+      return ISDF_OK;
+    }
+    reg = (reg > 0.0) ? reg * 100.0 : 1e-14;
   }
-  { ProfScope ps(h, "rocsolver_dpotrf[flop]", (double)P * P * P / 3.0);
-    BLAS_TRY(h, rocsolver_dpotrf(h->blas, rocblas_fill_upper, P, d_A, P, info)); }
-  int h_info = 0;
-  HIP_TRY(h, hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  if (h_info != 0) return isdf_fail(h, ISDF_ERR_NUM, "matrix is not numerically positive definite (minor %d of %d)", h_info, P);
-  return ISDF_OK;
+  return isdf_fail(h, ISDF_ERR_NUM, "matrix is not numerically positive definite even with diagonal shift %g * max diag",
+                   reg / 100.0);
+}
+
+extern "C" int isdf_bj_probe_rows(isdf_handle h, double* d_T, int n, const double* d_fac, const double* d_D, int P,
+                                  int nblk, const int32_t* blk_off, const double* d_Yp, int64_t ng, int64_t ldy,
+                                  double* d_F, int64_t ldf) {
+  // T (n, P) rows t_j  ->  e_j = A'^-1 D^-1 t_j (in place),  F (n, ng) = E Y' = (Theta^T t_j) on the grid columns
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_T && d_fac && d_D && d_Yp && d_F && n > 0 && P > 0 && ng > 0 && ldy >= ng && ldf >= ng);
+  int rc = isdf_block_solve(h, d_D, P, nblk, blk_off, 1, 1, d_T, n, P);      // t^T D^-T = (D^-1 t)^T
+  if (rc) return rc;
+  const double one = 1.0;
+  // column-major view T_cm (P x n): T_cm <- U^-1 U^-T T_cm with A' = U^T U
+  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose,
+                            rocblas_diagonal_non_unit, P, n, &one, d_fac, P, d_T, P));
+  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none,
+                            rocblas_diagonal_non_unit, P, n, &one, d_fac, P, d_T, P));
+  return gemm_rm(h, 'N', 'N', n, ng, P, 1.0, d_T, P, d_Yp, ldy, 0.0, d_F, ldf);
 }
 
 extern "C" int isdf_gather_aoP(isdf_handle h, const double* d_ao, int nao, int64_t ld, const int64_t* d_ip, int P,

@@ -57,7 +57,7 @@ int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out
 
 extern "C" {
 
-int isdf_abi_version(void) { return 9; }
+int isdf_abi_version(void) { return 10; }
 
 int isdf_create(int device_id, isdf_handle* out) {
   if (!out) return ISDF_ERR_ARG;

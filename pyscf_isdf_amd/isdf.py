@@ -13,6 +13,7 @@ every stage executes in libmi355_isdf.so via ``backend.HipBackend``.  There is n
 """
 import sys
 import time
+import warnings
 import numpy as np
 import torch
 from . import gto
@@ -75,7 +76,15 @@ class ISDF:
         self.reg_used = 0.0
         self.k_ip_factor = None           # k-points: points = c_isdf * nao * k_ip_factor (default min(nk, 2))
         self.force_sharded = False       # run the multi-GPU code path even on one rank (tests)
-        self.fit_route = 'cholesky'      # 'cholesky': forward solve over the grid (S3b); 'blockjacobi': none at all (S3c)
+        self.fit_route = 'auto'          # 'cholesky': forward solve over the grid (S3b), always safe;
+                                         # 'blockjacobi': no solve over the grid (S3c), amplifies rounding by cond(A');
+                                         # 'auto': S3c, verified with probe densities, S3b when the check fails
+        self.bj_check_tol = 3e-8         # 'auto': largest accepted relative mismatch of the probe energies (tracks
+                                         # max|dK|/|K| of the two routes within a factor of a few, profiles/r01_bj_*)
+        self.bj_max_c = 12               # 'auto': do not even try S3c above this c_isdf (cond(A') grows ~100x per +5)
+        self.bj_nprobe = 8
+        self.bj_check = None             # the measured mismatch of the last 'auto' build
+        self.fit_route_used = None
         self.block_shift = 0.0           # relative diagonal shift of the per-atom blocks in the S3c route
         self.explicit_theta = False      # True: form Theta itself (second O(P^2 G) solve); same W in exact arithmetic
         self.fft_batch = None             # rows per FFT batch (None: sized from free memory)
@@ -163,6 +172,93 @@ class ISDF:
             buf = self.backend.empty((n,), dtype=dtype)
             self._bufs[name] = buf
         return buf[:n].view(*shape)
+
+    # ---- S3c helpers (block-Jacobi route) ---------------------------------------------------------------
+    def _bj_prepare(self, ao, nh, d_ip, ip_off, aoP, scratch=None):
+        """aoP <- ao[:, ip]^T;  returns (Aprime_factor, Dblk): the per-atom block factors D and the Cholesky
+        factor of A' = D^-1 A D^-T (+ reg_rel)."""
+        be = self.backend
+        P = aoP.shape[0]
+        be.gather_aoP(ao, d_ip, aoP)
+        A = self._buffer('factor', (P, P))
+        be.gram_sq(aoP, A, nh)
+        Dblk = self._buffer('Dblk', (P, P))
+        be.block_chol(A, ip_off, self.block_shift, Dblk)
+        be.block_solve(Dblk, ip_off, 0, 0, A)            # A' = D^-1 A D^-T
+        be.block_solve(Dblk, ip_off, 1, 1, A)
+        self.reg_used = be.chol_inplace(A, self.reg_rel, scratch=scratch)
+        return A, Dblk
+
+    def _bj_rows(self, aoP, nh, ao, ng, Dblk, ip_off, out):
+        """out (P, ng) <- Y' = D^-1 (aoP ao)^2 on ng grid columns."""
+        be = self.backend
+        be.pair_gram_rows(aoP, ao, ng, out, nh)
+        be.block_solve(Dblk, ip_off, 0, 0, out)
+
+    def _bj_finish(self, Afac, Dblk, ip_off, W, symmetric=True):
+        """W <- D^-T [A'^-1 W A'^-1] D^-1 (W holds M' on entry)."""
+        be = self.backend
+        be.W_from_factor(Afac, 2, W)
+        be.W_from_factor(Afac, 0, W)
+        be.block_solve(Dblk, ip_off, 0, 1, W)
+        be.block_solve(Dblk, ip_off, 1, 0, W)
+        if symmetric:
+            be.symmetrize_mean(W)         # the rounding noise along null(A) is not symmetric; the mean keeps it in null(A)
+
+    def _fit_routes(self):
+        if self.fit_route not in ('auto', 'blockjacobi', 'cholesky'):
+            raise ValueError("fit_route must be 'auto', 'blockjacobi' or 'cholesky'")
+        if self.explicit_theta or self.fit_route == 'cholesky':
+            return ['cholesky']
+        if self.fit_route == 'blockjacobi':
+            return ['blockjacobi']
+        if self.c_isdf > self.bj_max_c:
+            return ['cholesky']
+        return ['blockjacobi', 'cholesky']
+
+    def _bj_probe_mismatch(self, aoT_P, Afac, Dblk, ip_off, Yp, ng, grid_slice):
+        """A-posteriori check of the S3c route: for random symmetric R_j the density t_j = diag(phi_P R_j phi_P^T)
+        at the points has the Coulomb energy  t^T W t  through the matrix and  w sum_g f conv(f), f = Theta^T t,
+        through the fitted density itself (vector operations only: one pass over Y', nprobe FFTs).  The second form
+        does not see the cond(A')-amplified rounding of M'; their largest relative difference is returned."""
+        be, comm = self.backend, self.comm
+        cell = self.cell
+        nao, P = aoT_P.shape
+        n = int(self.bj_nprobe)
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        rng = np.random.default_rng(20240203)
+        R = rng.standard_normal((n, nao, nao))
+        R = R + R.transpose(0, 2, 1)
+        T = be.empty((n, P))
+        be.rho(aoT_P, P, be.to_device(R), T)
+        T0 = T.clone()
+        # matrix side: t^T W t
+        TW = be.empty((n, P))
+        be.gemm_nt(T0, self.W, TW)
+        e_mat = np.einsum('jp,jp->j', be.to_host(TW), be.to_host(T0))
+        # density side
+        F = be.empty((n, ng))
+        be.bj_probe_rows(T, Afac, Dblk, ip_off, Yp, ng, F)
+        if grid_slice is None:
+            CF = be.empty((n, G))
+            be.coulomb_rows(F, mesh, a, n, out=CF)
+            E = be.empty((n, n))
+            be.gemm_nt(F, CF, E)
+            e_fit = cell.vol / G * np.diag(be.to_host(E))
+        else:
+            # the fitted densities live on grid slices: zero-padded all_reduce, replicated FFT (as the sharded J)
+            g0, g1 = grid_slice
+            full = be.zeros((n, G))
+            full[:, g0:g1] = F
+            comm.all_reduce_sum(full)
+            be.coulomb_rows(full, mesh, a, n)
+            E = be.empty((n, n))
+            be.gemm_nt(F, full[:, g0:g1].contiguous(), E)
+            comm.all_reduce_sum(E)
+            e_fit = cell.vol / G * np.diag(be.to_host(E))
+        return float(abs(e_mat - e_fit).max() / abs(e_fit).max())
 
     def _tick(self, name, t0):
         self.backend.synchronize()
@@ -257,44 +353,53 @@ class ISDF:
             t0 = self._tick('S2_select_ip', t0)
             theta = self._buffer('theta', (max(Pmax, nao + kmax), G))[:P]
             self.aoP = self._buffer('aoP', (P, nao))
-            chol = self._buffer('factor', (P, P))
             d_ip = be.to_device(self.ip)
-            if self.fit_route == 'blockjacobi' and not self.explicit_theta:
-                # S3c: no triangular solve over the grid.  theta <- Y' = D^-1 (aoP ao)^2, chol <- A (for A')
-                ip_off = np.append(0, np.cumsum(rank)).astype(np.int32)
-                be.gather_aoP(self.ao, d_ip, self.aoP)
-                be.gram_sq(self.aoP, chol)
-                Dblk = self._buffer('Dblk', (P, P))
-                be.block_chol(chol, ip_off, self.block_shift, Dblk)
-                be.pair_gram_rows(self.aoP, self.ao, G, theta)
-                be.block_solve(Dblk, ip_off, 0, 0, theta)
-                factor = ('blockjacobi', chol, Dblk, ip_off)
-            else:
-                self.reg_used = be.fit_prepare(self.ao, d_ip, self.reg_rel, self.aoP, chol)
-                # forward solve only (Y = Lr^-1 B); the backward solve is applied to the (P, P) matrix below
-                be.fit_apply(chol, self.aoP, self.ao, G, theta, forward_only=not self.explicit_theta)
-                factor = None if self.explicit_theta else (chol, 0)
-            t0 = self._tick('S3_fit', t0)
+            self.W = self._buffer('W', (P, P))
+            for route in self._fit_routes():
+                if route == 'blockjacobi':
+                    # S3c: no triangular solve over the grid.  theta <- Y' = D^-1 (aoP ao)^2
+                    ip_off = np.append(0, np.cumsum(rank)).astype(np.int32)
+                    Afac, Dblk = self._bj_prepare(self.ao, 0, d_ip, ip_off, self.aoP, scratch=self.W)
+                    self._bj_rows(self.aoP, 0, self.ao, G, Dblk, ip_off, theta)
+                else:
+                    chol = self._buffer('factor', (P, P))
+                    self.reg_used = be.fit_prepare(self.ao, d_ip, self.reg_rel, self.aoP, chol)
+                    # forward solve only (Y = Lr^-1 B); the backward solve is applied to the (P, P) matrix below
+                    be.fit_apply(chol, self.aoP, self.ao, G, theta, forward_only=not self.explicit_theta)
+                t0 = self._tick('S3_fit', t0)
+                batch = self.fft_batch or _default_fft_batch(G, P, be.free_bytes())
+                be.coulomb_W(theta, mesh, a, 0, P, batch, self.W, upper_only=True)
+                be.symmetrize_upper(self.W)
+                if route == 'blockjacobi':
+                    self._bj_finish(Afac, Dblk, ip_off, self.W)
+                elif not self.explicit_theta:
+                    be.W_from_factor(chol, 0, self.W)
+                t0 = self._tick('S4S5_coulomb_W', t0)
+                self.fit_route_used = route
+                if route == 'blockjacobi' and self.fit_route == 'auto':
+                    aoT = be.empty((nao, P))
+                    be.gather_cols(self.ao, d_ip, aoT)
+                    self.bj_check = self._bj_probe_mismatch(aoT, Afac, Dblk, ip_off, theta, G, None)
+                    del aoT
+                    t0 = self._tick('S5_route_check', t0)
+                    if self.bj_check <= self.bj_check_tol:
+                        break
+                    warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e); '
+                                  'rebuilding W with the Cholesky route' % (self.bj_check, self.bj_check_tol))
+            del theta
+            self._built = True
+            return self
         else:
             raise ValueError("select must be 'local' or 'global'")
 
-        # S4 + S5 Coulomb convolution and W
+        # S4 + S5 Coulomb convolution and W (global selection)
         self.W = self._buffer('W', (P, P))
         batch = self.fft_batch or _default_fft_batch(G, P)
         be.coulomb_W(theta, mesh, a, 0, P, batch, self.W, upper_only=True)
         be.symmetrize_upper(self.W)
-        if factor is not None and factor[0] == 'blockjacobi':
-            _, A, Dblk, ip_off = factor
-            be.block_solve(Dblk, ip_off, 0, 0, A)            # A' = D^-1 A D^-T
-            be.block_solve(Dblk, ip_off, 1, 1, A)
-            be.chol_inplace(A, self.reg_rel)
-            self.reg_used = self.reg_rel
-            be.W_from_factor(A, 2, self.W)                   # W' = A'^-1 M' A'^-1
-            be.W_from_factor(A, 0, self.W)
-            be.block_solve(Dblk, ip_off, 0, 1, self.W)       # W = D^-T W' D^-1
-            be.block_solve(Dblk, ip_off, 1, 0, self.W)
-        elif factor is not None:
+        if factor is not None:
             be.W_from_factor(factor[0], factor[1], self.W)
+        self.fit_route_used = 'selection-cholesky'
         del theta
         t0 = self._tick('S4S5_coulomb_W', t0)
         self._built = True
@@ -471,57 +576,74 @@ class ISDF:
         P = len(self.ip)
         t0 = self._tick('S2_select_ip', t0)
 
-        # S3: phi at the points (tiny collocation, replicated), Cholesky replicated, fit on the slice
+        # S3: phi at the points (tiny collocation, replicated), P x P factorisations replicated, rows on the slice
         aoP_T = be.empty((nao, P))
         be.eval_ao(*ao_args, be.to_device(np.ascontiguousarray(coords[self.ip].T)), aoP_T)
         self.aoP = self._buffer('aoP', (P, nao))
-        chol = self._buffer('chol', (P, P))
-        self.reg_used = be.fit_prepare(aoP_T, be.to_device(np.arange(P, dtype=np.int64)), self.reg_rel, self.aoP, chol)
-        del aoP_T
         theta = self._buffer('theta', (P, ng))
-        be.fit_apply(chol, self.aoP, self.ao, ng, theta, forward_only=not self.explicit_theta)
-        t0 = self._tick('S3_fit', t0)
+        ar = be.to_device(np.arange(P, dtype=np.int64))
+        ip_off = np.append(0, np.cumsum([len(merged[b]) for b in sorted(merged)])).astype(np.int32)
+        for route in self._fit_routes():
+            if route == 'blockjacobi':
+                Afac, Dblk = self._bj_prepare(aoP_T, 0, ar, ip_off, self.aoP, scratch=self._buffer('W', (P, P)))
+                self._bj_rows(self.aoP, 0, self.ao, ng, Dblk, ip_off, theta)
+            else:
+                chol = self._buffer('factor', (P, P))
+                self.reg_used = be.fit_prepare(aoP_T, ar, self.reg_rel, self.aoP, chol)
+                be.fit_apply(chol, self.aoP, self.ao, ng, theta, forward_only=not self.explicit_theta)
+            t0 = self._tick('S3_fit', t0)
 
-        # S4 + S5 streamed over row batches: rank q convolves rows P_q[t*nb : (t+1)*nb] in step t
-        w = cell.vol / G
-        self.W = self._buffer('W', (P, P))
-        self.W.zero_()
-        slices = [comm.split_range(G, r) for r in range(R)]
-        rows = [comm.split_range(P, r) for r in range(R)]
-        nb = self.fft_batch or _default_fft_batch(G, max(1, P // R))
-        nsteps = max(-(-(hi - lo) // nb) for lo, hi in rows)
-        for t in range(nsteps):
-            bat = [(min(lo + t * nb, hi), min(lo + (t + 1) * nb, hi)) for lo, hi in rows]   # rows handled by rank q
-            nrow = [hi - lo for lo, hi in bat]
-            # all-to-all 1: send Theta[bat_q, S_r] to q; receive Theta[bat_r, S_q] from q
-            send = [theta[lo:hi] for lo, hi in bat]
-            recv = [be.empty((nrow[rk], s1 - s0)) for s0, s1 in slices]
-            comm.all_to_all(recv, send)
-            full = be.empty((nrow[rk], G))
-            for (s0, s1), piece in zip(slices, recv):
-                full[:, s0:s1] = piece
-            del recv
-            if nrow[rk]:
-                be.coulomb_rows(full, mesh, a, max(1, nrow[rk]))
-            # all-to-all 2: send V[bat_r, S_q] to q; receive V[bat_q, S_r] from q
-            send = [full[:, s0:s1].contiguous() for s0, s1 in slices]
-            recv = [be.empty((nrow[q], ng)) for q in range(R)]
-            comm.all_to_all(recv, send)
-            del full, send
-            for q in range(R):
-                if nrow[q]:
-                    # W[bat_q, c0:] = w V[bat_q, S_r] Theta[c0:, S_r]^T  (partial over this rank's slice).
-                    # W is symmetric: only the columns from the batch's first row on are computed and
-                    # the lower part is mirrored after the all-reduce (half the flops).
-                    c0 = bat[q][0]
-                    be.gemm_nt(recv[q], theta[c0:], self.W[bat[q][0]:bat[q][1], c0:], alpha=w, beta=0.0)
-            del recv
-        del theta
-        comm.all_reduce_sum(self.W)
-        be.symmetrize_upper(self.W)
-        if not self.explicit_theta:
-            be.W_from_factor(chol, 0, self.W)
-        t0 = self._tick('S4S5_coulomb_W', t0)
+            # S4 + S5 streamed over row batches: rank q convolves rows P_q[t*nb : (t+1)*nb] in step t
+            w = cell.vol / G
+            self.W = self._buffer('W', (P, P))
+            self.W.zero_()
+            slices = [comm.split_range(G, r) for r in range(R)]
+            rows = [comm.split_range(P, r) for r in range(R)]
+            nb = self.fft_batch or _default_fft_batch(G, max(1, P // R))
+            nsteps = max(-(-(hi - lo) // nb) for lo, hi in rows)
+            for t in range(nsteps):
+                bat = [(min(lo + t * nb, hi), min(lo + (t + 1) * nb, hi)) for lo, hi in rows]   # rows handled by rank q
+                nrow = [hi - lo for lo, hi in bat]
+                # all-to-all 1: send Theta[bat_q, S_r] to q; receive Theta[bat_r, S_q] from q
+                send = [theta[lo:hi] for lo, hi in bat]
+                recv = [be.empty((nrow[rk], s1 - s0)) for s0, s1 in slices]
+                comm.all_to_all(recv, send)
+                full = be.empty((nrow[rk], G))
+                for (s0, s1), piece in zip(slices, recv):
+                    full[:, s0:s1] = piece
+                del recv
+                if nrow[rk]:
+                    be.coulomb_rows(full, mesh, a, max(1, nrow[rk]))
+                # all-to-all 2: send V[bat_r, S_q] to q; receive V[bat_q, S_r] from q
+                send = [full[:, s0:s1].contiguous() for s0, s1 in slices]
+                recv = [be.empty((nrow[q], ng)) for q in range(R)]
+                comm.all_to_all(recv, send)
+                del full, send
+                for q in range(R):
+                    if nrow[q]:
+                        # W[bat_q, c0:] = w V[bat_q, S_r] Theta[c0:, S_r]^T  (partial over this rank's slice).
+                        # W is symmetric: only the columns from the batch's first row on are computed and
+                        # the lower part is mirrored after the all-reduce (half the flops).
+                        c0 = bat[q][0]
+                        be.gemm_nt(recv[q], theta[c0:], self.W[bat[q][0]:bat[q][1], c0:], alpha=w, beta=0.0)
+                del recv
+            comm.all_reduce_sum(self.W)
+            be.symmetrize_upper(self.W)
+            if route == 'blockjacobi':
+                self._bj_finish(Afac, Dblk, ip_off, self.W)
+            elif not self.explicit_theta:
+                be.W_from_factor(chol, 0, self.W)
+            t0 = self._tick('S4S5_coulomb_W', t0)
+            self.fit_route_used = route
+            if route == 'blockjacobi' and self.fit_route == 'auto':
+                # every rank computes the same number (replicated W, all-reduced probe energies): same decision
+                self.bj_check = self._bj_probe_mismatch(aoP_T, Afac, Dblk, ip_off, theta, ng, (g0, g1))
+                t0 = self._tick('S5_route_check', t0)
+                if self.bj_check <= self.bj_check_tol:
+                    break
+                warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e); '
+                              'rebuilding W with the Cholesky route' % (self.bj_check, self.bj_check_tol))
+        del theta, aoP_T
         self._built = True
         return self
 
@@ -624,9 +746,18 @@ class ISDF:
         # S3 global fit, forward solve only (Y); the factor is applied to the (P, P) matrices
         Y = self._buffer('theta', (max(P, P_target), G))[:P]
         aoP_X = self._buffer('aoP', (P, 2 * nh))
-        chol = self._buffer('factor', (P, P))
-        self.reg_used = be.fit_prepare_cplx(X, nh, ip_dev, self.reg_rel, aoP_X, chol)
-        be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=not self.explicit_theta)
+        # k-points: the probe check is not implemented for the complex W^q, so 'auto' means the Cholesky route;
+        # fit_route='blockjacobi' is honoured unguarded
+        use_bj = self.fit_route == 'blockjacobi' and not self.explicit_theta and self.select != 'global'
+        self.fit_route_used = 'blockjacobi' if use_bj else 'cholesky'
+        if use_bj:
+            ip_off = np.append(0, np.cumsum(rank)).astype(np.int32)
+            Afac, Dblk = self._bj_prepare(X, nh, ip_dev, ip_off, aoP_X)
+            self._bj_rows(aoP_X, nh, X, G, Dblk, ip_off, Y)
+        else:
+            chol = self._buffer('factor', (P, P))
+            self.reg_used = be.fit_prepare_cplx(X, nh, ip_dev, self.reg_rel, aoP_X, chol)
+            be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=not self.explicit_theta)
         t0 = self._tick('S3_fit', t0)
 
         # Bloch AOs at the points: phi^k(r_P) = exp(i k.r_P) u^k(r_P), (P, nao) complex per k
@@ -664,7 +795,10 @@ class ISDF:
             coulG = be.to_device(pbc_tools.get_coulG(cell, q, mesh))
             be.coulomb_Wq(Y, mesh, coulG, w, 0, P, batch, Wre, Wim, upper_only=True)
             be.symmetrize_hermitian(Wre, Wim)
-            if not self.explicit_theta:
+            if use_bj:
+                self._bj_finish(Afac, Dblk, ip_off, Wre, symmetric=False)
+                self._bj_finish(Afac, Dblk, ip_off, Wim, symmetric=False)
+            elif not self.explicit_theta:
                 be.W_from_factor(chol, 0, Wre)
                 be.W_from_factor(chol, 0, Wim)
             Wc = be.empty((P, P), dtype=torch.complex128)
@@ -923,10 +1057,14 @@ def _aoslice_by_atom(cell):
     raise AttributeError('cell lacks aoslice_by_atom')
 
 
-def _default_fft_batch(G, P):
+def _default_fft_batch(G, P, free_bytes=None):
     """Rows per FFT batch: up to ~7 GiB for the real batch (+ as much for its half spectrum), a
-    multiple of the GEMM's 128-row tile so that no MFMA work is wasted on padding."""
+    multiple of the GEMM's 128-row tile so that no MFMA work is wasted on padding.  With free_bytes
+    the batch also has to fit what is left: 8 G per row for V, ~8 G for the half spectrum and as much
+    again for the FFT's work area, 2 GiB kept back for the GEMM's slab buffers."""
     nb = int((7 << 30) // (8 * G))
+    if free_bytes is not None:
+        nb = min(nb, int(max(0, free_bytes - (2 << 30)) // (24 * G)))
     nb = min(P, nb, 1024)
     if nb >= 128:
         nb -= nb % 128

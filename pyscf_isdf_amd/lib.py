@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 
@@ -39,13 +39,15 @@ SIGNATURES = {
     'isdf_pair_gram_rows': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64]),
     'isdf_block_chol': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_dbl, c_vp]),
     'isdf_block_solve': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_i64, c_i64]),
-    'isdf_chol_inplace': (c_int, [c_vp, c_vp, c_int, c_dbl]),
+    'isdf_chol_inplace': (c_int, [c_vp, c_vp, c_int, c_dbl, c_vp, ctypes.POINTER(c_dbl)]),
+    'isdf_bj_probe_rows': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64]),
     'isdf_gather_T': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),
     'isdf_W_from_factor': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64]),
     'isdf_fit_global': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_vp, c_i64, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_coulomb_W': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64]),
     'isdf_coulomb_rows': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_vp, c_i64]),
     'isdf_symmetrize_upper': (c_int, [c_vp, c_vp, c_int, c_i64]),
+    'isdf_symmetrize_mean': (c_int, [c_vp, c_vp, c_int, c_i64]),
     'isdf_get_j': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_vp]),
     'isdf_rho': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_i64]),
     'isdf_coulomb_potential': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),

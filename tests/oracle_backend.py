@@ -26,6 +26,9 @@ class OracleBackend:
     def synchronize(self):
         pass
 
+    def free_bytes(self):
+        return 1 << 60
+
     def empty_cache(self):
         pass
 
@@ -81,10 +84,19 @@ class OracleBackend:
         aoP.copy_(torch.from_numpy(np.ascontiguousarray(ao.numpy()[:, ip.numpy()].T)))
 
     def gram_sq(self, aoP, A, nh=0):
-        A.copy_(torch.from_numpy(aoP.numpy().dot(aoP.numpy().T) ** 2))
+        ap = aoP.numpy()
+        a = ap.dot(ap.T) ** 2
+        if nh:
+            a += np.hstack([ap[:, nh:], -ap[:, :nh]]).dot(ap.T) ** 2
+        A.copy_(torch.from_numpy(a))
 
     def pair_gram_rows(self, aoP, ao, ng, B, nh=0):
-        B[:, :ng] = torch.from_numpy(aoP.numpy().dot(ao.numpy()[:, :ng]) ** 2)
+        ap = aoP.numpy()
+        x = ao.numpy()[:, :ng]
+        b = ap.dot(x) ** 2
+        if nh:
+            b += np.hstack([ap[:, nh:], -ap[:, :nh]]).dot(x) ** 2
+        B[:, :ng] = torch.from_numpy(b)
 
     def block_chol(self, A, blk_off, shift_rel, D):
         a = A.numpy()
@@ -107,10 +119,24 @@ class OracleBackend:
                 # X op(D)^-1 = (op(D)^-T X^T)^T
                 x[:, s] = scipy.linalg.solve_triangular(d[s, s], x[:, s].T, lower=True, trans='N' if trans else 'T').T
 
-    def chol_inplace(self, A, shift_rel):
-        a = A.numpy()
-        a[np.diag_indices(len(a))] += shift_rel * a.diagonal().max()
-        A.copy_(torch.from_numpy(np.linalg.cholesky(a)))
+    def chol_inplace(self, A, shift_rel, scratch=None):
+        a0 = A.numpy().copy()
+        reg = shift_rel
+        for attempt in range(5):
+            a = a0.copy()
+            a[np.diag_indices(len(a))] += reg * a.diagonal().max()
+            try:
+                A.copy_(torch.from_numpy(np.linalg.cholesky(a)))
+                return reg
+            except np.linalg.LinAlgError:
+                reg = reg * 100.0 if reg > 0 else 1e-14
+        raise np.linalg.LinAlgError('not positive definite')
+
+    def bj_probe_rows(self, T, fac, D, blk_off, Yp, ng, F):
+        self.block_solve(D, blk_off, 1, 1, T)
+        t = scipy.linalg.cho_solve((fac.numpy(), True), T.numpy().T).T
+        T.copy_(torch.from_numpy(np.ascontiguousarray(t)))
+        F[:, :ng] = torch.from_numpy(t.dot(Yp.numpy()[:, :ng]))
 
     def gather_T(self, L, k, piv, T):
         T.copy_(torch.from_numpy(np.triu(L.numpy()[:k][:, piv.numpy()[:k]])))
@@ -146,6 +172,9 @@ class OracleBackend:
         w = W.numpy()
         iu = np.triu_indices(len(w), 1)
         w.T[iu] = w[iu]
+
+    def symmetrize_mean(self, W):
+        W.copy_((W + W.T) / 2)
 
     def gemm_nt(self, A, B, C, alpha=1.0, beta=0.0, kscale=None):
         b = B.numpy() if kscale is None else B.numpy() * kscale.numpy()

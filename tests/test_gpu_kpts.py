@@ -124,6 +124,24 @@ def test_isdf_kpts_end_to_end(select):
     assert abs(vk - vk_or).max() < 1e-8 * abs(vk_or).max()
 
 
+def test_isdf_kpts_fit_routes_agree():
+    """k-point build: the (opt-in, unguarded) block-Jacobi route and the Cholesky route give the same K on a
+    well-conditioned point set; 'auto' keeps the Cholesky route for k-points."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell, coords, Ls, rcut, kpts, aos, dms = _setup()
+    out = {}
+    for route in ('cholesky', 'blockjacobi'):
+        df = ISDF(cell, kpts=kpts, c_isdf=4, select='local')
+        df.fit_route = route
+        out[route] = (df.get_jk(dms, kpts=kpts, with_j=False)[1], df.ip.copy())
+    assert np.array_equal(out['cholesky'][1], out['blockjacobi'][1])
+    d = out['cholesky'][0] - out['blockjacobi'][0]
+    assert abs(d).max() < 1e-7 * abs(out['cholesky'][0]).max()
+    df = ISDF(cell, kpts=kpts, c_isdf=4, select='local')
+    vk = df.get_jk(dms, kpts=kpts, with_j=False)[1]
+    assert df.fit_route == 'auto' and abs(vk - out['cholesky'][0]).max() < 1e-12 * abs(vk).max()
+
+
 def test_select_complex_mode_panel_from_global_memory(be):
     """Many AOs x k-points: the pivot panel (2 x 9000 doubles) no longer fits the LDS staging budget and
     is broadcast from global memory; pivots must still equal the plain-C oracle's."""

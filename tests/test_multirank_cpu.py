@@ -18,7 +18,7 @@ def _setup_path():
             sys.path.insert(0, p)
 
 
-def _run_case(comm, fft_batch):
+def _run_case(comm, fft_batch, route='cholesky'):
     _setup_path()
     import cells
     from oracle_backend import OracleBackend
@@ -30,41 +30,48 @@ def _run_case(comm, fft_batch):
     dm = dm + dm.transpose(0, 2, 1)
     df = ISDF(cell, c_isdf=3, select='local', backend=OracleBackend(), comm=comm)
     df.fft_batch = fft_batch
+    df.fit_route = route
+    df.bj_check_tol = 1e-6                     # c_isdf=3 on 8 AOs: the check value is ~1e-8, far from the decision
     df.build()
     vj, vk = df.get_jk(dm)
-    return df.ip.copy(), df.W.numpy().copy(), vj, vk
+    return df.ip.copy(), df.W.numpy().copy(), vj, vk, df.fit_route_used, df.bj_check
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, route):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     _setup_path()
     from pyscf_isdf_amd.parallel import Comm
-    ip, W, vj, vk = _run_case(Comm.from_env(), fft_batch=5)      # ragged batches: 12 rows per rank, 5 per step
+    out = _run_case(Comm.from_env(), 5, route)                   # ragged batches: 12 rows per rank, 5 per step
     if rank == 0:
-        q.put((ip, W, vj, vk))
+        q.put(out)
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_match_one_rank():
+@pytest.mark.parametrize('route', ['cholesky', 'blockjacobi', 'auto'])
+def test_two_ranks_match_one_rank(route):
     _setup_path()
     from pyscf_isdf_amd.parallel import Comm
-    ip1, W1, vj1, vk1 = _run_case(Comm(), fft_batch=None)
+    ip1, W1, vj1, vk1, used1, chk1 = _run_case(Comm(), None, route)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, route)) for r in range(2)]
     for p in procs:
         p.start()
-    ip2, W2, vj2, vk2 = q.get(timeout=240)
+    ip2, W2, vj2, vk2, used2, chk2 = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.array_equal(ip1, ip2)
-    assert abs(W1 - W2).max() < 1e-9 * abs(W1).max()
+    assert used1 == used2 == ('cholesky' if route == 'cholesky' else 'blockjacobi')
+    if route == 'auto':
+        # the probe energies are all-reduced over the grid slices: both layouts measure the same mismatch
+        assert chk1 is not None and abs(chk1 - chk2) <= 0.5 * chk1 + 1e-13
+    assert abs(W1 - W2).max() < (1e-9 if route == 'cholesky' else 1e-6) * abs(W1).max()
     assert abs(vj1 - vj2).max() < 1e-10 and abs(vk1 - vk2).max() < 1e-8 * abs(vk1).max()
 
 

@@ -104,3 +104,28 @@ def test_local_blocks_with_global_fit(hec):
     vk = oisdf.get_k(r['aoP'], r['W'], dm)
     # 24 points for 21 independent pair products: the diagonal shift bounds the accuracy here
     assert abs(vk - fftdf.get_k(ao, dm, a, mesh)).max() < 1e-5
+
+
+def test_auto_route_logic_with_checker_backend():
+    """Host logic of fit_route='auto' (no GPU): probe check accepted on a well-conditioned set, Cholesky fallback with
+    a warning on an over-complete one; the checker backend implements the same stage methods as the HIP one."""
+    import warnings
+    import cells
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he2_triclinic()
+    dm = np.eye(cell.nao_nr())
+    ref = ISDF(cell, c_isdf=8, select='local', backend=OracleBackend()); ref.fit_route = 'cholesky'
+    k_ref = ref.get_jk(dm, with_j=False)[1]
+    df = ISDF(cell, c_isdf=8, select='local', backend=OracleBackend())
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        k_auto = df.get_jk(dm, with_j=False)[1]
+    assert df.fit_route == 'auto' and df.fit_route_used == 'cholesky' and df.bj_check > df.bj_check_tol
+    assert any('probe check' in str(w.message) for w in rec)
+    assert abs(k_auto - k_ref).max() < 1e-12
+    ok = ISDF(cell, c_isdf=4, select='local', backend=OracleBackend())
+    ok.get_jk(dm, with_j=False)
+    assert ok.fit_route_used == 'blockjacobi' and ok.bj_check <= ok.bj_check_tol
+    with pytest.raises(ValueError):
+        bad = ISDF(cell, c_isdf=4, select='local', backend=OracleBackend()); bad.fit_route = 'nonsense'; bad.build()
