@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument('--workload', default=os.environ.get('ISDF_BENCH_WORKLOAD', 'diamond-444-dzvp-120'))
     ap.add_argument('--select', default='local', choices=['local', 'global'])
     ap.add_argument('--c-isdf', type=int, default=10)
+    ap.add_argument('--fit-route', default=None, choices=['auto', 'cholesky', 'blockjacobi'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--stage-report', default=None, help='write the per-kernel table to this file')
     return ap.parse_args()
@@ -112,7 +113,7 @@ def cpu_baseline(cell, c_isdf, gpu_stage_sizes):
     aoP[:n7].T.dot(M.dot(aoP))
     est['S7_get_k'] = (time.perf_counter() - t) * P / n7
     total = sum(est.values())
-    sample = ('numpy/scipy oracle, stage samples extrapolated linearly: S1 %d of %d grid points; S2 1 of %d atom blocks '
+    sample = ('numpy/scipy oracle (Cholesky fit route), stage samples extrapolated linearly: S1 %d of %d grid points; S2 1 of %d atom blocks '
               '(%d pts, %d pivots); S3 full %dx%d Cholesky + %d of %d grid columns; S4 %d of %d FFT rows; S5 %d rows x %d cols; '
               'S6 %d grid points; S7 %d of %d rows; measured %.1f s of CPU work; per-stage estimate (s): %s'
               % (n1, G, natm, m_b, k_b, P, P, n3, G, n4, P, n4, n5, n1, n7, P, time.perf_counter() - t_all,
@@ -153,6 +154,8 @@ def main():
             dm.append((c * occ).dot(c.conj().T))
         dm = np.array(dm)
         df = ISDF(cell, kpts=kpts, c_isdf=args.c_isdf, select=args.select, comm=comm)
+    if args.fit_route:
+        df.fit_route = args.fit_route
     be = df.backend
 
     def barrier():
@@ -230,7 +233,9 @@ def main():
             'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': workloads.WORKLOADS[args.workload][1], 'natm': cell.natm, 'nao': nao, 'ngrids': G,
                        'nip': P, 'c_isdf': args.c_isdf, 'select': args.select, 'parallelism': ('grid-shard x%d' if kpts is None else 'q-shard x%d') % world,
-                       'nkpts': (1 if kpts is None else len(kpts))},
+                       'nkpts': (1 if kpts is None else len(kpts)),
+                       'fit_route': df.fit_route, 'fit_route_used': df.fit_route_used,
+                       'route_probe_mismatch': df.bj_check, 'route_probe_tol': df.bj_check_tol},
             'whole_path_algorithmic_GBps': round(alg_bytes / sec_per_step / 1e9, 1),
             'stage_seconds_last_step': {k: round(v, 4) for k, v in df.timings.items()},
             'energies': ({'EJ': float(np.einsum('ij,ji', vj, dm) / 2), 'EK': float(np.einsum('ij,ji', vk, dm) / 4)} if kpts is None else

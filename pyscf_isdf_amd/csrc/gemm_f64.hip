@@ -378,21 +378,27 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
                     (((uintptr_t)A) % 16 == 0) && (((uintptr_t)B) % 16 == 0) &&
                     (!kscale || ((uintptr_t)kscale) % 16 == 0);
   ARG_CHECK(h, g.nunits_pad < 2147483647LL);
-  ProfScope ps(h, "gemm_nt_mfma_kernel[flop]", 2.0 * M * N * (double)K);
-  if (useB) {
-    const size_t lds = sizeof(double) * 2 * (BM2 + BN) * LDT;
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nt_mfma_kernel_b<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nt_mfma_kernel_b<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    if (kscale) hipLaunchKernelGGL(gemm_nt_mfma_kernel_b<true>, dim3((unsigned)g.nunits_pad), dim3(TPB2), lds, h->stream, g);
-    else hipLaunchKernelGGL(gemm_nt_mfma_kernel_b<false>, dim3((unsigned)g.nunits_pad), dim3(TPB2), lds, h->stream, g);
-  } else if (fast) hipLaunchKernelGGL(gemm_nt_mfma_kernel<true>, dim3((unsigned)g.nunits_pad), dim3(TPB), 0, h->stream, g);
-  else hipLaunchKernelGGL(gemm_nt_mfma_kernel<false>, dim3((unsigned)g.nunits_pad), dim3(TPB), 0, h->stream, g);
-  KERNEL_CHECK(h);
+  // one profiling label per kernel instantiation, named as rocprofv3 names them
+  const char* label = useB ? (kscale ? "gemm_nt_mfma_kernel_b<true>[flop]" : "gemm_nt_mfma_kernel_b<false>[flop]")
+                           : (fast ? "gemm_nt_mfma_kernel<true>[flop]" : "gemm_nt_mfma_kernel<false>[flop]");
+  {
+    ProfScope ps(h, label, 2.0 * M * N * (double)K);
+    if (useB) {
+      const size_t lds = sizeof(double) * 2 * (BM2 + BN) * LDT;
+      static bool attr_set = false;
+      if (!attr_set) {
+        HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nt_mfma_kernel_b<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nt_mfma_kernel_b<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+      }
+      if (kscale) hipLaunchKernelGGL(gemm_nt_mfma_kernel_b<true>, dim3((unsigned)g.nunits_pad), dim3(TPB2), lds, h->stream, g);
+      else hipLaunchKernelGGL(gemm_nt_mfma_kernel_b<false>, dim3((unsigned)g.nunits_pad), dim3(TPB2), lds, h->stream, g);
+    } else if (fast) hipLaunchKernelGGL(gemm_nt_mfma_kernel<true>, dim3((unsigned)g.nunits_pad), dim3(TPB), 0, h->stream, g);
+    else hipLaunchKernelGGL(gemm_nt_mfma_kernel<false>, dim3((unsigned)g.nunits_pad), dim3(TPB), 0, h->stream, g);
+    KERNEL_CHECK(h);
+  }
   if (!g.direct) {
+    ProfScope ps(h, "gemm_reduce_slabs_kernel[byte]", 8.0 * (double)M * N * (g.nslab + 1));
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdiv((int64_t)M * N, 256)), dim3(256), 0, h->stream,
                        g.P, g.nslab, g.slab_stride, M, N, alpha, beta, C, ldc);
     KERNEL_CHECK(h);
