@@ -133,8 +133,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        # production: one rank per GPU over RCCL.  ISDF_ONE_GPU=1 ISDF_DIST_BACKEND=gloo rehearses the N > 1 code
+        # path with all ranks on device 0 (tools/rehearse_ranks_one_gpu.sh) - never a benchmark number.
+        torch.cuda.set_device(0 if os.environ.get('ISDF_ONE_GPU') else local_rank)
+        dist.init_process_group(os.environ.get('ISDF_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
     comm = Comm.from_env()
 
     cell = workloads.make_cell(args.workload)
@@ -243,6 +245,8 @@ def main():
                           'EK': float(np.einsum('kij,kji', vk, dm).real / 4 / len(kpts))}),
             'roofline': roof,
         }
+        if os.environ.get('ISDF_ONE_GPU'):
+            out['data'] = 'synthetic; REHEARSAL: %d ranks on one GPU over gloo, not a benchmark' % world
         if world == 1 and not args.no_cpu_baseline and kpts is None:
             ncores = os.cpu_count() or 1
             val, sample = cpu_baseline(cell, args.c_isdf, dict(P=P))

@@ -11,6 +11,7 @@ pyscf/pbc/df/df_jk.py:1411-1444: the result has the shape of ``dm``; Γ point + 
 What runs where: this file is host orchestration only (which stage, which buffers, which rank);
 every stage executes in libmi355_isdf.so via ``backend.HipBackend``.  There is no CPU path.
 """
+import os
 import sys
 import time
 import warnings
@@ -83,6 +84,7 @@ class ISDF:
                                          # max|dK|/|K| of the two routes within a factor of a few, profiles/r01_bj_*)
         self.bj_max_c = 12               # 'auto': do not even try S3c above this c_isdf (cond(A') grows ~100x per +5)
         self.bj_nprobe = 8
+        self.bj_group = 1                # S3c preconditioner blocks = point sets of this many consecutive atoms
         self.bj_check = None             # the measured mismatch of the last 'auto' build
         self.fit_route_used = None
         self.block_shift = 0.0           # relative diagonal shift of the per-atom blocks in the S3c route
@@ -118,6 +120,8 @@ class ISDF:
             dev = 0
             if self._comm is not None:
                 dev = self._comm.local_rank
+            if os.environ.get('ISDF_ONE_GPU'):           # rehearsal: several ranks share device 0
+                dev = 0
             self._backend = HipBackend(dev)
         return self._backend
 
@@ -204,6 +208,14 @@ class ISDF:
         be.block_solve(Dblk, ip_off, 1, 0, W)
         if symmetric:
             be.symmetrize_mean(W)         # the rounding noise along null(A) is not symmetric; the mean keeps it in null(A)
+
+    def _bj_blocks(self, counts):
+        """Offsets of the preconditioner blocks: the per-atom point counts, bj_group consecutive atoms merged."""
+        off = np.append(0, np.cumsum(counts)).astype(np.int32)
+        g = max(1, int(self.bj_group))
+        if g > 1:
+            off = np.unique(np.append(off[::g], off[-1])).astype(np.int32)
+        return off
 
     def _fit_routes(self):
         if self.fit_route not in ('auto', 'blockjacobi', 'cholesky'):
@@ -358,7 +370,7 @@ class ISDF:
             for route in self._fit_routes():
                 if route == 'blockjacobi':
                     # S3c: no triangular solve over the grid.  theta <- Y' = D^-1 (aoP ao)^2
-                    ip_off = np.append(0, np.cumsum(rank)).astype(np.int32)
+                    ip_off = self._bj_blocks(rank)
                     Afac, Dblk = self._bj_prepare(self.ao, 0, d_ip, ip_off, self.aoP, scratch=self.W)
                     self._bj_rows(self.aoP, 0, self.ao, G, Dblk, ip_off, theta)
                 else:
@@ -582,7 +594,7 @@ class ISDF:
         self.aoP = self._buffer('aoP', (P, nao))
         theta = self._buffer('theta', (P, ng))
         ar = be.to_device(np.arange(P, dtype=np.int64))
-        ip_off = np.append(0, np.cumsum([len(merged[b]) for b in sorted(merged)])).astype(np.int32)
+        ip_off = self._bj_blocks([len(merged[b]) for b in sorted(merged)])
         for route in self._fit_routes():
             if route == 'blockjacobi':
                 Afac, Dblk = self._bj_prepare(aoP_T, 0, ar, ip_off, self.aoP, scratch=self._buffer('W', (P, P)))
@@ -751,7 +763,7 @@ class ISDF:
         use_bj = self.fit_route == 'blockjacobi' and not self.explicit_theta and self.select != 'global'
         self.fit_route_used = 'blockjacobi' if use_bj else 'cholesky'
         if use_bj:
-            ip_off = np.append(0, np.cumsum(rank)).astype(np.int32)
+            ip_off = self._bj_blocks(rank)
             Afac, Dblk = self._bj_prepare(X, nh, ip_dev, ip_off, aoP_X)
             self._bj_rows(aoP_X, nh, X, G, Dblk, ip_off, Y)
         else:

@@ -23,9 +23,19 @@ class Comm:
         lo = r * base + min(r, rem)
         return lo, lo + base + (1 if r < rem else 0)
 
+    def _staged(self, t):
+        """gloo moves host memory: device tensors are staged through the host (rehearsals of the N > 1 path with
+        several ranks on ONE GPU, tools/rehearse_ranks_one_gpu.sh; the production backend is nccl = RCCL)."""
+        return self.size > 1 and t.is_cuda and dist.get_backend(self.group) == 'gloo'
+
     def all_reduce_sum(self, t):
         if self.size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self._staged(t):
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def all_gather_rows(self, t_local, counts):
@@ -35,8 +45,14 @@ class Comm:
         mx = max(counts)
         pad = torch.zeros((mx,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
         pad[:t_local.shape[0]] = t_local
-        bufs = [torch.empty_like(pad) for _ in range(self.size)]
-        dist.all_gather(bufs, pad, group=self.group)
+        if self._staged(pad):
+            hp = pad.cpu()
+            hb = [torch.empty_like(hp) for _ in range(self.size)]
+            dist.all_gather(hb, hp, group=self.group)
+            bufs = [b.to(pad.device) for b in hb]
+        else:
+            bufs = [torch.empty_like(pad) for _ in range(self.size)]
+            dist.all_gather(bufs, pad, group=self.group)
         return torch.cat([bufs[r][:counts[r]] for r in range(self.size)], dim=0)
 
     def all_gather_object(self, obj):
@@ -55,14 +71,22 @@ class Comm:
         if dist.get_backend(self.group) == 'gloo':
             # gloo has no all_to_all: pairwise exchange (CPU tests only)
             reqs = []
+            staged = {}
             for q in range(self.size):
                 if q == self.rank:
                     recv[q].copy_(send[q])
                 else:
-                    reqs.append(dist.isend(send[q], q, group=self.group))
-                    reqs.append(dist.irecv(recv[q], q, group=self.group))
+                    sq, rq = send[q], recv[q]
+                    if rq.is_cuda:
+                        sq = sq.cpu()
+                        staged[q] = torch.empty(rq.shape, dtype=rq.dtype)
+                        rq = staged[q]
+                    reqs.append(dist.isend(sq, q, group=self.group))
+                    reqs.append(dist.irecv(rq, q, group=self.group))
             for r in reqs:
                 r.wait()
+            for q, h in staged.items():
+                recv[q].copy_(h)
         else:
             dist.all_to_all(recv, send, group=self.group)
 

@@ -8,6 +8,7 @@ from pyscf_isdf_amd.isdf import ISDF
 
 name = sys.argv[1] if len(sys.argv) > 1 else 'diamond-222-dzvp-80'
 cs = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [10]
+group = int(os.environ.get('BJ_GROUP', '1'))
 cell = workloads.make_cell(name)
 dm, c, occ = workloads.make_dm(cell)
 for c_isdf in cs:
@@ -16,6 +17,7 @@ for c_isdf in cs:
         df = ISDF(cell, c_isdf=c_isdf, select='local')
         df.fit_route = route if route == 'cholesky' else 'auto'
         df.bj_check_tol = 1e99
+        df.bj_group = group
         t0 = time.perf_counter()
         vk[route] = df.get_jk(dm, with_j=False)[1]
         t1 = time.perf_counter()
@@ -31,7 +33,7 @@ for c_isdf in cs:
             # per-atom block offsets: points are stored atom by atom
             from pyscf_isdf_amd.isdf import partition_grid_by_atom
             owner = partition_grid_by_atom(df.grids.coords[df.ip], cell.atom_coords(), cell.lattice_vectors())
-            ip_off = np.append(0, np.cumsum(np.bincount(owner, minlength=cell.natm))).astype(np.int32)
+            ip_off = df._bj_blocks(np.bincount(owner, minlength=cell.natm))
             be.block_solve(D, ip_off, 0, 0, A); be.block_solve(D, ip_off, 1, 1, A)
             A = (A + A.T) / 2
             w = torch.linalg.eigvalsh(A)
