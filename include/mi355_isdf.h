@@ -162,7 +162,9 @@ int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, 
  *   isdf_gram_sq         d_A (P, P) = (aoP aoP^T)^2
  *   isdf_pair_gram_rows  d_B (P, ldb) = (aoP ao)^2 on ng grid columns
  *   isdf_block_chol      d_D (P, P): zero except the diagonal blocks, which hold the row-major lower Cholesky
- *                        factors D_b of A_bb + shift_rel*max(diag A)*I
+ *                        factors D_b of A_bb + shift*max(diag A)*I; shift = shift_rel, raised per block (1e-14, x100 per
+ *                        retry) when the block is not numerically positive definite - D is only a preconditioner;
+ *                        *shift_used = the largest shift any block needed
  *   isdf_block_solve     side 0: X (P, n) <- op(D)^-1 X;  side 1: X (n, P) <- X op(D)^-1;  op = D (trans 0) | D^T (trans 1)
  *   isdf_chol_inplace    d_A <- Cholesky factor (same storage convention and the same shift ladder as
  *                        isdf_fit_prepare's d_chol; *reg_used = the relative shift that succeeded; d_scratch:
@@ -174,7 +176,7 @@ int isdf_gram_sq(isdf_handle h, const double* d_aoP, int P, int nao, int nh, dou
 int isdf_pair_gram_rows(isdf_handle h, const double* d_aoP, int P, int nao, int nh, const double* d_ao,
                         int64_t ng, int64_t ld, double* d_B, int64_t ldb);
 int isdf_block_chol(isdf_handle h, const double* d_A, int P, int nblk, const int32_t* blk_off,
-                    double shift_rel, double* d_D);
+                    double shift_rel, double* d_D, double* shift_used);
 int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nblk, const int32_t* blk_off, int side,
                      int trans, double* d_X, int64_t n, int64_t ldx);
 int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel, double* d_scratch, double* reg_used);

@@ -154,8 +154,10 @@ class HipBackend:
     def block_chol(self, A, blk_off, shift_rel, D):
         self._stream()
         blk_off = np.ascontiguousarray(blk_off, dtype=np.int32)
+        used = ctypes.c_double(0.0)
         self.handle.call('isdf_block_chol', self._p(A), A.shape[0], len(blk_off) - 1, _np_ptr(blk_off), float(shift_rel),
-                         self._p(D))
+                         self._p(D), ctypes.byref(used))
+        return used.value
 
     def block_solve(self, D, blk_off, side, trans, X):
         """side 0: X (P, n) <- op(D)^-1 X; side 1: X (n, P) <- X op(D)^-1."""

@@ -359,7 +359,7 @@ __global__ void add_diag_const_kernel(double* __restrict__ A, int n, int64_t ld,
 }  // namespace
 
 extern "C" int isdf_block_chol(isdf_handle h, const double* d_A, int P, int nblk, const int32_t* blk_off,
-                               double shift_rel, double* d_D) {
+                               double shift_rel, double* d_D, double* shift_used) {
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_A && d_D && blk_off && P > 0 && nblk > 0 && blk_off[0] == 0 && blk_off[nblk] == P && shift_rel >= 0);
   int* info = (int*)isdf_ws(h, "fit_info", 256);
@@ -367,34 +367,38 @@ extern "C" int isdf_block_chol(isdf_handle h, const double* d_A, int P, int nblk
   double* maxdiag = (double*)(info + 16);
   HIP_TRY(h, hipMemsetAsync(d_D, 0, sizeof(double) * (size_t)P * P, h->stream));
   hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, h->stream, d_A, P, maxdiag);
+  double md = 0.0;
+  HIP_TRY(h, hipMemcpyAsync(&md, maxdiag, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  double worst = 0.0;
   for (int b = 0; b < nblk; ++b) {
     const int off = blk_off[b], nb = blk_off[b + 1] - off;
     if (nb <= 0) continue;
     ARG_CHECK(h, nb <= 65535);
-    hipLaunchKernelGGL(copy_block_kernel, dim3((unsigned)cdiv(nb, 128), (unsigned)nb), dim3(128), 0, h->stream, d_A, P, off,
-                       nb, d_D);
-    KERNEL_CHECK(h);
-  }
-  // the shift needs the strided diagonal of each block: do it for the whole D diagonal at once
-  if (shift_rel > 0) {
-    double md = 0.0;
-    HIP_TRY(h, hipMemcpyAsync(&md, maxdiag, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    hipLaunchKernelGGL(add_diag_const_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, h->stream, d_D, P, (int64_t)P,
-                       shift_rel * md);
-    KERNEL_CHECK(h);
-  }
-  for (int b = 0; b < nblk; ++b) {
-    const int off = blk_off[b], nb = blk_off[b + 1] - off;
-    if (nb <= 0) continue;
-    // column-major upper factor of the block == row-major lower D_b (A_bb = D_b D_b^T)
-    BLAS_TRY(h, rocsolver_dpotrf(h->blas, rocblas_fill_upper, nb, d_D + (int64_t)off * P + off, P, info));
-    int h_info = 0;
-    HIP_TRY(h, hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // D is only a preconditioner: any invertible block works as long as the same D is used throughout, so a block
+    // that is not numerically positive definite (its points were selected on slightly different AO values, or the
+    // set is over-complete) simply gets a larger diagonal shift: shift_rel, then 1e-14, x100 per retry
+    double reg = shift_rel;
+    int h_info = 1;
+    for (int attempt = 0; attempt < 6 && h_info != 0; ++attempt) {
+      hipLaunchKernelGGL(copy_block_kernel, dim3((unsigned)cdiv(nb, 128), (unsigned)nb), dim3(128), 0, h->stream, d_A, P,
+                         off, nb, d_D);
+      if (reg > 0)
+        hipLaunchKernelGGL(add_diag_const_kernel, dim3((unsigned)cdiv(nb, 256)), dim3(256), 0, h->stream,
+                           d_D + (int64_t)off * P + off, nb, (int64_t)P, reg * md);
+      KERNEL_CHECK(h);
+      // column-major upper factor of the block == row-major lower D_b (A_bb = D_b D_b^T)
+      BLAS_TRY(h, rocsolver_dpotrf(h->blas, rocblas_fill_upper, nb, d_D + (int64_t)off * P + off, P, info));
+      HIP_TRY(h, hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      if (h_info == 0) { worst = std::max(worst, reg); break; }
+      reg = (reg > 0.0) ? reg * 100.0 : 1e-14;
+    }
     if (h_info != 0)
-      return isdf_fail(h, ISDF_ERR_NUM, "diagonal block %d of A_PP is not positive definite (minor %d of %d)", b, h_info, nb);
+      return isdf_fail(h, ISDF_ERR_NUM, "diagonal block %d of A_PP is not positive definite even with shift %g * max diag "
+                       "(minor %d of %d)", b, reg / 100.0, h_info, nb);
   }
+  if (shift_used) *shift_used = worst;
   return ISDF_OK;
 }
 

@@ -87,7 +87,9 @@ class ISDF:
         self.bj_group = 1                # S3c preconditioner blocks = point sets of this many consecutive atoms
         self.bj_check = None             # the measured mismatch of the last 'auto' build
         self.fit_route_used = None
-        self.block_shift = 0.0           # relative diagonal shift of the per-atom blocks in the S3c route
+        self.block_shift = 0.0           # relative diagonal shift of the per-atom blocks in the S3c route (raised per
+                                         # block when a block is not positive definite: D is only a preconditioner)
+        self.block_shift_used = 0.0
         self.explicit_theta = False      # True: form Theta itself (second O(P^2 G) solve); same W in exact arithmetic
         self.fft_batch = None             # rows per FFT batch (None: sized from free memory)
         self._backend = backend
@@ -187,7 +189,7 @@ class ISDF:
         A = self._buffer('factor', (P, P))
         be.gram_sq(aoP, A, nh)
         Dblk = self._buffer('Dblk', (P, P))
-        be.block_chol(A, ip_off, self.block_shift, Dblk)
+        self.block_shift_used = be.block_chol(A, ip_off, self.block_shift, Dblk)
         be.block_solve(Dblk, ip_off, 0, 0, A)            # A' = D^-1 A D^-T
         be.block_solve(Dblk, ip_off, 1, 1, A)
         self.reg_used = be.chol_inplace(A, self.reg_rel, scratch=scratch)
@@ -588,20 +590,45 @@ class ISDF:
         P = len(self.ip)
         t0 = self._tick('S2_select_ip', t0)
 
-        # S3: phi at the points (tiny collocation, replicated), P x P factorisations replicated, rows on the slice
-        aoP_T = be.empty((nao, P))
-        be.eval_ao(*ao_args, be.to_device(np.ascontiguousarray(coords[self.ip].T)), aoP_T)
+        # S3: phi at the points = columns of the slice collocations (every point lies in exactly one slice; zero-padded
+        # all_reduce of 8 P N bytes).  Taking them from the SAME evaluation as the fit's right-hand sides keeps
+        # B[:, ip] == A_PP to the last bit (a separate collocation differs by the image-screening tolerance, which
+        # the fit amplifies by cond(A)).  P x P factorisations replicated, rows of the fit on the slice.
+        aoP_T = be.zeros((nao, P))
+        mine_p = np.nonzero((self.ip >= g0) & (self.ip < g1))[0]
+        if len(mine_p):
+            loc = be.empty((nao, len(mine_p)))
+            be.gather_cols(self.ao, be.to_device(self.ip[mine_p] - g0), loc)
+            aoP_T[:, be.to_device(mine_p)] = loc
+            del loc
+        comm.all_reduce_sum(aoP_T)
         self.aoP = self._buffer('aoP', (P, nao))
         theta = self._buffer('theta', (P, ng))
         ar = be.to_device(np.arange(P, dtype=np.int64))
         ip_off = self._bj_blocks([len(merged[b]) for b in sorted(merged)])
         for route in self._fit_routes():
+            # the P x P factorisations run on rank 0 and are broadcast (2 x 8 P^2 bytes): every rank then holds the
+            # same bits, and the shift ladders' decisions cannot diverge between ranks
             if route == 'blockjacobi':
-                Afac, Dblk = self._bj_prepare(aoP_T, 0, ar, ip_off, self.aoP, scratch=self._buffer('W', (P, P)))
+                Afac = self._buffer('factor', (P, P))
+                Dblk = self._buffer('Dblk', (P, P))
+                def root_factorise():
+                    self._bj_prepare(aoP_T, 0, ar, ip_off, self.aoP, scratch=self._buffer('W', (P, P)))
+                    return self.reg_used
+                reg = comm.run_on_root(root_factorise)
+                if comm.rank != 0:
+                    be.gather_aoP(aoP_T, ar, self.aoP)
+                comm.broadcast(Afac)
+                comm.broadcast(Dblk)
+                self.reg_used = comm.agree_max(reg or 0.0)
                 self._bj_rows(self.aoP, 0, self.ao, ng, Dblk, ip_off, theta)
             else:
                 chol = self._buffer('factor', (P, P))
-                self.reg_used = be.fit_prepare(aoP_T, ar, self.reg_rel, self.aoP, chol)
+                reg = comm.run_on_root(lambda: be.fit_prepare(aoP_T, ar, self.reg_rel, self.aoP, chol))
+                if comm.rank != 0:
+                    be.gather_aoP(aoP_T, ar, self.aoP)
+                comm.broadcast(chol)
+                self.reg_used = comm.agree_max(reg or 0.0)
                 be.fit_apply(chol, self.aoP, self.ao, ng, theta, forward_only=not self.explicit_theta)
             t0 = self._tick('S3_fit', t0)
 
@@ -648,8 +675,8 @@ class ISDF:
             t0 = self._tick('S4S5_coulomb_W', t0)
             self.fit_route_used = route
             if route == 'blockjacobi' and self.fit_route == 'auto':
-                # every rank computes the same number (replicated W, all-reduced probe energies): same decision
-                self.bj_check = self._bj_probe_mismatch(aoP_T, Afac, Dblk, ip_off, theta, ng, (g0, g1))
+                # replicated W, all-reduced probe energies; the max over ranks makes the decision identical everywhere
+                self.bj_check = comm.agree_max(self._bj_probe_mismatch(aoP_T, Afac, Dblk, ip_off, theta, ng, (g0, g1)))
                 t0 = self._tick('S5_route_check', t0)
                 if self.bj_check <= self.bj_check_tol:
                     break

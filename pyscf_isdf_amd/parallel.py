@@ -38,6 +38,42 @@ class Comm:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def broadcast(self, t, src=0):
+        """Every rank ends with rank src's tensor."""
+        if self.size > 1:
+            if self._staged(t):
+                h = t.cpu()
+                dist.broadcast(h, src, group=self.group)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src, group=self.group)
+        return t
+
+    def agree_max(self, x):
+        """max over the ranks of a host float: decisions taken on replicated data must not diverge in the last bit."""
+        if self.size == 1:
+            return float(x)
+        h = torch.tensor([float(x)], dtype=torch.float64)
+        if dist.get_backend(self.group) != 'gloo':
+            h = h.cuda()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+        return float(h.item())
+
+    def run_on_root(self, fn):
+        """fn() on rank 0 only; a failure there is raised on EVERY rank (nobody is left waiting in a collective).
+        Returns fn()'s value on rank 0, None elsewhere."""
+        out, err = None, None
+        if self.rank == 0:
+            try:
+                out = fn()
+            except Exception as e:                      # noqa: BLE001 - re-raised below on every rank
+                err = e
+        if self.agree_max(0.0 if err is None else 1.0) > 0.0:
+            if err is not None:
+                raise err
+            raise RuntimeError('rank 0 failed in a root-only stage (see its traceback)')
+        return out
+
     def all_gather_rows(self, t_local, counts):
         """Concatenate row blocks of unequal height (counts[r] rows from rank r)."""
         if self.size == 1:

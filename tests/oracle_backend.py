@@ -101,11 +101,23 @@ class OracleBackend:
     def block_chol(self, A, blk_off, shift_rel, D):
         a = A.numpy()
         d = np.zeros_like(a)
+        worst = 0.0
         for b in range(len(blk_off) - 1):
             s = slice(blk_off[b], blk_off[b + 1])
-            if s.stop > s.start:
-                d[s, s] = np.linalg.cholesky(a[s, s] + shift_rel * a.diagonal().max() * np.eye(s.stop - s.start))
+            if s.stop == s.start:
+                continue
+            reg = shift_rel
+            for attempt in range(6):
+                try:
+                    d[s, s] = np.linalg.cholesky(a[s, s] + reg * a.diagonal().max() * np.eye(s.stop - s.start))
+                    worst = max(worst, reg)
+                    break
+                except np.linalg.LinAlgError:
+                    reg = reg * 100.0 if reg > 0 else 1e-14
+            else:
+                raise np.linalg.LinAlgError('block %d not positive definite' % b)
         D.copy_(torch.from_numpy(d))
+        return worst
 
     def block_solve(self, D, blk_off, side, trans, X):
         d, x = D.numpy(), X.numpy()

@@ -508,6 +508,26 @@ def test_symmetrize_mean_and_probe_rows(be):
     assert abs(be.to_host(dF) - E.dot(Y)).max() < 1e-11 * abs(E.dot(Y)).max()
 
 
+def test_block_chol_shifts_a_block_that_is_not_positive_definite(be):
+    """D is only a preconditioner: a numerically indefinite diagonal block gets a larger shift instead of an error."""
+    rng = np.random.default_rng(8)
+    P = 24
+    off = np.array([0, 10, 24], dtype=np.int32)
+    Z = rng.standard_normal((P, 40))
+    A = Z.dot(Z.T)
+    A[:10, :10] -= (np.linalg.eigvalsh(A[:10, :10])[0] + 1e-9 * A.diagonal().max()) * np.eye(10)   # smallest eigenvalue < 0
+    assert np.linalg.eigvalsh(A[:10, :10])[0] < 0 < np.linalg.eigvalsh(A[10:, 10:])[0]
+    D = be.empty((P, P))
+    used = be.block_chol(be.to_device(A), off, 0.0, D)
+    assert 1e-14 <= used <= 1e-4
+    Dh = be.to_host(D)
+    L0 = np.tril(Dh[:10, :10]); L1 = np.tril(Dh[10:, 10:])
+    md = A.diagonal().max()
+    assert abs(L0.dot(L0.T) - (A[:10, :10] + used * md * np.eye(10))).max() < 1e-10 * md
+    assert abs(L1.dot(L1.T) - A[10:, 10:]).max() < 1e-12 * md                    # the healthy block is not shifted
+    assert abs(Dh[:10, 10:]).max() == 0 and abs(Dh[10:, :10]).max() == 0
+
+
 def test_block_jacobi_route_building_blocks(be):
     """S3c primitives vs numpy on a random SPD problem with unequal blocks, and the assembled W vs the oracle."""
     rng = np.random.default_rng(12)

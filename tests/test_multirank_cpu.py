@@ -136,3 +136,51 @@ def test_split_range_covers_everything():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(size - 1))
             assert max(hi - lo for lo, hi in parts) - min(hi - lo for lo, hi in parts) <= 1
+
+
+def _root_fail_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _setup_path()
+    from pyscf_isdf_amd.parallel import Comm
+    comm = Comm.from_env()
+    out = []
+    out.append(comm.run_on_root(lambda: 42))                       # value on rank 0, None elsewhere
+
+    def boom():
+        raise ValueError('root-only stage failed')
+    try:
+        comm.run_on_root(boom)
+        out.append('no error')
+    except ValueError as e:
+        out.append('ValueError: %s' % e)
+    except RuntimeError as e:
+        out.append('RuntimeError: %s' % e)
+    t = torch.full((3,), float(rank + 1), dtype=torch.float64)
+    comm.broadcast(t, 0)
+    out.append(t.tolist())
+    out.append(comm.agree_max(0.5 + rank))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_root_only_stage_failure_reaches_every_rank():
+    """A root-only stage (the P x P factorisations of the sharded build) that fails must fail on every rank instead of
+    leaving the others in the next collective; broadcast and agree_max give every rank the root's bits / one decision."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_root_fail_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == 42 and res[1][0] is None
+    assert res[0][1].startswith('ValueError') and res[1][1].startswith('RuntimeError')
+    assert res[0][2] == res[1][2] == [1.0, 1.0, 1.0]
+    assert res[0][3] == res[1][3] == 1.5
