@@ -55,7 +55,7 @@ class Comm:
             return float(x)
         h = torch.tensor([float(x)], dtype=torch.float64)
         if dist.get_backend(self.group) != 'gloo':
-            h = h.cuda()
+            h = h.to(torch.device('cuda', self.local_rank))
         dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
         return float(h.item())
 
