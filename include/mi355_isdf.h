@@ -181,6 +181,10 @@ int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nblk, const in
                      int trans, double* d_X, int64_t n, int64_t ldx);
 int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel, double* d_scratch, double* reg_used);
 
+/* d_X (P, n) row-major, ldx >= n  <-  A^-1 X, A = U^T U the factor of isdf_fit_prepare / isdf_chol_inplace.  Column blocks are
+ * independent: the grid-sharded build gives every rank n = P/R columns of the P x P finishing solves. */
+int isdf_factor_solve(isdf_handle h, const double* d_fac, int P, double* d_X, int64_t n, int64_t ldx);
+
 /* A-posteriori check of the block-Jacobi route (it amplifies rounding in M' by cond(A')):
  * for probe vectors t_j (rows of d_T, values of a density at the points) the fitted density Theta^T t_j on ng grid
  * columns,   d_T (n, P) <- e_j = A'^-1 D^-1 t_j  (in place),   d_F (n, ldf) <- E Y'.

@@ -175,6 +175,11 @@ class HipBackend:
                          self._p(scratch) if scratch is not None else None, ctypes.byref(reg))
         return reg.value
 
+    def factor_solve(self, fac, X):
+        """X (P, n) <- A^-1 X, A = U^T U (fac as stored by fit_prepare / chol_inplace)."""
+        self._stream()
+        self.handle.call('isdf_factor_solve', self._p(fac), fac.shape[0], self._p(X), X.shape[1], X.stride(0))
+
     def bj_probe_rows(self, T, fac, D, blk_off, Yp, ng, F):
         """T (n, P) <- A'^-1 D^-1 t_j in place; F (n, ng) <- T Yp."""
         self._stream()

@@ -469,6 +469,20 @@ extern "C" int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift
                    reg / 100.0);
 }
 
+extern "C" int isdf_factor_solve(isdf_handle h, const double* d_fac, int P, double* d_X, int64_t n, int64_t ldx) {
+  // X (P, n) row-major <- A^-1 X with A = U^T U (d_fac as stored by isdf_fit_prepare / isdf_chol_inplace).
+  // Column-major view X_cm (n x P, ld = ldx): X_cm <- X_cm U^-1 U^-T.
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_fac && d_X && P > 0 && n > 0 && ldx >= n && n < 2147483647LL && ldx < 2147483647LL);
+  const double one = 1.0;
+  ProfScope ps(h, "rocblas_dtrsm[flop]", 2.0 * (double)P * P * (double)n, 2);
+  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
+                            rocblas_diagonal_non_unit, (rocblas_int)n, P, &one, d_fac, P, d_X, (rocblas_int)ldx));
+  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_transpose,
+                            rocblas_diagonal_non_unit, (rocblas_int)n, P, &one, d_fac, P, d_X, (rocblas_int)ldx));
+  return ISDF_OK;
+}
+
 extern "C" int isdf_bj_probe_rows(isdf_handle h, double* d_T, int n, const double* d_fac, const double* d_D, int P,
                                   int nblk, const int32_t* blk_off, const double* d_Yp, int64_t ng, int64_t ldy,
                                   double* d_F, int64_t ldf) {

@@ -40,6 +40,7 @@ SIGNATURES = {
     'isdf_block_chol': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_dbl, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_block_solve': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_i64, c_i64]),
     'isdf_chol_inplace': (c_int, [c_vp, c_vp, c_int, c_dbl, c_vp, ctypes.POINTER(c_dbl)]),
+    'isdf_factor_solve': (c_int, [c_vp, c_vp, c_int, c_vp, c_i64, c_i64]),
     'isdf_bj_probe_rows': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64]),
     'isdf_gather_T': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),
     'isdf_W_from_factor': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64]),

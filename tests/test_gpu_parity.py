@@ -506,6 +506,13 @@ def test_symmetrize_mean_and_probe_rows(be):
     E = np.linalg.solve(Ap, np.linalg.solve(Dh, T.T)).T
     assert abs(be.to_host(dT) - E).max() < 1e-11 * abs(E).max()
     assert abs(be.to_host(dF) - E.dot(Y)).max() < 1e-11 * abs(E.dot(Y)).max()
+    # factor_solve on a column block with a row stride (the sharded finishing solves)
+    X = rng.standard_normal((P, 11))
+    big = be.to_device(np.hstack([X, np.zeros((P, 3))]))
+    view = big[:, :11]
+    be.factor_solve(dA, view)
+    assert abs(be.to_host(big)[:, :11] - np.linalg.solve(Ap, X)).max() < 1e-11 * abs(X).max()
+    assert abs(be.to_host(big)[:, 11:]).max() == 0
 
 
 def test_block_chol_shifts_a_block_that_is_not_positive_definite(be):
