@@ -83,7 +83,7 @@ def cpu_baseline(cell, c_isdf, gpu_stage_sizes):
     n3 = min(G, 1024)
     t = time.perf_counter()
     B = aoP.dot(aoT_s[:, :n3]) ** 2
-    theta_s = scipy.linalg.cho_solve(cf, B)
+    scipy.linalg.cho_solve(cf, B)
     est['S3_fit'] = t_chol + (time.perf_counter() - t) * G / n3
     del A, cf
     # S4 Coulomb convolution of a few full-grid rows; S5 W rows
@@ -142,7 +142,7 @@ def main():
     cell = workloads.make_cell(args.workload)
     kpts = workloads.make_kpts(args.workload, cell)
     if kpts is None:
-        dm, mo_coeff, mo_occ = workloads.make_dm(cell)
+        dm = workloads.make_dm(cell)[0]
         df = ISDF(cell, c_isdf=args.c_isdf, select=args.select, comm=comm)
     else:
         # k-point workload (configs[3]): Hermitian D^k = C^k occ C^k^H with random unitary C^k

@@ -523,7 +523,6 @@ class ISDF:
         if max_rows is None:
             max_rows = max(nocc, int((4 << 30) // (8 * G)) // nocc * nocc)
         vk = be.empty((nao, nao))
-        lo, hi = self.comm.split_range(nao)
         if self.comm.size > 1 or self.force_sharded:
             raise NotImplementedError('get_k_exact is a single-GPU verification path')
         be.get_k_exact(self.ao, G, be.to_device(np.ascontiguousarray(c)), mesh, a, 0, nao, max_rows, vk)
@@ -920,7 +919,6 @@ class ISDF:
             t0 = self._tick('S6_get_j', t0)
             vj = vj.reshape(dm_in.shape)
         if with_k:
-            P = len(self.ip)
             d_vk = be.zeros((nset, nk, nao, nao), dtype=torch.complex128)
             for s in range(nset):
                 d_dm = [be.to_device(np.ascontiguousarray(dms[s, k])) for k in range(nk)]

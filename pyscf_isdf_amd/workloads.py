@@ -14,6 +14,8 @@ WORKLOADS = {
                             'intermediate: diamond 3x3x3, gth-dzvp, 96^3'),
     'water64-dzvp-160': (lambda: water64('gth-dzvp', (160, 160, 160)),
                          'configs[4]: 64 H2O box, gth-dzvp, 160^3 (needs >= 4 GPUs: Theta is 482 GB)'),
+    'water64-dzvp-108': (lambda: water64('gth-dzvp', (108, 108, 108)),
+                         'reduced configs[4]: 64 H2O box, gth-dzvp, 108^3 (fits one GPU: the fit rows take 148 GB)'),
     'mgo-333-dzvp-k222': (lambda: mgo_supercell(3, 'gth-dzvp', (96, 96, 96)),
                           'configs[3]: MgO 3x3x3, gth-dzvp, 96^3, 2x2x2 k-mesh'),
     'mgo-222-dzvp-k222': (lambda: mgo_supercell(2, 'gth-dzvp', (64, 64, 64)),

@@ -26,7 +26,6 @@ for c_isdf in cs:
         if route == 'blockjacobi' and '--eig' in sys.argv:
             be = df.backend
             P = len(df.ip)
-            rank = np.bincount(workloads.np.zeros(1, dtype=int)) if False else None
             A = be.empty((P, P)); be.gram_sq(df.aoP, A)
             wA = torch.linalg.eigvalsh(A)
             D = df._buffer('Dblk', (P, P))
