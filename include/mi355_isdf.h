@@ -155,7 +155,8 @@ int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, 
 
 /* S3c. Block-Jacobi route — no triangular solve over the grid.  With A = A_PP, B = A_P and
  * D = blockdiag(chol(A_bb)) over the per-atom blocks of points [blk_off[b], blk_off[b+1]):
- *   Y' = D^-1 B,  M' = w conv(Y') Y'^T (isdf_coulomb_W),  A' = D^-1 A D^-T,
+ *   Y' = D^-1 B,  M' = w conv(Y') Y'^T (isdf_coulomb_W),  A' = D^-1 A D^-T   (A already carries the fit's diagonal shift,
+ *   isdf_shift_diag, so that S3b and S3c solve the same regularised normal equations),
  *   W  = D^-T [A'^-1 M' A'^-1] D^-1     ( = A^-1 [w conv(B) B^T] A^-1, the same W as S3a/S3b ).
  * Building blocks (nh > 0 selects the complex k-point mode of the Gram products):
  *   isdf_gather_aoP      d_aoP (P, nao) = ao[:, ip]^T
@@ -179,6 +180,8 @@ int isdf_block_chol(isdf_handle h, const double* d_A, int P, int nblk, const int
                     double shift_rel, double* d_D, double* shift_used);
 int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nblk, const int32_t* blk_off, int side,
                      int trans, double* d_X, int64_t n, int64_t ldx);
+/* d_A <- d_A + shift_rel * max(diag d_A) * I. */
+int isdf_shift_diag(isdf_handle h, double* d_A, int P, double shift_rel);
 int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel, double* d_scratch, double* reg_used);
 
 /* d_X (P, n) row-major, ldx >= n  <-  A^-1 X, A = U^T U the factor of isdf_fit_prepare / isdf_chol_inplace.  Column blocks are
@@ -221,9 +224,9 @@ int isdf_coulomb_rows(isdf_handle h, const double* d_in, int nrows, int64_t ld,
                       const int32_t mesh[3], const double a[9], int batch, double* d_out, int64_t ldo);
 /* W[q][p] = W[p][q] for q > p. */
 int isdf_symmetrize_upper(isdf_handle h, double* d_W, int P, int64_t ldw);
-/* W <- (W + W^T) / 2 (after the two-sided solves of the block-Jacobi route, whose rounding along null(A_PP) is not
+/* W <- (W + W^T) / 2, or (W - W^T) / 2 with antisymmetric != 0 (the imaginary plane of a Hermitian W^q) (after the two-sided solves of the block-Jacobi route, whose rounding along null(A_PP) is not
  * symmetric; the mean keeps that noise inside null(A_PP) x null(A_PP), mirroring one triangle would not). */
-int isdf_symmetrize_mean(isdf_handle h, double* d_W, int P, int64_t ldw);
+int isdf_symmetrize_mean(isdf_handle h, double* d_W, int P, int64_t ldw, int antisymmetric);
 
 /* S6. J exactly as pyscf/pbc/df/fft_jk.py:63-107 (Γ, real dm):
  *   rho = sum_mn dm_mn ao_m ao_n;  v = (vol/G) ifft(coulG fft rho).real;  vj = ao (v .* ao)^T.

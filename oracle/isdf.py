@@ -195,10 +195,11 @@ def build_local_select_global_fit(aoT, a, mesh, owner, nip_per_block, reg_rel=1e
 
 def build_W_blockjacobi(aoT, ip, blk_off, a, mesh, reg_rel=1e-12, block_shift=0.0):
     """W without any triangular solve over the grid (include/mi355_isdf.h S3c):
-    D = blockdiag(chol(A_bb)), Y' = D^-1 B, M' = w conv(Y') Y'^T, A' = D^-1 A D^-T (+ reg),
-    W = D^-T [A'^-1 M' A'^-1] D^-1."""
+    A <- A + reg (the fit's regularisation, as in the Cholesky route), D = blockdiag(chol(A_bb)), Y' = D^-1 B,
+    M' = w conv(Y') Y'^T, A' = D^-1 A D^-T, W = D^-T [A'^-1 M' A'^-1] D^-1."""
     aoP = aoT[:, ip]
     A = aoP.T.dot(aoP) ** 2
+    A = A + reg_rel * A.diagonal().max() * np.eye(len(ip))
     B = aoP.T.dot(aoT) ** 2
     P = len(ip)
     D = np.zeros((P, P))
@@ -209,7 +210,6 @@ def build_W_blockjacobi(aoT, ip, blk_off, a, mesh, reg_rel=1e-12, block_shift=0.
     Yp = scipy.linalg.solve_triangular(D, B, lower=True)
     Mp = build_W(Yp, a, mesh)
     Ap = scipy.linalg.solve_triangular(D, scipy.linalg.solve_triangular(D, A, lower=True).T, lower=True).T
-    Ap = Ap + reg_rel * Ap.diagonal().max() * np.eye(P)
     cf = scipy.linalg.cho_factor(Ap)
     Wp = scipy.linalg.cho_solve(cf, scipy.linalg.cho_solve(cf, Mp).T).T
     return scipy.linalg.solve_triangular(D, scipy.linalg.solve_triangular(D, Wp, lower=True, trans='T').T, lower=True, trans='T').T

@@ -167,6 +167,10 @@ class HipBackend:
         self.handle.call('isdf_block_solve', self._p(D), D.shape[0], len(blk_off) - 1, _np_ptr(blk_off), int(side), int(trans),
                          self._p(X), int(n), X.stride(0))
 
+    def shift_diag(self, A, shift_rel):
+        self._stream()
+        self.handle.call('isdf_shift_diag', self._p(A), A.shape[0], float(shift_rel))
+
     def chol_inplace(self, A, shift_rel, scratch=None):
         self._stream()
         reg = ctypes.c_double(0.0)
@@ -226,9 +230,9 @@ class HipBackend:
         self._stream()
         self.handle.call('isdf_symmetrize_upper', self._p(W), W.shape[0], W.stride(0))
 
-    def symmetrize_mean(self, W):
+    def symmetrize_mean(self, W, antisymmetric=False):
         self._stream()
-        self.handle.call('isdf_symmetrize_mean', self._p(W), W.shape[0], W.stride(0))
+        self.handle.call('isdf_symmetrize_mean', self._p(W), W.shape[0], W.stride(0), int(bool(antisymmetric)))
 
     def get_j(self, ao, ngrids, mesh, a, dm, vj):
         self._stream()

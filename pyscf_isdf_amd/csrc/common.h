@@ -106,6 +106,11 @@ int gemm_nt_f64(isdf_handle h, int M, int N, int64_t K, double alpha, const doub
 int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, const double* A, int64_t lda,
                        const double* B, int64_t ldb, const double* kscale, double beta, double* C,
                        int64_t ldc);
+// Triangular solves by substitution (trsm.hip): L (m x m) lower triangular, row-major (reads the lower triangle only).
+//   left:  X (m x n, row-major) <- op(L)^-1 X      right: X (n x m, row-major) <- X op(L)^-1      op = L | L^T (trans)
+int trsm_lower_left(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx);
+int trsm_lower_right(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx);
+int transpose_rm(isdf_handle h, const double* src, int64_t lds, int64_t rows, int64_t cols, double* dst, int64_t ldd);
 // Row-major wrappers over rocBLAS for the well-shaped products.
 // C (M x N, ldc) = alpha * op(A) * op(B) + beta * C, all row-major; opA/opB 'N' or 'T'.
 int gemm_rm(isdf_handle h, char opA, char opB, int64_t M, int64_t N, int64_t K, double alpha,

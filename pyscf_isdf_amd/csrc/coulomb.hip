@@ -119,8 +119,8 @@ __global__ void mirror_upper_kernel(double* __restrict__ W, int P, int64_t ldw) 
     if (r < P && cc < P && r > cc) W[(int64_t)r * ldw + cc] = tile[tx][i];
   }
 }
-// W <- (W + W^T) / 2, tile pairs (by, bx) / (bx, by) with bx >= by
-__global__ void mean_symmetric_kernel(double* __restrict__ W, int P, int64_t ldw) {
+// W <- (W + sign W^T) / 2, tile pairs (by, bx) / (bx, by) with bx >= by
+__global__ void mean_symmetric_kernel(double* __restrict__ W, int P, int64_t ldw, double sign) {
   __shared__ double up[32][33], lo[32][33];
   const int bx = blockIdx.x, by = blockIdx.y;
   if (bx < by) return;
@@ -134,18 +134,19 @@ __global__ void mean_symmetric_kernel(double* __restrict__ W, int P, int64_t ldw
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     const int r = by * 32 + i, cc = bx * 32 + tx;
-    if (r < P && cc < P) W[(int64_t)r * ldw + cc] = 0.5 * (up[i][tx] + lo[tx][i]);
+    if (r < P && cc < P) W[(int64_t)r * ldw + cc] = 0.5 * (up[i][tx] + sign * lo[tx][i]);
     const int r2 = bx * 32 + i, c2 = by * 32 + tx;
-    if (bx != by && r2 < P && c2 < P) W[(int64_t)r2 * ldw + c2] = 0.5 * (lo[i][tx] + up[tx][i]);
+    if (bx != by && r2 < P && c2 < P) W[(int64_t)r2 * ldw + c2] = 0.5 * (lo[i][tx] + sign * up[tx][i]);
   }
 }
 }  // namespace
 
-extern "C" int isdf_symmetrize_mean(isdf_handle h, double* d_W, int P, int64_t ldw) {
+extern "C" int isdf_symmetrize_mean(isdf_handle h, double* d_W, int P, int64_t ldw, int antisymmetric) {
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_W && P > 0 && ldw >= P);
   const unsigned nt = (unsigned)cdiv(P, 32);
-  hipLaunchKernelGGL(mean_symmetric_kernel, dim3(nt, nt), dim3(32, 8), 0, h->stream, d_W, P, ldw);
+  hipLaunchKernelGGL(mean_symmetric_kernel, dim3(nt, nt), dim3(32, 8), 0, h->stream, d_W, P, ldw,
+                     antisymmetric ? -1.0 : 1.0);
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

@@ -261,23 +261,21 @@ extern "C" int isdf_W_from_factor(isdf_handle h, const double* d_F, int P, int k
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_F && d_M && P > 0 && ldm >= P && (kind == 0 || kind == 1 || kind == 2));
   const double one = 1.0;
-  ProfScope ps(h, "rocblas_dtrsm[flop]", 2.0 * (double)P * P * P, 2);
+  // kinds 0 and 2: F is the column-major upper U of A = U^T U, i.e. the row-major lower L with A = L L^T
   if (kind == 2) {
-    // F as kind 0 (A = U^T U):  M <- U^-T M U^-1  (the other half of A^-1 M A^-1; follow with kind 0)
-    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose,
-                              rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
-    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
-                              rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
+    // M <- U^-T M U^-1 = L^-1 M L^-T  (the other half of A^-1 M A^-1; follow with kind 0)
+    int rc = trsm_lower_left(h, false, P, P, d_F, P, d_M, ldm);
+    if (rc) return rc;
+    return trsm_lower_right(h, true, P, P, d_F, P, d_M, ldm);
   } else if (kind == 0) {
-    // F = Cholesky factor of A_PP as stored by isdf_fit_prepare: column-major upper U, A = U^T U,
-    // Theta = U^-1 Y  =>  W = U^-1 M U^-T
-    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none,
-                              rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
-    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_transpose,
-                              rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
+    // Theta = U^-1 Y  =>  W = U^-1 M U^-T = L^-T M L^-1
+    int rc = trsm_lower_left(h, true, P, P, d_F, P, d_M, ldm);
+    if (rc) return rc;
+    return trsm_lower_right(h, false, P, P, d_F, P, d_M, ldm);
   } else {
     // F = T (row-major upper) from isdf_gather_T, i.e. column-major lower Lc = T^T,
-    // Theta = T^-1 L  =>  W = T^-1 M T^-T = Lc^-T M Lc^-1
+    // Theta = T^-1 L  =>  W = T^-1 M T^-T = Lc^-T M Lc^-1   (global selection only: rocBLAS)
+    ProfScope ps(h, "rocblas_dtrsm[flop]", 2.0 * (double)P * P * P, 2);
     BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
                               rocblas_diagonal_non_unit, P, P, &one, d_F, P, d_M, (rocblas_int)ldm));
     BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none,
@@ -410,27 +408,29 @@ extern "C" int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nbl
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_D && d_X && blk_off && P > 0 && nblk > 0 && n > 0 && (side == 0 || side == 1) && (trans == 0 || trans == 1));
   ARG_CHECK(h, n < 2147483647LL && ldx < 2147483647LL);
-  const double one = 1.0;
   for (int b = 0; b < nblk; ++b) {
     const int off = blk_off[b], nb = blk_off[b + 1] - off;
     if (nb <= 0) continue;
-    const double* U = d_D + (int64_t)off * P + off;
-    ProfScope ps(h, "rocblas_dtrsm[flop]", (double)n * nb * nb);
-    if (side == 0) {
-      // column-major view: X_cm (n x P, ld = ldx); rows blk of X == columns blk of X_cm: X_cm[:, blk] <- X_cm[:, blk] op(D)^-T
-      // D^-1 X  <->  X_cm D^-T = X_cm U^-1  (trans 0);   D^-T X  <->  X_cm D^-1 = X_cm U^-T (trans 1)
-      BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper,
-                                trans == 0 ? rocblas_operation_none : rocblas_operation_transpose,
-                                rocblas_diagonal_non_unit, (rocblas_int)n, nb, &one, U, P, d_X + (int64_t)off * ldx,
-                                (rocblas_int)ldx));
-    } else {
-      // X (n x P row-major) column block == rows blk of X_cm (P x n, ld = ldx): X_cm[blk, :] <- op(D)^-T X_cm[blk, :]
-      // X D^-1  <->  D^-T X_cm = U^-1 X_cm (trans 0);   X D^-T  <->  D^-1 X_cm = U^-T X_cm (trans 1)
-      BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper,
-                                trans == 0 ? rocblas_operation_none : rocblas_operation_transpose,
-                                rocblas_diagonal_non_unit, nb, (rocblas_int)n, &one, U, P, d_X + off, (rocblas_int)ldx));
-    }
+    const double* Db = d_D + (int64_t)off * P + off;     // row-major lower D_b, leading dimension P
+    const int rc = (side == 0) ? trsm_lower_left(h, trans != 0, nb, n, Db, P, d_X + (int64_t)off * ldx, ldx)
+                               : trsm_lower_right(h, trans != 0, nb, n, Db, P, d_X + off, ldx);
+    if (rc) return rc;
   }
+  return ISDF_OK;
+}
+
+extern "C" int isdf_shift_diag(isdf_handle h, double* d_A, int P, double shift_rel) {
+  // A <- A + shift_rel * max(diag A) * I  (the fit's regularisation, applied before the block scaling of S3c so that
+  // both fit routes solve the same regularised normal equations)
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_A && P > 0 && shift_rel >= 0);
+  if (shift_rel == 0.0) return ISDF_OK;
+  int* info = (int*)isdf_ws(h, "fit_info", 256);
+  if (!info) return ISDF_ERR_HIP;
+  double* maxdiag = (double*)(info + 16);
+  hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, h->stream, d_A, P, maxdiag);
+  hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, h->stream, d_A, P, maxdiag, shift_rel);
+  KERNEL_CHECK(h);
   return ISDF_OK;
 }
 
@@ -470,17 +470,13 @@ extern "C" int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift
 }
 
 extern "C" int isdf_factor_solve(isdf_handle h, const double* d_fac, int P, double* d_X, int64_t n, int64_t ldx) {
-  // X (P, n) row-major <- A^-1 X with A = U^T U (d_fac as stored by isdf_fit_prepare / isdf_chol_inplace).
-  // Column-major view X_cm (n x P, ld = ldx): X_cm <- X_cm U^-1 U^-T.
+  // X (P, n) row-major <- A^-1 X = L^-T L^-1 X, A = L L^T (d_fac: row-major lower L == the column-major upper U of
+  // isdf_fit_prepare / isdf_chol_inplace)
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_fac && d_X && P > 0 && n > 0 && ldx >= n && n < 2147483647LL && ldx < 2147483647LL);
-  const double one = 1.0;
-  ProfScope ps(h, "rocblas_dtrsm[flop]", 2.0 * (double)P * P * (double)n, 2);
-  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
-                            rocblas_diagonal_non_unit, (rocblas_int)n, P, &one, d_fac, P, d_X, (rocblas_int)ldx));
-  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_transpose,
-                            rocblas_diagonal_non_unit, (rocblas_int)n, P, &one, d_fac, P, d_X, (rocblas_int)ldx));
-  return ISDF_OK;
+  int rc = trsm_lower_left(h, false, P, n, d_fac, P, d_X, ldx);
+  if (rc) return rc;
+  return trsm_lower_left(h, true, P, n, d_fac, P, d_X, ldx);
 }
 
 extern "C" int isdf_bj_probe_rows(isdf_handle h, double* d_T, int n, const double* d_fac, const double* d_D, int P,
@@ -491,12 +487,11 @@ extern "C" int isdf_bj_probe_rows(isdf_handle h, double* d_T, int n, const doubl
   ARG_CHECK(h, d_T && d_fac && d_D && d_Yp && d_F && n > 0 && P > 0 && ng > 0 && ldy >= ng && ldf >= ng);
   int rc = isdf_block_solve(h, d_D, P, nblk, blk_off, 1, 1, d_T, n, P);      // t^T D^-T = (D^-1 t)^T
   if (rc) return rc;
-  const double one = 1.0;
-  // column-major view T_cm (P x n): T_cm <- U^-1 U^-T T_cm with A' = U^T U
-  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose,
-                            rocblas_diagonal_non_unit, P, n, &one, d_fac, P, d_T, P));
-  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none,
-                            rocblas_diagonal_non_unit, P, n, &one, d_fac, P, d_T, P));
+  // rows t^T <- t^T A'^-1 = t^T L^-T L^-1  (A' = L L^T symmetric)
+  rc = trsm_lower_right(h, true, P, n, d_fac, P, d_T, P);
+  if (rc) return rc;
+  rc = trsm_lower_right(h, false, P, n, d_fac, P, d_T, P);
+  if (rc) return rc;
   return gemm_rm(h, 'N', 'N', n, ng, P, 1.0, d_T, P, d_Yp, ldy, 0.0, d_F, ldf);
 }
 

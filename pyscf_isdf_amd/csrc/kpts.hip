@@ -61,14 +61,14 @@ __global__ void mirror_upper_sign_kernel(double* __restrict__ W, int P, int64_t 
   }
 }
 
-// Wc[p,q] = (Wre + i Wim)[p,q] * ph[p] * conj(ph[q]); the diagonal of the antisymmetric part is zeroed
+// Wc[p,q] = (Wre + i Wim)[p,q] * ph[p] * conj(ph[q])
 __global__ void finish_Wq_kernel(const double* __restrict__ Wre, const double* __restrict__ Wim, int P, int64_t ldw,
                                  const double2* __restrict__ ph, double2* __restrict__ Wc) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   const int p = blockIdx.y;
   if (q >= P) return;
   const double a = Wre[(int64_t)p * ldw + q];
-  const double b = (p == q) ? 0.0 : Wim[(int64_t)p * ldw + q];
+  const double b = Wim[(int64_t)p * ldw + q];
   const double2 fp = ph[p], fq = ph[q];
   // f = ph[p] * conj(ph[q])
   const double fr = fp.x * fq.x + fp.y * fq.y;

@@ -1,0 +1,151 @@
+// Triangular solves with many right-hand sides, by substitution.
+//
+//   X (m x n, row-major, ldx)  <-  op(L)^-1 X,    L (m x m) lower triangular, row-major, ldl;  op = L | L^T
+//
+// One primitive for every place the ISDF fit applies a Cholesky factor: the per-atom block factors D_b on the
+// (P, G) fit rows and on the (P, P) matrices, and the factor of A' on the (P, P) matrices.  rocBLAS's trsm inverts
+// 128 x 128 diagonal blocks and multiplies; with the factors of nearly singular Gram matrices that loses accuracy in
+// exactly the directions the block-Jacobi route amplifies (measured on the He2 k-point test: K off by 4e-2 against
+// 4e-8 with substitution), and its left/right variants apply *different* approximate inverses, so D^-1 A D^-T and
+// D^-1 B stop being consistent.  Here the diagonal blocks (64 rows) are solved by plain forward/backward substitution,
+// one right-hand side per lane, the triangle read through the scalar cache; everything off the diagonal is rocBLAS
+// dgemm.  Right-sided solves are done as left-sided ones on the transpose.
+#include "common.h"
+
+namespace {
+
+constexpr int SB = 64;     // rows per substitution block (one register per row and lane)
+
+// rows [0, nb) of X (nb <= 64):  x <- L^-1 x  (TRANS = false)  or  x <- L^-T x  (TRANS = true)
+template <bool TRANS>
+__global__ __launch_bounds__(256) void subst_kernel(const double* __restrict__ L, int64_t ldl, int nb,
+                                                    double* __restrict__ X, int64_t ldx, int64_t n) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  double x[SB];
+#pragma unroll
+  for (int i = 0; i < SB; ++i) x[i] = (i < nb) ? X[(int64_t)i * ldx + c] : 0.0;
+  if (!TRANS) {
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      if (i < nb) {
+        double s = x[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s = fma(-L[(int64_t)i * ldl + k], x[k], s);
+        x[i] = s / L[(int64_t)i * ldl + i];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = SB - 1; i >= 0; --i) {
+      if (i < nb) {
+        double s = x[i];
+#pragma unroll
+        for (int k = i + 1; k < SB; ++k)
+          if (k < nb) s = fma(-L[(int64_t)k * ldl + i], x[k], s);
+        x[i] = s / L[(int64_t)i * ldl + i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < SB; ++i)
+    if (i < nb) X[(int64_t)i * ldx + c] = x[i];
+}
+
+// dst (cols x rows, ldd) = src (rows x cols, lds)^T, 32 x 32 tiles through LDS
+__global__ void transpose_kernel(const double* __restrict__ src, int64_t lds, int64_t rows, int64_t cols,
+                                 double* __restrict__ dst, int64_t ldd) {
+  __shared__ double tile[32][33];
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int64_t r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[r * lds + c] : 0.0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int64_t r = c0 + i, c = r0 + tx;        // dst row = src column
+    if (r < cols && c < rows) dst[r * ldd + c] = tile[tx][i];
+  }
+}
+
+int subst(isdf_handle h, bool trans, const double* L, int64_t ldl, int nb, double* X, int64_t ldx, int64_t n) {
+  ProfScope ps(h, trans ? "trsm_subst_kernel<true>[flop]" : "trsm_subst_kernel<false>[flop]", (double)nb * nb * (double)n);
+  const dim3 grid((unsigned)cdiv(n, 256));
+  if (trans) hipLaunchKernelGGL(subst_kernel<true>, grid, dim3(256), 0, h->stream, L, ldl, nb, X, ldx, n);
+  else hipLaunchKernelGGL(subst_kernel<false>, grid, dim3(256), 0, h->stream, L, ldl, nb, X, ldx, n);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+}  // namespace
+
+int transpose_rm(isdf_handle h, const double* src, int64_t lds, int64_t rows, int64_t cols, double* dst, int64_t ldd) {
+  ARG_CHECK(h, src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= rows);
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32)), dim3(32, 8), 0, h->stream,
+                     src, lds, rows, cols, dst, ldd);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+int trsm_lower_left(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx) {
+  ARG_CHECK(h, L && X && m > 0 && n > 0 && ldl >= m && ldx >= n);
+  // two levels: panels of PB rows are updated with one large dgemm each, the panel's own triangle goes through
+  // 64-row substitution blocks with small dgemm updates inside the panel
+  const int PB = 512;
+  int rc;
+  if (!trans) {
+    for (int r0 = 0; r0 < m; r0 += PB) {
+      const int r1 = std::min(m, r0 + PB);
+      if (r0 > 0) {   // X[r0:r1] -= L[r0:r1, 0:r0] X[0:r0]
+        rc = gemm_rm(h, 'N', 'N', r1 - r0, n, r0, -1.0, L + (int64_t)r0 * ldl, ldl, X, ldx, 1.0, X + (int64_t)r0 * ldx, ldx);
+        if (rc) return rc;
+      }
+      for (int s0 = r0; s0 < r1; s0 += SB) {
+        const int s1 = std::min(r1, s0 + SB);
+        if (s0 > r0) {   // X[s0:s1] -= L[s0:s1, r0:s0] X[r0:s0]
+          rc = gemm_rm(h, 'N', 'N', s1 - s0, n, s0 - r0, -1.0, L + (int64_t)s0 * ldl + r0, ldl, X + (int64_t)r0 * ldx, ldx,
+                       1.0, X + (int64_t)s0 * ldx, ldx);
+          if (rc) return rc;
+        }
+        rc = subst(h, false, L + (int64_t)s0 * ldl + s0, ldl, s1 - s0, X + (int64_t)s0 * ldx, ldx, n);
+        if (rc) return rc;
+      }
+    }
+  } else {
+    // L^T x = b: from the bottom up; the coupling of rows [a, b) to later rows [b, e) is L[b:e, a:b]^T
+    const int npan = (int)cdiv(m, PB);
+    for (int p = npan - 1; p >= 0; --p) {
+      const int r0 = p * PB, r1 = std::min(m, r0 + PB);
+      if (r1 < m) {   // X[r0:r1] -= L[r1:m, r0:r1]^T X[r1:m]
+        rc = gemm_rm(h, 'T', 'N', r1 - r0, n, m - r1, -1.0, L + (int64_t)r1 * ldl + r0, ldl, X + (int64_t)r1 * ldx, ldx, 1.0,
+                     X + (int64_t)r0 * ldx, ldx);
+        if (rc) return rc;
+      }
+      const int nsb = (int)cdiv(r1 - r0, SB);
+      for (int q = nsb - 1; q >= 0; --q) {
+        const int s0 = r0 + q * SB, s1 = std::min(r1, s0 + SB);
+        if (s1 < r1) {   // X[s0:s1] -= L[s1:r1, s0:s1]^T X[s1:r1]
+          rc = gemm_rm(h, 'T', 'N', s1 - s0, n, r1 - s1, -1.0, L + (int64_t)s1 * ldl + s0, ldl, X + (int64_t)s1 * ldx, ldx,
+                       1.0, X + (int64_t)s0 * ldx, ldx);
+          if (rc) return rc;
+        }
+        rc = subst(h, true, L + (int64_t)s0 * ldl + s0, ldl, s1 - s0, X + (int64_t)s0 * ldx, ldx, n);
+        if (rc) return rc;
+      }
+    }
+  }
+  return ISDF_OK;
+}
+
+int trsm_lower_right(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx) {
+  // X (n x m, row-major, ldx) <- X op(L)^-1  ==  ( op(L)^-T X^T )^T
+  ARG_CHECK(h, L && X && m > 0 && n > 0 && ldl >= m && ldx >= m);
+  double* T = (double*)isdf_ws(h, "trsm_T", sizeof(double) * (size_t)m * (size_t)n);
+  if (!T) return ISDF_ERR_HIP;
+  int rc = transpose_rm(h, X, ldx, n, m, T, n);
+  if (rc) return rc;
+  rc = trsm_lower_left(h, !trans, m, n, L, ldl, T, n);
+  if (rc) return rc;
+  return transpose_rm(h, T, n, m, n, X, ldx);
+}

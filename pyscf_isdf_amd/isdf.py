@@ -84,7 +84,8 @@ class ISDF:
                                          # max|dK|/|K| of the two routes within a factor of a few, profiles/r01_bj_*)
         self.bj_max_c = 12               # 'auto': do not even try S3c above this c_isdf (cond(A') grows ~100x per +5)
         self.bj_nprobe = 8
-        self.bj_group = 1                # S3c preconditioner blocks = point sets of this many consecutive atoms
+        self.bj_cluster_radius = 2.4     # Bohr; atoms closer than this share a preconditioner block (X-H bonds)
+        self.bj_group = 1                # merge this many consecutive clusters into one block (experiments)
         self.bj_check = None             # the measured mismatch of the last 'auto' build
         self.fit_route_used = None
         self.block_shift = 0.0           # relative diagonal shift of the per-atom blocks in the S3c route (raised per
@@ -188,11 +189,15 @@ class ISDF:
         be.gather_aoP(ao, d_ip, aoP)
         A = self._buffer('factor', (P, P))
         be.gram_sq(aoP, A, nh)
+        # the fit's regularisation goes onto A itself, before the block scaling: both routes then solve the same
+        # (A + reg I) x = b and differ by rounding only; A' gets a further shift only if its factorisation fails
+        be.shift_diag(A, self.reg_rel)
         Dblk = self._buffer('Dblk', (P, P))
         self.block_shift_used = be.block_chol(A, ip_off, self.block_shift, Dblk)
         be.block_solve(Dblk, ip_off, 0, 0, A)            # A' = D^-1 A D^-T
         be.block_solve(Dblk, ip_off, 1, 1, A)
-        self.reg_used = be.chol_inplace(A, self.reg_rel, scratch=scratch)
+        extra = be.chol_inplace(A, 0.0, scratch=scratch)
+        self.reg_used = self.reg_rel + extra
         return A, Dblk
 
     def _bj_rows(self, aoP, nh, ao, ng, Dblk, ip_off, out):
@@ -201,19 +206,52 @@ class ISDF:
         be.pair_gram_rows(aoP, ao, ng, out, nh)
         be.block_solve(Dblk, ip_off, 0, 0, out)
 
-    def _bj_finish(self, Afac, Dblk, ip_off, W, symmetric=True):
+    def _bj_finish(self, Afac, Dblk, ip_off, W, antisymmetric=False):
         """W <- D^-T [A'^-1 W A'^-1] D^-1 (W holds M' on entry)."""
         be = self.backend
         be.W_from_factor(Afac, 2, W)
         be.W_from_factor(Afac, 0, W)
         be.block_solve(Dblk, ip_off, 0, 1, W)
         be.block_solve(Dblk, ip_off, 1, 0, W)
-        if symmetric:
-            be.symmetrize_mean(W)         # the rounding noise along null(A) is not symmetric; the mean keeps it in null(A)
+        # the rounding noise along null(A) is not (anti)symmetric; the mean keeps it inside null(A) x null(A)
+        be.symmetrize_mean(W, antisymmetric)
 
-    def _bj_blocks(self, counts):
-        """Offsets of the preconditioner blocks: the per-atom point counts, bj_group consecutive atoms merged."""
-        off = np.append(0, np.cumsum(counts)).astype(np.int32)
+    def _bj_clusters(self):
+        """Atoms grouped for the S3c preconditioner: single linkage (minimum image) below bj_cluster_radius Bohr.  The
+        default joins X-H bonds only: a hydrogen's 50 points are nearly dependent on its neighbour's, so per-atom
+        blocks leave A' = D^-1 A D^-T badly conditioned on molecular systems (64 H2O: probe mismatch 1e-6 with
+        per-atom blocks), while diamond (C-C 2.9 Bohr) keeps one block per atom.  Returns a list of atom-index lists,
+        ordered by their first atom; the interpolation points are stored cluster by cluster."""
+        cell = self.cell
+        natm = cell.natm
+        parent = list(range(natm))
+
+        def find(i):
+            while parent[i] != i:
+                parent[i] = parent[parent[i]]
+                i = parent[i]
+            return i
+        r = float(self.bj_cluster_radius or 0.0)
+        if r > 0 and natm > 1:
+            a = np.asarray(cell.lattice_vectors(), dtype=float)
+            frac = np.asarray(cell.atom_coords(), dtype=float).dot(np.linalg.inv(a))
+            d = frac[:, None, :] - frac[None, :, :]
+            d -= np.round(d)
+            dist = np.linalg.norm(d.dot(a), axis=2)
+            for i, j in zip(*np.nonzero(np.triu(dist < r, 1))):
+                ri, rj = find(int(i)), find(int(j))
+                if ri != rj:
+                    parent[max(ri, rj)] = min(ri, rj)
+        groups = {}
+        for i in range(natm):
+            groups.setdefault(find(i), []).append(i)
+        return [groups[k] for k in sorted(groups)]
+
+    def _bj_blocks(self, counts, clusters):
+        """Offsets of the preconditioner blocks for points stored cluster by cluster (counts: points per atom);
+        bj_group consecutive clusters are merged on top."""
+        per = [int(sum(counts[b] for b in cl)) for cl in clusters]
+        off = np.append(0, np.cumsum(per)).astype(np.int32)
         g = max(1, int(self.bj_group))
         if g > 1:
             off = np.unique(np.append(off[::g], off[-1])).astype(np.int32)
@@ -387,7 +425,8 @@ class ISDF:
             rank = be.select_ip(ao_sel, blk_off, nip, self.select_tol, self.tie_rtol, L, piv)
             del ao_sel, L, scratch
             piv_h = be.to_host(piv)
-            ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(cell.natm)])
+            clusters = self._bj_clusters()
+            ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for cl in clusters for b in cl])
             self.ip = ip.astype(np.int64)
             P = len(ip)
             t0 = self._tick('S2_select_ip', t0)
@@ -398,7 +437,7 @@ class ISDF:
             for route in self._fit_routes():
                 if route == 'blockjacobi':
                     # S3c: no triangular solve over the grid.  theta <- Y' = D^-1 (aoP ao)^2
-                    ip_off = self._bj_blocks(rank)
+                    ip_off = self._bj_blocks(rank, clusters)
                     Afac, Dblk = self._bj_prepare(self.ao, 0, d_ip, ip_off, self.aoP, scratch=self.W)
                     self._bj_rows(self.aoP, 0, self.ao, G, Dblk, ip_off, theta)
                 else:
@@ -611,7 +650,8 @@ class ISDF:
         merged = {}
         for d in all_ips:
             merged.update(d)
-        self.ip = np.concatenate([merged[b] for b in sorted(merged)]).astype(np.int64)
+        clusters = self._bj_clusters()
+        self.ip = np.concatenate([merged[b] for cl in clusters for b in cl]).astype(np.int64)
         P = len(self.ip)
         t0 = self._tick('S2_select_ip', t0)
 
@@ -630,7 +670,7 @@ class ISDF:
         self.aoP = self._buffer('aoP', (P, nao))
         theta = self._buffer('theta', (P, ng))
         ar = be.to_device(np.arange(P, dtype=np.int64))
-        ip_off = self._bj_blocks([len(merged[b]) for b in sorted(merged)])
+        ip_off = self._bj_blocks([len(merged[b]) for b in range(cell.natm)], clusters)
         for route in self._fit_routes():
             # the P x P factorisations run on rank 0 and are broadcast (2 x 8 P^2 bytes): every rank then holds the
             # same bits, and the shift ladders' decisions cannot diverge between ranks
@@ -802,7 +842,8 @@ class ISDF:
             rank = be.select_ip_cplx(Xs, nh, blk_off, nip, self.select_tol, self.tie_rtol, L, piv)
             del Xs, L
             piv_h = be.to_host(piv)
-            self.ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(cell.natm)]).astype(np.int64)
+            clusters = self._bj_clusters()
+            self.ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for cl in clusters for b in cl]).astype(np.int64)
             ip_dev = be.to_device(self.ip)
         P = len(self.ip)
         t0 = self._tick('S2_select_ip', t0)
@@ -815,7 +856,7 @@ class ISDF:
         use_bj = self.fit_route == 'blockjacobi' and not self.explicit_theta and self.select != 'global'
         self.fit_route_used = 'blockjacobi' if use_bj else 'cholesky'
         if use_bj:
-            ip_off = self._bj_blocks(rank)
+            ip_off = self._bj_blocks(rank, clusters)
             Afac, Dblk = self._bj_prepare(X, nh, ip_dev, ip_off, aoP_X)
             self._bj_rows(aoP_X, nh, X, G, Dblk, ip_off, Y)
         else:
@@ -860,8 +901,8 @@ class ISDF:
             be.coulomb_Wq(Y, mesh, coulG, w, 0, P, batch, Wre, Wim, upper_only=True)
             be.symmetrize_hermitian(Wre, Wim)
             if use_bj:
-                self._bj_finish(Afac, Dblk, ip_off, Wre, symmetric=False)
-                self._bj_finish(Afac, Dblk, ip_off, Wim, symmetric=False)
+                self._bj_finish(Afac, Dblk, ip_off, Wre)
+                self._bj_finish(Afac, Dblk, ip_off, Wim, antisymmetric=True)
             elif not self.explicit_theta:
                 be.W_from_factor(chol, 0, Wre)
                 be.W_from_factor(chol, 0, Wim)

@@ -39,6 +39,7 @@ SIGNATURES = {
     'isdf_pair_gram_rows': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64]),
     'isdf_block_chol': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_dbl, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_block_solve': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_i64, c_i64]),
+    'isdf_shift_diag': (c_int, [c_vp, c_vp, c_int, c_dbl]),
     'isdf_chol_inplace': (c_int, [c_vp, c_vp, c_int, c_dbl, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_factor_solve': (c_int, [c_vp, c_vp, c_int, c_vp, c_i64, c_i64]),
     'isdf_bj_probe_rows': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64]),
@@ -48,7 +49,7 @@ SIGNATURES = {
     'isdf_coulomb_W': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64]),
     'isdf_coulomb_rows': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_vp, c_i64]),
     'isdf_symmetrize_upper': (c_int, [c_vp, c_vp, c_int, c_i64]),
-    'isdf_symmetrize_mean': (c_int, [c_vp, c_vp, c_int, c_i64]),
+    'isdf_symmetrize_mean': (c_int, [c_vp, c_vp, c_int, c_i64, c_int]),
     'isdf_get_j': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_vp]),
     'isdf_rho': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_i64]),
     'isdf_coulomb_potential': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),

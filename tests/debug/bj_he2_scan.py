@@ -8,7 +8,7 @@ from oracle_backend import OracleBackend
 from pyscf_isdf_amd.isdf import ISDF
 
 cell, coords, Ls, rcut, kpts, aos, dms = T._setup()
-for mode in ('gamma',):
+for mode in ('gamma', 'k'):
     for c in (4, 6, 8, 10):
         ks = {}
         for bname in ('hip', 'cpu'):

@@ -131,6 +131,10 @@ class OracleBackend:
                 # X op(D)^-1 = (op(D)^-T X^T)^T
                 x[:, s] = scipy.linalg.solve_triangular(d[s, s], x[:, s].T, lower=True, trans='N' if trans else 'T').T
 
+    def shift_diag(self, A, shift_rel):
+        a = A.numpy()
+        a[np.diag_indices(len(a))] += shift_rel * a.diagonal().max()
+
     def chol_inplace(self, A, shift_rel, scratch=None):
         a0 = A.numpy().copy()
         reg = shift_rel
@@ -188,8 +192,8 @@ class OracleBackend:
         iu = np.triu_indices(len(w), 1)
         w.T[iu] = w[iu]
 
-    def symmetrize_mean(self, W):
-        W.copy_((W + W.T) / 2)
+    def symmetrize_mean(self, W, antisymmetric=False):
+        W.copy_((W - W.T) / 2 if antisymmetric else (W + W.T) / 2)
 
     def gemm_nt(self, A, B, C, alpha=1.0, beta=0.0, kscale=None):
         b = B.numpy() if kscale is None else B.numpy() * kscale.numpy()

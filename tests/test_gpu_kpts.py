@@ -131,13 +131,13 @@ def test_isdf_kpts_fit_routes_agree():
     cell, coords, Ls, rcut, kpts, aos, dms = _setup()
     out = {}
     for route in ('cholesky', 'blockjacobi'):
-        df = ISDF(cell, kpts=kpts, c_isdf=4, select='local')
+        df = ISDF(cell, kpts=kpts, c_isdf=10, select='local')
         df.fit_route = route
         out[route] = (df.get_jk(dms, kpts=kpts, with_j=False)[1], df.ip.copy())
     assert np.array_equal(out['cholesky'][1], out['blockjacobi'][1])
     d = out['cholesky'][0] - out['blockjacobi'][0]
-    assert abs(d).max() < 1e-7 * abs(out['cholesky'][0]).max()
-    df = ISDF(cell, kpts=kpts, c_isdf=4, select='local')
+    assert abs(d).max() < 1e-6 * abs(out['cholesky'][0]).max()
+    df = ISDF(cell, kpts=kpts, c_isdf=10, select='local')
     vk = df.get_jk(dms, kpts=kpts, with_j=False)[1]
     assert df.fit_route == 'auto' and abs(vk - out['cholesky'][0]).max() < 1e-12 * abs(vk).max()
 

@@ -485,6 +485,9 @@ def test_symmetrize_mean_and_probe_rows(be):
         d = be.to_device(M)
         be.symmetrize_mean(d)
         assert np.array_equal(be.to_host(d), (M + M.T) / 2)
+        d = be.to_device(M)
+        be.symmetrize_mean(d, antisymmetric=True)
+        assert np.array_equal(be.to_host(d), (M - M.T) / 2)
     # probe rows: T <- A'^-1 D^-1 t (A' = D^-1 A D^-T), F = T Y'
     P, n, ng = 37, 5, 90
     off = np.array([0, 12, 12, 30, 37], dtype=np.int32)
@@ -513,6 +516,41 @@ def test_symmetrize_mean_and_probe_rows(be):
     be.factor_solve(dA, view)
     assert abs(be.to_host(big)[:, :11] - np.linalg.solve(Ap, X)).max() < 1e-11 * abs(X).max()
     assert abs(be.to_host(big)[:, 11:]).max() == 0
+
+
+@pytest.mark.parametrize('m', [1, 63, 64, 65, 130, 515, 1100])
+def test_substitution_trsm_all_variants(be, m):
+    """trsm.hip through isdf_block_solve with one block: left/right, L / L^T, ragged 64-row substitution blocks and
+    512-row panels, odd numbers of right-hand sides and a row stride; and an ill-conditioned factor, where substitution
+    keeps the small backward error that an inversion-based trsm loses."""
+    import scipy.linalg
+    rng = np.random.default_rng(m)
+    L = np.tril(rng.standard_normal((m, m))) * 0.3 + np.diag(1.0 + rng.random(m))
+    D = be.to_device(L + np.triu(rng.standard_normal((m, m)), 1))          # garbage above the diagonal must be ignored
+    off = np.array([0, m], dtype=np.int32)
+    n = 777
+    for side in (0, 1):
+        for trans in (0, 1):
+            X = rng.standard_normal((m, n) if side == 0 else (n, m))
+            buf = be.to_device(np.hstack([X, np.zeros((X.shape[0], 5))]))
+            view = buf[:, :X.shape[1]]
+            be.block_solve(D, off, side, trans, view)
+            if side == 0:
+                ref = scipy.linalg.solve_triangular(L, X, lower=True, trans='T' if trans else 'N')
+            else:
+                ref = scipy.linalg.solve_triangular(L, X.T, lower=True, trans='N' if trans else 'T').T
+            got = be.to_host(buf)
+            assert abs(got[:, :X.shape[1]] - ref).max() < 1e-10 * abs(ref).max(), (side, trans)
+            assert abs(got[:, X.shape[1]:]).max() == 0
+    if m >= 130:
+        # Cholesky factor of a Gram matrix with condition number 1e12: residual of L x = b at rounding level
+        Z = rng.standard_normal((m, m)) * np.logspace(0, -6, m)
+        Lc = np.linalg.cholesky(Z.dot(Z.T) + 1e-13 * np.eye(m))
+        Xc = rng.standard_normal((m, 50))
+        d = be.to_device(Xc)
+        be.block_solve(be.to_device(Lc), off, 0, 0, d)
+        res = Lc.dot(be.to_host(d)) - Xc
+        assert abs(res).max() < 1e-9 * (abs(Lc).max() * abs(be.to_host(d)).max())
 
 
 def test_block_chol_shifts_a_block_that_is_not_positive_definite(be):
@@ -571,8 +609,8 @@ def test_block_jacobi_route_building_blocks(be):
 
 
 def test_auto_route_probe_check_accepts_and_falls_back():
-    """fit_route='auto': the probe check accepts the block-Jacobi route on a well-conditioned point set and falls
-    back to the Cholesky route (with a warning) on an over-complete one, where S3c loses 1e-5 in K (measured)."""
+    """fit_route='auto': the probe check accepts the block-Jacobi route; when its mismatch exceeds the tolerance
+    (forced here with a tiny tolerance) the build warns and rebuilds W with the Cholesky route."""
     import warnings
     from pyscf_isdf_amd.isdf import ISDF
     cell = cells.cell_he2_triclinic()
@@ -580,23 +618,21 @@ def test_auto_route_probe_check_accepts_and_falls_back():
     dm = np.eye(nao)
     ref = ISDF(cell, c_isdf=8, select='local'); ref.fit_route = 'cholesky'
     k_ref = ref.get_jk(dm, with_j=False)[1]
-    df = ISDF(cell, c_isdf=8, select='local')                 # 64 points for 36 pair products: A is rank deficient
+    ok = ISDF(cell, c_isdf=8, select='local')                 # 64 points for 36 pair products: A is rank deficient
+    k_ok = ok.get_jk(dm, with_j=False)[1]
+    assert ok.fit_route_used == 'blockjacobi' and 0 < ok.bj_check <= ok.bj_check_tol
+    # both routes solve the same regularised normal equations: they differ by (amplified) rounding only,
+    # and the probe mismatch is of the size of that difference
+    err = abs(k_ok - k_ref).max() / abs(k_ref).max()
+    assert err < 1e-6 and ok.bj_check < 1e-6
+    df = ISDF(cell, c_isdf=8, select='local')
+    df.bj_check_tol = 1e-13
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter('always')
         k_auto = df.get_jk(dm, with_j=False)[1]
     assert df.fit_route_used == 'cholesky' and df.bj_check > df.bj_check_tol
     assert any('probe check' in str(w.message) for w in rec)
     assert abs(k_auto - k_ref).max() < 1e-10 * abs(k_ref).max()
-    bj = ISDF(cell, c_isdf=8, select='local'); bj.fit_route = 'blockjacobi'
-    k_bj = bj.get_jk(dm, with_j=False)[1]
-    # the unguarded route really is off by more than the check tolerance here, and the check value tracks it
-    err = abs(k_bj - k_ref).max() / abs(k_ref).max()
-    assert err > df.bj_check_tol and 0.01 * err < df.bj_check < 100 * err
-    ok = ISDF(cell, c_isdf=4, select='local')
-    k4 = ok.get_jk(dm, with_j=False)[1]
-    assert ok.fit_route_used == 'blockjacobi' and ok.bj_check <= ok.bj_check_tol
-    ch = ISDF(cell, c_isdf=4, select='local'); ch.fit_route = 'cholesky'
-    assert abs(k4 - ch.get_jk(dm, with_j=False)[1]).max() < 1e-8 * abs(k4).max()
     hi = ISDF(cell, c_isdf=15, select='local')
     assert hi._fit_routes() == ['cholesky']                   # above bj_max_c the trial is skipped
 

@@ -17,7 +17,10 @@ for c_isdf in cs:
         df = ISDF(cell, c_isdf=c_isdf, select='local')
         df.fit_route = route if route == 'cholesky' else 'auto'
         df.bj_check_tol = 1e99
+        df.bj_max_c = 10**9
         df.bj_group = group
+        if 'BJ_RADIUS' in os.environ:
+            df.bj_cluster_radius = float(os.environ['BJ_RADIUS'])
         t0 = time.perf_counter()
         vk[route] = df.get_jk(dm, with_j=False)[1]
         t1 = time.perf_counter()
@@ -32,7 +35,7 @@ for c_isdf in cs:
             # per-atom block offsets: points are stored atom by atom
             from pyscf_isdf_amd.isdf import partition_grid_by_atom
             owner = partition_grid_by_atom(df.grids.coords[df.ip], cell.atom_coords(), cell.lattice_vectors())
-            ip_off = df._bj_blocks(np.bincount(owner, minlength=cell.natm))
+            ip_off = df._bj_blocks(np.bincount(owner, minlength=cell.natm), df._bj_clusters())
             be.block_solve(D, ip_off, 0, 0, A); be.block_solve(D, ip_off, 1, 1, A)
             A = (A + A.T) / 2
             w = torch.linalg.eigvalsh(A)
