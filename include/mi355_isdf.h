@@ -51,6 +51,11 @@ const char* isdf_last_error(isdf_handle h);
 int64_t isdf_workspace_bytes(isdf_handle h);
 /* Release cached workspace and FFT plans (keeps the context usable). */
 int isdf_release_workspace(isdf_handle h);
+/* Runtime switches.  "trsm_substitution": 0 (default) the fit's triangular solves with Cholesky factors go through rocBLAS
+ * dtrsm, 1 through the substitution blocks of trsm.hip (plain forward/backward substitution on 64-row diagonal blocks +
+ * dgemm updates: slower, no inverted diagonal blocks; also the way to profile with rocprofv3 --pmc, which crashes inside
+ * rocBLAS's trsm on the 1.7M-column right-hand sides).  Unknown keys are an error. */
+int isdf_set_option(isdf_handle h, const char* key, int value);
 
 /* Optional in-library profiling (bench.py's roofline leg): when enabled, the library brackets its
  * hot kernel launches with HIP events on the work stream and accumulates, per kernel name, the number

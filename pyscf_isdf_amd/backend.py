@@ -6,6 +6,7 @@ libmi355_isdf.so.  The method set below is the contract between the host driver
 passing a checker backend with the same methods (tests/oracle_backend.py) — the product never does.
 """
 import ctypes
+import os
 import numpy as np
 import torch
 from . import lib as _lib
@@ -26,6 +27,8 @@ class HipBackend:
         self.device = torch.device('cuda', device)
         torch.cuda.set_device(self.device)
         self.handle = _lib.Handle(device)
+        if os.environ.get('ISDF_TRSM') == 'subst':        # e.g. for rocprofv3 --pmc runs (include/mi355_isdf.h)
+            self.set_option('trsm_substitution', 1)
 
     # ---- memory -------------------------------------------------------------------------------
     def empty(self, shape, dtype=torch.float64):
@@ -42,6 +45,9 @@ class HipBackend:
 
     def to_host(self, t):
         return t.detach().cpu().numpy()
+
+    def set_option(self, key, value):
+        self.handle.call('isdf_set_option', key.encode(), int(value))
 
     def free_bytes(self):
         """Device memory obtainable right now: free on the device + free inside torch's cache."""

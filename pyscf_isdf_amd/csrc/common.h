@@ -41,6 +41,8 @@ struct isdf_ctx {
   // named workspace buffers (grow-only until isdf_release_workspace)
   std::map<std::string, std::pair<void*, size_t>> ws;
   int num_cu = 256;
+  // triangular solves of the fit: 0 = rocBLAS dtrsm (default, faster), 1 = substitution blocks of trsm.hip
+  int trsm_substitution = 0;
 };
 
 int isdf_fail(isdf_handle h, int code, const char* fmt, ...);
@@ -111,6 +113,10 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
 int trsm_lower_left(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx);
 int trsm_lower_right(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx);
 int transpose_rm(isdf_handle h, const double* src, int64_t lds, int64_t rows, int64_t cols, double* dst, int64_t ldd);
+// The fit's triangular solves with a row-major lower factor L: dispatch on h->trsm_substitution between rocBLAS dtrsm
+// (column-major view: the same buffer is the upper factor U = L^T) and trsm_lower_*.
+int tri_left(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx);
+int tri_right(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx);
 // Row-major wrappers over rocBLAS for the well-shaped products.
 // C (M x N, ldc) = alpha * op(A) * op(B) + beta * C, all row-major; opA/opB 'N' or 'T'.
 int gemm_rm(isdf_handle h, char opA, char opB, int64_t M, int64_t N, int64_t K, double alpha,

@@ -264,14 +264,14 @@ extern "C" int isdf_W_from_factor(isdf_handle h, const double* d_F, int P, int k
   // kinds 0 and 2: F is the column-major upper U of A = U^T U, i.e. the row-major lower L with A = L L^T
   if (kind == 2) {
     // M <- U^-T M U^-1 = L^-1 M L^-T  (the other half of A^-1 M A^-1; follow with kind 0)
-    int rc = trsm_lower_left(h, false, P, P, d_F, P, d_M, ldm);
+    int rc = tri_left(h, false, P, P, d_F, P, d_M, ldm);
     if (rc) return rc;
-    return trsm_lower_right(h, true, P, P, d_F, P, d_M, ldm);
+    return tri_right(h, true, P, P, d_F, P, d_M, ldm);
   } else if (kind == 0) {
     // Theta = U^-1 Y  =>  W = U^-1 M U^-T = L^-T M L^-1
-    int rc = trsm_lower_left(h, true, P, P, d_F, P, d_M, ldm);
+    int rc = tri_left(h, true, P, P, d_F, P, d_M, ldm);
     if (rc) return rc;
-    return trsm_lower_right(h, false, P, P, d_F, P, d_M, ldm);
+    return tri_right(h, false, P, P, d_F, P, d_M, ldm);
   } else {
     // F = T (row-major upper) from isdf_gather_T, i.e. column-major lower Lc = T^T,
     // Theta = T^-1 L  =>  W = T^-1 M T^-T = Lc^-T M Lc^-1   (global selection only: rocBLAS)
@@ -412,8 +412,8 @@ extern "C" int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nbl
     const int off = blk_off[b], nb = blk_off[b + 1] - off;
     if (nb <= 0) continue;
     const double* Db = d_D + (int64_t)off * P + off;     // row-major lower D_b, leading dimension P
-    const int rc = (side == 0) ? trsm_lower_left(h, trans != 0, nb, n, Db, P, d_X + (int64_t)off * ldx, ldx)
-                               : trsm_lower_right(h, trans != 0, nb, n, Db, P, d_X + off, ldx);
+    const int rc = (side == 0) ? tri_left(h, trans != 0, nb, n, Db, P, d_X + (int64_t)off * ldx, ldx)
+                               : tri_right(h, trans != 0, nb, n, Db, P, d_X + off, ldx);
     if (rc) return rc;
   }
   return ISDF_OK;
@@ -474,9 +474,9 @@ extern "C" int isdf_factor_solve(isdf_handle h, const double* d_fac, int P, doub
   // isdf_fit_prepare / isdf_chol_inplace)
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_fac && d_X && P > 0 && n > 0 && ldx >= n && n < 2147483647LL && ldx < 2147483647LL);
-  int rc = trsm_lower_left(h, false, P, n, d_fac, P, d_X, ldx);
+  int rc = tri_left(h, false, P, n, d_fac, P, d_X, ldx);
   if (rc) return rc;
-  return trsm_lower_left(h, true, P, n, d_fac, P, d_X, ldx);
+  return tri_left(h, true, P, n, d_fac, P, d_X, ldx);
 }
 
 extern "C" int isdf_bj_probe_rows(isdf_handle h, double* d_T, int n, const double* d_fac, const double* d_D, int P,
@@ -488,9 +488,9 @@ extern "C" int isdf_bj_probe_rows(isdf_handle h, double* d_T, int n, const doubl
   int rc = isdf_block_solve(h, d_D, P, nblk, blk_off, 1, 1, d_T, n, P);      // t^T D^-T = (D^-1 t)^T
   if (rc) return rc;
   // rows t^T <- t^T A'^-1 = t^T L^-T L^-1  (A' = L L^T symmetric)
-  rc = trsm_lower_right(h, true, P, n, d_fac, P, d_T, P);
+  rc = tri_right(h, true, P, n, d_fac, P, d_T, P);
   if (rc) return rc;
-  rc = trsm_lower_right(h, false, P, n, d_fac, P, d_T, P);
+  rc = tri_right(h, false, P, n, d_fac, P, d_T, P);
   if (rc) return rc;
   return gemm_rm(h, 'N', 'N', n, ng, P, 1.0, d_T, P, d_Yp, ldy, 0.0, d_F, ldf);
 }

@@ -59,6 +59,13 @@ extern "C" {
 
 int isdf_abi_version(void) { return 10; }
 
+int isdf_set_option(isdf_handle h, const char* key, int value) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, key != nullptr);
+  if (std::string(key) == "trsm_substitution") { h->trsm_substitution = value ? 1 : 0; return ISDF_OK; }
+  return isdf_fail(h, ISDF_ERR_ARG, "isdf_set_option: unknown key '%s'", key);
+}
+
 int isdf_create(int device_id, isdf_handle* out) {
   if (!out) return ISDF_ERR_ARG;
   *out = nullptr;

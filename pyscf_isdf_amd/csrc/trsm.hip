@@ -2,14 +2,15 @@
 //
 //   X (m x n, row-major, ldx)  <-  op(L)^-1 X,    L (m x m) lower triangular, row-major, ldl;  op = L | L^T
 //
-// One primitive for every place the ISDF fit applies a Cholesky factor: the per-atom block factors D_b on the
-// (P, G) fit rows and on the (P, P) matrices, and the factor of A' on the (P, P) matrices.  rocBLAS's trsm inverts
-// 128 x 128 diagonal blocks and multiplies; with the factors of nearly singular Gram matrices that loses accuracy in
-// exactly the directions the block-Jacobi route amplifies (measured on the He2 k-point test: K off by 4e-2 against
-// 4e-8 with substitution), and its left/right variants apply *different* approximate inverses, so D^-1 A D^-T and
-// D^-1 B stop being consistent.  Here the diagonal blocks (64 rows) are solved by plain forward/backward substitution,
-// one right-hand side per lane, the triangle read through the scalar cache; everything off the diagonal is rocBLAS
-// dgemm.  Right-sided solves are done as left-sided ones on the transpose.
+// An alternative to rocBLAS dtrsm for every place the ISDF fit applies a Cholesky factor (the per-atom block factors D_b
+// on the (P, G) fit rows and on the (P, P) matrices, the factor of A' on the (P, P) matrices), selected at run time with
+// isdf_set_option(h, "trsm_substitution", 1).  rocBLAS's trsm inverts 128 x 128 diagonal blocks and multiplies; here the
+// diagonal blocks (64 rows) are solved by plain forward/backward substitution, one right-hand side per lane, the triangle
+// read through the scalar cache, and everything off the diagonal is rocBLAS dgemm; right-sided solves are left-sided ones
+// on the transpose.  Measured: the two give the same K to the noise level of the block-Jacobi route on every case tried
+// (He2 test cell, diamond 2x2x2 / 4x4x4), rocBLAS is faster (12.4 s against 12.8 s per step at 4x4x4; many small launches
+// here), so rocBLAS stays the default; this path is what rocprofv3 --pmc runs use (the profiler crashes inside rocBLAS's
+// trsm on 1.7M-column right-hand sides) and a cross-check that does not share rocBLAS's algorithm.
 #include "common.h"
 
 namespace {
@@ -148,4 +149,30 @@ int trsm_lower_right(isdf_handle h, bool trans, int m, int64_t n, const double* 
   rc = trsm_lower_left(h, !trans, m, n, L, ldl, T, n);
   if (rc) return rc;
   return transpose_rm(h, T, n, m, n, X, ldx);
+}
+
+// ---- dispatch ------------------------------------------------------------------------------------------
+// Row-major X (m x n) is the column-major X^T (n x m); the row-major lower L is the column-major upper U = L^T:
+//   L^-1 X   <->  X^T U^-1      L^-T X  <->  X^T U^-T      (rocBLAS side right)
+//   X L^-1   <->  U^-1 X^T      X L^-T  <->  U^-T X^T      (rocBLAS side left)
+int tri_left(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx) {
+  if (h->trsm_substitution) return trsm_lower_left(h, trans, m, n, L, ldl, X, ldx);
+  ARG_CHECK(h, L && X && m > 0 && n > 0 && ldl >= m && ldx >= n && n < 2147483647LL && ldx < 2147483647LL && ldl < 2147483647LL);
+  const double one = 1.0;
+  ProfScope ps(h, "rocblas_dtrsm[flop]", (double)n * m * m);
+  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper,
+                            trans ? rocblas_operation_transpose : rocblas_operation_none, rocblas_diagonal_non_unit,
+                            (rocblas_int)n, m, &one, L, (rocblas_int)ldl, X, (rocblas_int)ldx));
+  return ISDF_OK;
+}
+
+int tri_right(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx) {
+  if (h->trsm_substitution) return trsm_lower_right(h, trans, m, n, L, ldl, X, ldx);
+  ARG_CHECK(h, L && X && m > 0 && n > 0 && ldl >= m && ldx >= m && n < 2147483647LL && ldx < 2147483647LL && ldl < 2147483647LL);
+  const double one = 1.0;
+  ProfScope ps(h, "rocblas_dtrsm[flop]", (double)n * m * m);
+  BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper,
+                            trans ? rocblas_operation_transpose : rocblas_operation_none, rocblas_diagonal_non_unit, m,
+                            (rocblas_int)n, &one, L, (rocblas_int)ldl, X, (rocblas_int)ldx));
+  return ISDF_OK;
 }

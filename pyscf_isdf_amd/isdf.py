@@ -82,6 +82,8 @@ class ISDF:
                                          # 'auto': S3c, verified with probe densities, S3b when the check fails
         self.bj_check_tol = 3e-8         # 'auto': largest accepted relative mismatch of the probe energies (tracks
                                          # max|dK|/|K| of the two routes within a factor of a few, profiles/r01_bj_*)
+        self.bj_auto_kpts = False        # k-points: 'auto' = Cholesky route unless this is set (the fit is < 10 % of a k-point
+                                         # build, and a failed check costs a second pass over all q: MgO 2x2x2 reads 7e-8)
         self.bj_max_c = 12               # 'auto': do not even try S3c above this c_isdf (cond(A') grows ~100x per +5)
         self.bj_nprobe = 8
         self.bj_cluster_radius = 2.4     # Bohr; atoms closer than this share a preconditioner block (X-H bonds)
@@ -294,14 +296,18 @@ class ISDF:
             return ['cholesky']
         return ['blockjacobi', 'cholesky']
 
-    def _bj_probe_mismatch(self, aoT_P, Afac, Dblk, ip_off, Yp, ng, grid_slice):
+    def _bj_probe_mismatch(self, aoT_P, Afac, Dblk, ip_off, Yp, ng, grid_slice, W=None):
         """A-posteriori check of the S3c route: for random symmetric R_j the density t_j = diag(phi_P R_j phi_P^T)
         at the points has the Coulomb energy  t^T W t  through the matrix and  w sum_g f conv(f), f = Theta^T t,
         through the fitted density itself (vector operations only: one pass over Y', nprobe FFTs).  The second form
-        does not see the cond(A')-amplified rounding of M'; their largest relative difference is returned."""
+        does not see the cond(A')-amplified rounding of M'; their largest relative difference is returned.
+        aoT_P: (nao, P), or a list of such planes whose densities are added (k-points: Re/Im u^k at the points, the
+        density sum_k u^k* R u^k with real symmetric R; W = the real plane of W^{q=0})."""
         be, comm = self.backend, self.comm
         cell = self.cell
-        nao, P = aoT_P.shape
+        planes = aoT_P if isinstance(aoT_P, (list, tuple)) else [aoT_P]
+        nao, P = planes[0].shape
+        W = self.W if W is None else W
         n = int(self.bj_nprobe)
         mesh = np.asarray(self.mesh, dtype=np.int32)
         G = int(np.prod(mesh))
@@ -309,12 +315,17 @@ class ISDF:
         rng = np.random.default_rng(20240203)
         R = rng.standard_normal((n, nao, nao))
         R = R + R.transpose(0, 2, 1)
-        T = be.empty((n, P))
-        be.rho(aoT_P, P, be.to_device(R), T)
+        T = be.zeros((n, P))
+        d_R = be.to_device(R)
+        tmp = be.empty((n, P))
+        for pl in planes:
+            be.rho(pl, P, d_R, tmp)
+            T += tmp
+        del tmp
         T0 = T.clone()
         # matrix side: t^T W t
         TW = be.empty((n, P))
-        be.gemm_nt(T0, self.W, TW)
+        be.gemm_nt(T0, W, TW)
         e_mat = np.einsum('jp,jp->j', be.to_host(TW), be.to_host(T0))
         # density side
         F = be.empty((n, ng))
@@ -851,34 +862,12 @@ class ISDF:
         # S3 global fit, forward solve only (Y); the factor is applied to the (P, P) matrices
         Y = self._buffer('theta', (max(P, P_target), G))[:P]
         aoP_X = self._buffer('aoP', (P, 2 * nh))
-        # k-points: the probe check is not implemented for the complex W^q, so 'auto' means the Cholesky route;
-        # fit_route='blockjacobi' is honoured unguarded
-        use_bj = self.fit_route == 'blockjacobi' and not self.explicit_theta and self.select != 'global'
-        self.fit_route_used = 'blockjacobi' if use_bj else 'cholesky'
-        if use_bj:
-            ip_off = self._bj_blocks(rank, clusters)
-            Afac, Dblk = self._bj_prepare(X, nh, ip_dev, ip_off, aoP_X)
-            self._bj_rows(aoP_X, nh, X, G, Dblk, ip_off, Y)
-        else:
-            chol = self._buffer('factor', (P, P))
-            self.reg_used = be.fit_prepare_cplx(X, nh, ip_dev, self.reg_rel, aoP_X, chol)
-            be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=not self.explicit_theta)
-        t0 = self._tick('S3_fit', t0)
-
-        # Bloch AOs at the points: phi^k(r_P) = exp(i k.r_P) u^k(r_P), (P, nao) complex per k
-        uP = be.to_host(aoP_X)                                   # (P, 2 nh)
-        r_ip = coords[self.ip]
-        self._aoP_k = []
-        for k in range(nk):
-            u = uP[:, k * nao:(k + 1) * nao] + 1j * uP[:, nh + k * nao:nh + (k + 1) * nao]
-            self._aoP_k.append(be.to_device(np.ascontiguousarray(u * np.exp(1j * r_ip.dot(kpts[k]))[:, None])))
-
-        # S4 + S5 per q (this rank's share)
+        # q list: W^{-q} = conj(W^q) (Theta is real, coulG_{-q}[-G] = coulG_q[G]): build one of each +-q pair,
+        # the primaries dealt round-robin over the ranks
         self._qs, self._qindex = pbc_tools.unique_q(kpts)
         nq = len(self._qs)
         w = cell.vol / G
         batch = self.fft_batch or max(1, min(P, int((3 << 30) // (8 * G)) // 128 * 128 or 64))
-        # W^{-q} = conj(W^q) (Theta is real, coulG_{-q}[-G] = coulG_q[G]): build one of each +-q pair
         partner = -np.ones(nq, dtype=int)
         for iq in range(nq):
             for jq in range(nq):
@@ -890,25 +879,66 @@ class ISDF:
             self._q_owner[iq] = n % comm.size
             if partner[iq] >= 0:
                 self._q_owner[partner[iq]] = n % comm.size
-        self._Wq = {}
+        r_ip = coords[self.ip]
         Wre = self._buffer('Wre', (P, P))
         Wim = self._buffer('Wim', (P, P))
-        for iq in primary:
-            if self._q_owner[iq] != comm.rank:
-                continue
-            q = self._qs[iq]
-            coulG = be.to_device(pbc_tools.get_coulG(cell, q, mesh))
-            be.coulomb_Wq(Y, mesh, coulG, w, 0, P, batch, Wre, Wim, upper_only=True)
-            be.symmetrize_hermitian(Wre, Wim)
-            if use_bj:
-                self._bj_finish(Afac, Dblk, ip_off, Wre)
-                self._bj_finish(Afac, Dblk, ip_off, Wim, antisymmetric=True)
-            elif not self.explicit_theta:
-                be.W_from_factor(chol, 0, Wre)
-                be.W_from_factor(chol, 0, Wim)
-            Wc = be.empty((P, P), dtype=torch.complex128)
-            be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * r_ip.dot(q))), Wc)
-            self._Wq[iq] = Wc
+
+        # S3 + S4 + S5, route by route.  'auto' means the Cholesky route here unless bj_auto_kpts is set; then: block-
+        # Jacobi, verified on W^{q=0}, Cholesky when the check fails (the fit is replicated, so every rank takes the
+        # agreed decision after its share of the q list)
+        routes = self._fit_routes() if self.select != 'global' else ['cholesky']
+        if self.fit_route == 'auto' and not self.bj_auto_kpts:
+            routes = ['cholesky']
+        for route in routes:
+            if route == 'blockjacobi':
+                ip_off = self._bj_blocks(rank, clusters)
+                Afac, Dblk = self._bj_prepare(X, nh, ip_dev, ip_off, aoP_X)
+                self._bj_rows(aoP_X, nh, X, G, Dblk, ip_off, Y)
+            else:
+                chol = self._buffer('factor', (P, P))
+                self.reg_used = be.fit_prepare_cplx(X, nh, ip_dev, self.reg_rel, aoP_X, chol)
+                be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=not self.explicit_theta)
+            t0 = self._tick('S3_fit', t0)
+            self._Wq = {}
+            check = 0.0
+            for iq in primary:
+                if self._q_owner[iq] != comm.rank:
+                    continue
+                q = self._qs[iq]
+                coulG = be.to_device(pbc_tools.get_coulG(cell, q, mesh))
+                be.coulomb_Wq(Y, mesh, coulG, w, 0, P, batch, Wre, Wim, upper_only=True)
+                be.symmetrize_hermitian(Wre, Wim)
+                if route == 'blockjacobi':
+                    self._bj_finish(Afac, Dblk, ip_off, Wre)
+                    self._bj_finish(Afac, Dblk, ip_off, Wim, antisymmetric=True)
+                    if self.fit_route == 'auto' and abs(q).max() < 1e-9:
+                        # W^0 is real: the Gamma-point probe check with the densities sum_k u^k* R u^k
+                        t1 = self._tick('S4S5_coulomb_W', t0)
+                        planes = [aoP_X[:, o:o + nao].T.contiguous() for o in range(0, 2 * nh, nao)]
+                        check = self._bj_probe_mismatch(planes, Afac, Dblk, ip_off, Y, G, None, W=Wre)
+                        del planes
+                        t0 = self._tick('S5_route_check', t1)
+                elif not self.explicit_theta:
+                    be.W_from_factor(chol, 0, Wre)
+                    be.W_from_factor(chol, 0, Wim)
+                Wc = be.empty((P, P), dtype=torch.complex128)
+                be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * r_ip.dot(q))), Wc)
+                self._Wq[iq] = Wc
+            self.fit_route_used = route
+            if route == 'blockjacobi' and self.fit_route == 'auto':
+                self.bj_check = comm.agree_max(check)
+                if self.bj_check <= self.bj_check_tol:
+                    break
+                warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e); '
+                              'rebuilding the W^q with the Cholesky route' % (self.bj_check, self.bj_check_tol))
+                t0 = self._tick('S4S5_coulomb_W', t0)
+
+        # Bloch AOs at the points: phi^k(r_P) = exp(i k.r_P) u^k(r_P), (P, nao) complex per k
+        uP = be.to_host(aoP_X)                                   # (P, 2 nh)
+        self._aoP_k = []
+        for k in range(nk):
+            u = uP[:, k * nao:(k + 1) * nao] + 1j * uP[:, nh + k * nao:nh + (k + 1) * nao]
+            self._aoP_k.append(be.to_device(np.ascontiguousarray(u * np.exp(1j * r_ip.dot(kpts[k]))[:, None])))
         self._q_partner = partner
         t0 = self._tick('S4S5_coulomb_W', t0)
         self._built = True

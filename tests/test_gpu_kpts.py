@@ -125,8 +125,8 @@ def test_isdf_kpts_end_to_end(select):
 
 
 def test_isdf_kpts_fit_routes_agree():
-    """k-point build: the (opt-in, unguarded) block-Jacobi route and the Cholesky route give the same K on a
-    well-conditioned point set; 'auto' keeps the Cholesky route for k-points."""
+    """k-point build: the block-Jacobi route and the Cholesky route give the same K; with bj_auto_kpts 'auto' verifies the
+    block-Jacobi route on W^{q=0} (real: the Gamma-point probe check with the densities sum_k u^k* R u^k)."""
     from pyscf_isdf_amd.isdf import ISDF
     cell, coords, Ls, rcut, kpts, aos, dms = _setup()
     out = {}
@@ -139,7 +139,22 @@ def test_isdf_kpts_fit_routes_agree():
     assert abs(d).max() < 1e-6 * abs(out['cholesky'][0]).max()
     df = ISDF(cell, kpts=kpts, c_isdf=10, select='local')
     vk = df.get_jk(dms, kpts=kpts, with_j=False)[1]
-    assert df.fit_route == 'auto' and abs(vk - out['cholesky'][0]).max() < 1e-12 * abs(vk).max()
+    assert df.fit_route == 'auto' and df.fit_route_used == 'cholesky'       # k-points: opt-in (bj_auto_kpts)
+    assert abs(vk - out['cholesky'][0]).max() < 1e-12 * abs(vk).max()
+    df = ISDF(cell, kpts=kpts, c_isdf=10, select='local')
+    df.bj_auto_kpts = True
+    vk = df.get_jk(dms, kpts=kpts, with_j=False)[1]
+    assert df.fit_route_used == 'blockjacobi' and 0 < df.bj_check <= df.bj_check_tol
+    assert abs(vk - out['blockjacobi'][0]).max() < 1e-12 * abs(vk).max()
+    df = ISDF(cell, kpts=kpts, c_isdf=10, select='local')
+    df.bj_auto_kpts = True
+    df.bj_check_tol = 1e-14                                  # force the fallback
+    import warnings
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        vk = df.get_jk(dms, kpts=kpts, with_j=False)[1]
+    assert df.fit_route_used == 'cholesky' and len(rec) == 1
+    assert abs(vk - out['cholesky'][0]).max() < 1e-12 * abs(vk).max()
 
 
 def test_select_complex_mode_panel_from_global_memory(be):

@@ -519,10 +519,22 @@ def test_symmetrize_mean_and_probe_rows(be):
 
 
 @pytest.mark.parametrize('m', [1, 63, 64, 65, 130, 515, 1100])
-def test_substitution_trsm_all_variants(be, m):
-    """trsm.hip through isdf_block_solve with one block: left/right, L / L^T, ragged 64-row substitution blocks and
-    512-row panels, odd numbers of right-hand sides and a row stride; and an ill-conditioned factor, where substitution
-    keeps the small backward error that an inversion-based trsm loses."""
+@pytest.mark.parametrize('subst', [0, 1])
+def test_triangular_solves_both_implementations(be, m, subst):
+    """isdf_block_solve with one block through rocBLAS dtrsm (default) and through the substitution blocks of trsm.hip
+    (isdf_set_option "trsm_substitution"): left/right, L / L^T, ragged 64-row blocks and 512-row panels, odd numbers of
+    right-hand sides and a row stride; and the factor of an ill-conditioned Gram matrix (residual at rounding level)."""
+    import scipy.linalg
+    be.set_option('trsm_substitution', subst)
+    try:
+        _check_triangular_solves(be, m)
+    finally:
+        be.set_option('trsm_substitution', 0)
+    with pytest.raises(Exception):
+        be.set_option('no_such_option', 1)
+
+
+def _check_triangular_solves(be, m):
     import scipy.linalg
     rng = np.random.default_rng(m)
     L = np.tril(rng.standard_normal((m, m))) * 0.3 + np.diag(1.0 + rng.random(m))
@@ -664,3 +676,11 @@ def test_block_jacobi_route_end_to_end():
     W_or = oisdf.build_W_blockjacobi(aoT, df.ip, off, cell.lattice_vectors(), cell.mesh, reg_rel=df.reg_rel)
     k_or = oisdf.get_k(np.ascontiguousarray(aoT[:, df.ip].T), W_or, dm)
     assert abs(vk1 - k_or).max() < 1e-8 * abs(k_or).max()
+    # the same build with the substitution solves of trsm.hip instead of rocBLAS dtrsm
+    df.backend.set_option('trsm_substitution', 1)
+    try:
+        df.build()
+        vk2 = df.get_jk(dm, with_j=False)[1]
+    finally:
+        df.backend.set_option('trsm_substitution', 0)
+    assert abs(vk2 - vk1).max() < 1e-7 * abs(vk1).max()
