@@ -209,12 +209,15 @@ def main():
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_bench_cfg3_fetch_write.json')) as f:
                 pmc = json.load(f)
             for k, v in pmc.items():
-                if k.startswith('gemm_nt_mfma_kernel') and 'FETCH_SIZE_KB_per_launch' in v and v['launches'] > 4 \
+                fetch = v.get('FETCH_SIZE_per_launch', v.get('FETCH_SIZE_KB_per_launch'))     # counter unit: KB
+                write = v.get('WRITE_SIZE_per_launch', v.get('WRITE_SIZE_KB_per_launch'))
+                if k.startswith('gemm_nt_mfma_kernel') and fetch is not None and write is not None and v['launches'] > 4 \
                         and args.workload == 'diamond-444-dzvp-120' and world == 1:
-                    traffic = dict(bytes_per_launch=round((2 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024),
+                    traffic = dict(bytes_per_launch=round((2 * fetch + write) * 1024),
                                    algorithmic_bytes_per_launch=round(8.0 * (512 + 8320 + 256) * 1728000),
-                                   source='profiles/r01_pmc_bench_cfg3_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
-                                          'FETCH x2 per MI355X_MICROARCH.md; counts fabric requests incl. Infinity-Cache hits)')
+                                   source='profiles/r01_pmc_bench_cfg3_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in '
+                                          'separate passes of this command with ISDF_TRSM=subst, tools/pmc_summarise.py; FETCH x2 per '
+                                          'MI355X_MICROARCH.md; counts fabric requests incl. Infinity-Cache hits)')
         except (OSError, KeyError, ValueError):
             pass
         if dom['unit'] == 'TFLOP/s':
