@@ -76,6 +76,7 @@ class ISDF:
         self.reg_rel = 1e-12             # relative diagonal shift of A_PP in the global fit
         self.reg_used = 0.0
         self.k_ip_factor = None           # k-points: points = c_isdf * nao * k_ip_factor (default min(nk, 2))
+        self.kpts_band = None             # band k-points of the last k-point build (set by get_jk(kpts_band=...))
         self.force_sharded = False       # run the multi-GPU code path even on one rank (tests)
         self.fit_route = 'auto'          # 'cholesky': forward solve over the grid (S3b), always safe;
                                          # 'blockjacobi': no solve over the grid (S3c), amplifies rounding by cond(A');
@@ -368,7 +369,7 @@ class ISDF:
 
     def build(self):
         self.check_sanity()
-        if not self._is_gamma(self.kpts):
+        if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
             return self._build_kpts()
         if self.comm.size > 1 or self.force_sharded:
             return self._build_sharded()
@@ -502,10 +503,13 @@ class ISDF:
             raise NotImplementedError('range-separated Coulomb kernel (omega) is not implemented for ISDF')
         if kpts is None:
             kpts = self.kpts
-        if not self._is_gamma(kpts) or not self._is_gamma(self.kpts):
+        if not self._is_gamma(kpts) or not self._is_gamma(self.kpts) or not self._is_gamma(kpts_band):
+            if self._is_gamma(kpts) and np.asarray(dm).ndim == 2:
+                dm = np.asarray(dm)[None]                       # Gamma-point density, band structure requested
             return self._get_jk_kpts(dm, hermi, kpts, kpts_band, with_j, with_k, exxdiv)
-        if not self._is_gamma(kpts_band):
-            raise NotImplementedError('band k-points on a Gamma-point ISDF object are not implemented')
+        if self.kpts_band is not None:                          # back from a band calculation: Gamma-only build again
+            self.kpts_band = None
+            self._built = False
         if exxdiv is None:
             exxdiv = self.exxdiv
         if exxdiv not in (None, 'None', 'ewald'):
@@ -808,8 +812,20 @@ class ISDF:
         cell, be, comm = self.cell, self.backend, self.comm
         self.timings = {}
         t0 = time.perf_counter()
-        kpts = np.asarray(self.kpts, dtype=float).reshape(-1, 3)
-        nk = len(kpts)
+        kpts_scf = np.asarray(self.kpts, dtype=float).reshape(-1, 3)
+        # band k-points (kpts_band of get_jk) join the stack: the fit must also represent conj(u^{kb}) u^{k}
+        band = kpts_scf if self.kpts_band is None else np.asarray(self.kpts_band, dtype=float).reshape(-1, 3)
+        kall = [k for k in kpts_scf]
+        self._band_index = []
+        for kb in band:
+            hit = [i for i, k in enumerate(kall) if abs(k - kb).max() < 1e-9]
+            if hit:
+                self._band_index.append(hit[0])
+            else:
+                kall.append(kb)
+                self._band_index.append(len(kall) - 1)
+        kpts = np.array(kall)
+        nk = len(kpts)                       # size of the stack; the first len(kpts_scf) entries carry density
         mesh = np.asarray(self.mesh, dtype=np.int32)
         G = int(np.prod(mesh))
         nao = cell.nao_nr()
@@ -864,7 +880,7 @@ class ISDF:
         aoP_X = self._buffer('aoP', (P, 2 * nh))
         # q list: W^{-q} = conj(W^q) (Theta is real, coulG_{-q}[-G] = coulG_q[G]): build one of each +-q pair,
         # the primaries dealt round-robin over the ranks
-        self._qs, self._qindex = pbc_tools.unique_q(kpts)
+        self._qs, self._qindex = pbc_tools.unique_q(kpts_scf, band)      # index[k1 in band][k2 in kpts]
         nq = len(self._qs)
         w = cell.vol / G
         batch = self.fft_batch or max(1, min(P, int((3 << 30) // (8 * G)) // 128 * 128 or 64))
@@ -942,24 +958,38 @@ class ISDF:
         self._q_partner = partner
         t0 = self._tick('S4S5_coulomb_W', t0)
         self._built = True
-        self._k_built = kpts.copy()
+        self._k_built = kpts_scf.copy()
+        self._band_built = None if self.kpts_band is None else band.copy()
+        self._nk_stack = nk
         return self
 
     def _get_jk_kpts(self, dm, hermi, kpts, kpts_band, with_j, with_k, exxdiv):
-        if kpts_band is not None:
-            raise NotImplementedError('kpts_band for the k-point ISDF path is not implemented in this round')
+        """k-point J and K (pyscf/pbc/df/fft_jk.py:33-109,177-302 semantics).  dm (nk, N, N) or (nset, nk, N, N); with
+        kpts_band the result lives on the band k-points, (nband, N, N) [(N, N) for a single (3,) band vector], as
+        df_jk._format_jks shapes it (pyscf/pbc/df/df_jk.py:1426-1444)."""
         ex = exxdiv if exxdiv is not None else self.exxdiv
         if ex not in (None, 'None', 'ewald'):
             raise NotImplementedError("k-point ISDF: only exxdiv=None and 'ewald' are implemented")
         cell, be, comm = self.cell, self.backend, self.comm
         kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
-        if not self._built or getattr(self, '_k_built', None) is None or kpts.shape != self._k_built.shape \
-                or abs(kpts - self._k_built).max() > 1e-9:
+        band_in = None if kpts_band is None else np.asarray(kpts_band, dtype=float)
+        band = None if band_in is None else band_in.reshape(-1, 3)
+
+        def same(x, y):
+            if x is None or y is None:
+                return x is None and y is None
+            return x.shape == y.shape and abs(x - y).max() < 1e-9
+        if not self._built or getattr(self, '_k_built', None) is None or not same(kpts, self._k_built) \
+                or not same(band, getattr(self, '_band_built', None)):
             self.kpts = kpts
+            self.kpts_band = band
             self.build()
         nk = len(kpts)
+        nks = self._nk_stack                                     # k-points in the stacked periodic parts
+        bidx = list(range(nk)) if band is None else list(self._band_index)
+        nband = len(bidx)
         nao = cell.nao_nr()
-        nh = nk * nao
+        nh = nks * nao
         dm_in = np.asarray(dm)
         dms = np.asarray(dm_in, dtype=np.complex128).reshape(-1, nk, nao, nao)
         nset = dms.shape[0]
@@ -970,56 +1000,62 @@ class ISDF:
         G = int(np.prod(mesh))
         a = np.asarray(cell.lattice_vectors(), dtype=float)
         X = self.ao
+
+        def planes(k):
+            return X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao]
+        out_shape = dm_in.shape if band is None else \
+            (dm_in.shape[:-3] + ((nband,) if band_in.ndim > 1 else ()) + (nao, nao))
         vj = vk = None
         t0 = time.perf_counter()
         if with_j:
-            vj = np.zeros((nset, nk, nao, nao), dtype=np.complex128)
+            vj = np.zeros((nset, nband, nao, nao), dtype=np.complex128)
             for s in range(nset):
                 rho = be.zeros((1, G))
                 for k in range(nk):
                     dT = dms[s, k].T
-                    be.rho_k(X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao], G,
-                             be.to_device(np.ascontiguousarray(dT.real)), be.to_device(np.ascontiguousarray(dT.imag)),
-                             1.0 / nk, rho)
+                    be.rho_k(*planes(k), G, be.to_device(np.ascontiguousarray(dT.real)),
+                             be.to_device(np.ascontiguousarray(dT.imag)), 1.0 / nk, rho)
                 be.coulomb_potential(rho, mesh, a)
-                for k in range(nk):
+                for ib, kb in enumerate(bidx):
                     vre = be.empty((nao, nao))
                     vim = be.empty((nao, nao))
-                    be.vj_k(X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao], G, rho, vre, vim)
-                    vj[s, k] = be.to_host(vre) + 1j * be.to_host(vim)
+                    be.vj_k(*planes(kb), G, rho, vre, vim)
+                    vj[s, ib] = be.to_host(vre) + 1j * be.to_host(vim)
             t0 = self._tick('S6_get_j', t0)
-            vj = vj.reshape(dm_in.shape)
+            vj = vj.reshape(out_shape)
         if with_k:
-            d_vk = be.zeros((nset, nk, nao, nao), dtype=torch.complex128)
+            d_vk = be.zeros((nset, nband, nao, nao), dtype=torch.complex128)
             for s in range(nset):
                 d_dm = [be.to_device(np.ascontiguousarray(dms[s, k])) for k in range(nk)]
-                for k1 in range(nk):
+                for i1, k1 in enumerate(bidx):
                     for k2 in range(nk):
-                        iq = self._qindex[k1, k2]
+                        iq = self._qindex[i1, k2]
                         if self._q_owner[iq] != comm.rank:
                             continue
                         if iq in self._Wq:
                             Wq = self._Wq[iq]
                         else:                      # stored as its time-reversal partner: W^{-q} = conj(W^q)
                             Wq = torch.conj_physical(self._Wq[self._q_partner[iq]])
-                        be.get_k_pair(self._aoP_k[k1], self._aoP_k[k2], d_dm[k2], Wq, 1.0 / nk, d_vk[s, k1])
+                        be.get_k_pair(self._aoP_k[k1], self._aoP_k[k2], d_dm[k2], Wq, 1.0 / nk, d_vk[s, i1])
             if comm.size > 1:
                 flat = torch.view_as_real(d_vk)
                 comm.all_reduce_sum(flat)
             vk = be.to_host(d_vk)
             if ex == 'ewald':
-                # vk[k] += madelung * S^k D^k S^k (pyscf/pbc/df/df_jk.py:1446-1465); S^k by quadrature on the
-                # grid from the periodic parts (the Bloch phases cancel)
+                # vk[k] += madelung * S^k D^k S^k (pyscf/pbc/df/df_jk.py:1446-1465) for the band k-points that are
+                # k-points of the density; S^k by quadrature on the grid from the periodic parts (the phases cancel)
                 mad = gto.madelung(cell, _monkhorst_pack_size(cell, kpts))
                 w_const = be.to_device(np.full((1, G), cell.vol / G))
-                for k in range(nk):
+                for ib, kb in enumerate(bidx):
+                    if kb >= nk:
+                        continue
                     sre, sim = be.empty((nao, nao)), be.empty((nao, nao))
-                    be.vj_k(X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao], G, w_const, sre, sim)
+                    be.vj_k(*planes(kb), G, w_const, sre, sim)
                     Sk = be.to_host(sre) + 1j * be.to_host(sim)
                     for s in range(nset):
-                        vk[s, k] += mad * Sk.dot(dms[s, k]).dot(Sk)
+                        vk[s, ib] += mad * Sk.dot(dms[s, kb]).dot(Sk)
             t0 = self._tick('S7_get_k', t0)
-            vk = vk.reshape(dm_in.shape)
+            vk = vk.reshape(out_shape)
         return vj, vk
 
     # ---- ERIs from the factorisation (small systems; reached from SCF.get_jk's incore branch,

@@ -56,3 +56,31 @@ def test_kisdf_band_kpoints_and_interpolation_property():
     Ws = [kisdf.build_Wq(theta, a, mesh, q, coords[piv]) for q in qs]
     vk = kisdf.get_k_kpts([ao[piv] for ao in aos], Ws, qidx, dms, aoP_band=[ao_b[0][piv]])
     assert abs(vk - vk_ref).max() < 1e-5 * abs(vk_ref).max()             # 300 points: fitting error, not full rank
+
+
+def test_kpts_band_host_logic_with_checker_backend():
+    """get_jk(kpts, kpts_band) through the host driver (no GPU): band k-points join the stacked periodic parts, q = k2 - kb,
+    result shapes as df_jk._format_jks (df_jk.py:1426-1444); converges to the reference's constant for this call
+    (pyscf/pbc/df/test/test_fft.py:663-676) as the point set grows."""
+    import cells
+    from oracle_backend import OracleBackend
+    from oracle import pbc_tools as otools
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    np.random.seed(1)
+    kpts = np.random.random((4, 3))
+    kpts[3] = kpts[0] - kpts[1] + kpts[2]
+    np.random.seed(1)
+    kpts_band = np.random.random((2, 3))
+    nao, nk = cell.nao_nr(), 4
+    mo_coeff = np.random.random((nk, nao, nao))
+    mo_occ = np.array(np.random.random((nk, nao)) > .6, dtype=np.double)
+    dms = np.einsum('kpi,ki,kqi->kpq', mo_coeff, mo_occ, mo_coeff)
+    df = ISDF(cell, kpts=kpts, c_isdf=20, select='global', backend=OracleBackend())
+    df.select_tol = 0.0
+    df.k_ip_factor = 2
+    vj, vk = df.get_jk(dms, kpts=kpts, kpts_band=kpts_band)
+    assert vj.shape == vk.shape == (2, nao, nao) and df._nk_stack == 4          # the band points are k-points here
+    assert abs(otools.fp(vk) - (10.239828255099447 + 2.1190549216896182j)) < 1e-4
+    v1j, v1k = df.get_jk(dms, kpts=kpts, kpts_band=np.array([0.1, 0.2, 0.3]), with_j=False)
+    assert v1j is None and v1k.shape == (nao, nao) and df._nk_stack == 5
