@@ -189,49 +189,11 @@ extern "C" int isdf_fit_apply_cplx(isdf_handle h, const double* d_chol, const do
                        d_theta, (int64_t)P, ng, ldt);
   }
   KERNEL_CHECK(h);
-  // Theta = A^-1 B with A = Lr Lr^T (Lr = the factor read row-major, lower).  Blocked LEFT-looking
-  // triangular solves: block row jb first receives the contribution of all finished block rows in
-  // ONE deep GEMM (NB x ng x K, K up to P: the shape rocBLAS runs at the MFMA rate, and it only
-  // READS the finished rows), then a small TRSM with the diagonal block.  A monolithic rocBLAS TRSM
-  // reaches ~43 TF/s here (profiles/r01_probe_rocblas_hipfft_mfma64.log), a right-looking variant is
-  // bound by re-reading and re-writing the trailing rows at every step.
-  const double one = 1.0;
-  int NB = 1024;
-  if (const char* e = getenv("ISDF_TRSM_NB")) NB = std::max(64, atoi(e));
-  const int nblk = (int)cdiv(P, NB);
-  // forward: Y = Lr^-1 B
-  for (int b = 0; b < nblk; ++b) {
-    const int jb = b * NB;
-    const int nb = std::min(NB, P - jb);
-    if (jb > 0) {
-      // B[jb:jb+nb] -= Lr[jb:jb+nb, :jb] Y[:jb]
-      rc = gemm_rm(h, 'N', 'N', nb, ng, jb, -1.0, d_chol + (int64_t)jb * P, P, d_theta, ldt, 1.0,
-                   d_theta + (int64_t)jb * ldt, ldt);
-      if (rc) return rc;
-    }
-    ProfScope ps(h, "rocblas_dtrsm[flop]", (double)ng * nb * nb);
-    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
-                              rocblas_diagonal_non_unit, (rocblas_int)ng, nb, &one,
-                              d_chol + (int64_t)jb * P + jb, P, d_theta + (int64_t)jb * ldt, (rocblas_int)ldt));
-  }
-  if (forward_only) return ISDF_OK;   // caller wants Y = Lr^-1 B (see isdf_W_from_factor)
-  // backward: Theta = Lr^-T Y
-  for (int b = nblk - 1; b >= 0; --b) {
-    const int jb = b * NB;
-    const int nb = std::min(NB, P - jb);
-    const int j1 = jb + nb;
-    if (j1 < P) {
-      // Y[jb:j1] -= Lr[j1:, jb:j1]^T Theta[j1:]
-      rc = gemm_rm(h, 'T', 'N', nb, ng, P - j1, -1.0, d_chol + (int64_t)j1 * P + jb, P,
-                   d_theta + (int64_t)j1 * ldt, ldt, 1.0, d_theta + (int64_t)jb * ldt, ldt);
-      if (rc) return rc;
-    }
-    ProfScope ps(h, "rocblas_dtrsm[flop]", (double)ng * nb * nb);
-    BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_transpose,
-                              rocblas_diagonal_non_unit, (rocblas_int)ng, nb, &one,
-                              d_chol + (int64_t)jb * P + jb, P, d_theta + (int64_t)jb * ldt, (rocblas_int)ldt));
-  }
-  return ISDF_OK;
+  // Theta = A^-1 B with A = Lr Lr^T (Lr = the factor read row-major, lower): forward solve Y = Lr^-1 B, then (unless the
+  // caller wants Y, see isdf_W_from_factor) the backward solve Theta = Lr^-T Y; blocked left-looking (trsm.hip: tri_left)
+  rc = tri_left(h, false, P, ng, d_chol, P, d_theta, ldt);
+  if (rc || forward_only) return rc;
+  return tri_left(h, true, P, ng, d_chol, P, d_theta, ldt);
 }
 
 extern "C" int isdf_fit_global(isdf_handle h, const double* d_ao, int nao, int64_t ngrids, int64_t ld,
@@ -350,6 +312,38 @@ __global__ void copy_block_kernel(const double* __restrict__ A, int P, int off, 
   if (c >= nb) return;
   D[(int64_t)(off + r) * P + off + c] = A[(int64_t)(off + r) * P + off + c];
 }
+// F (n <= 8 rows, ng) = E (n, P) * Y (P, ng): one grid column per lane, the P-long dot products streamed row by row
+// (every load of a wave is one coalesced 512-byte row segment); E staged through LDS in 64-row pieces.  HBM-bound:
+// reads Y once.  (rocBLAS dgemm with M = 8 moves the same bytes at under 1 TB/s.)
+__global__ __launch_bounds__(256) void skinny_rows_kernel(const double* __restrict__ E, int n, int P,
+                                                          const double* __restrict__ Y, int64_t ldy, int64_t ng,
+                                                          double* __restrict__ F, int64_t ldf) {
+  __shared__ double sE[8][64];
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = g < ng;
+  double acc[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+  for (int p0 = 0; p0 < P; p0 += 64) {
+    const int np = min(64, P - p0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < 8 * 64; t += 256) {
+      const int j = t >> 6, pp = t & 63;
+      sE[j][pp] = (j < n && pp < np) ? E[(int64_t)j * P + p0 + pp] : 0.0;
+    }
+    __syncthreads();
+    if (live) {
+      const double* y = Y + (int64_t)p0 * ldy + g;
+#pragma unroll 8
+      for (int pp = 0; pp < np; ++pp) {
+        const double v = y[(int64_t)pp * ldy];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fma(sE[j][pp], v, acc[j]);
+      }
+    }
+  }
+  if (live)
+    for (int j = 0; j < n; ++j) F[(int64_t)j * ldf + g] = acc[j];
+}
+
 __global__ void add_diag_const_kernel(double* __restrict__ A, int n, int64_t ld, double v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) A[(int64_t)i * ld + i] += v;
@@ -492,7 +486,12 @@ extern "C" int isdf_bj_probe_rows(isdf_handle h, double* d_T, int n, const doubl
   if (rc) return rc;
   rc = tri_right(h, false, P, n, d_fac, P, d_T, P);
   if (rc) return rc;
-  return gemm_rm(h, 'N', 'N', n, ng, P, 1.0, d_T, P, d_Yp, ldy, 0.0, d_F, ldf);
+  if (n > 8) return gemm_rm(h, 'N', 'N', n, ng, P, 1.0, d_T, P, d_Yp, ldy, 0.0, d_F, ldf);
+  ProfScope ps(h, "skinny_rows_kernel[byte]", 8.0 * (double)P * (double)ng);
+  hipLaunchKernelGGL(skinny_rows_kernel, dim3((unsigned)cdiv(ng, 256)), dim3(256), 0, h->stream, d_T, n, P, d_Yp, ldy, ng, d_F,
+                     ldf);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
 }
 
 extern "C" int isdf_gather_aoP(isdf_handle h, const double* d_ao, int nao, int64_t ld, const int64_t* d_ip, int P,

@@ -12,6 +12,7 @@
 // here), so rocBLAS stays the default; this path is what rocprofv3 --pmc runs use (the profiler crashes inside rocBLAS's
 // trsm on 1.7M-column right-hand sides) and a cross-check that does not share rocBLAS's algorithm.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -155,9 +156,13 @@ int trsm_lower_right(isdf_handle h, bool trans, int m, int64_t n, const double* 
 // Row-major X (m x n) is the column-major X^T (n x m); the row-major lower L is the column-major upper U = L^T:
 //   L^-1 X   <->  X^T U^-1      L^-T X  <->  X^T U^-T      (rocBLAS side right)
 //   X L^-1   <->  U^-1 X^T      X L^-T  <->  U^-T X^T      (rocBLAS side left)
-int tri_left(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx) {
-  if (h->trsm_substitution) return trsm_lower_left(h, trans, m, n, L, ldl, X, ldx);
-  ARG_CHECK(h, L && X && m > 0 && n > 0 && ldl >= m && ldx >= n && n < 2147483647LL && ldx < 2147483647LL && ldl < 2147483647LL);
+namespace {
+int trsm_block_size() {
+  static const int nb = getenv("ISDF_TRSM_NB") ? std::max(64, atoi(getenv("ISDF_TRSM_NB"))) : 1024;
+  return nb;
+}
+// one rocBLAS dtrsm, column-major view (see the table above)
+int rb_left(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx) {
   const double one = 1.0;
   ProfScope ps(h, "rocblas_dtrsm[flop]", (double)n * m * m);
   BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_right, rocblas_fill_upper,
@@ -165,14 +170,81 @@ int tri_left(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64
                             (rocblas_int)n, m, &one, L, (rocblas_int)ldl, X, (rocblas_int)ldx));
   return ISDF_OK;
 }
-
-int tri_right(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx) {
-  if (h->trsm_substitution) return trsm_lower_right(h, trans, m, n, L, ldl, X, ldx);
-  ARG_CHECK(h, L && X && m > 0 && n > 0 && ldl >= m && ldx >= m && n < 2147483647LL && ldx < 2147483647LL && ldl < 2147483647LL);
+int rb_right(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx) {
   const double one = 1.0;
   ProfScope ps(h, "rocblas_dtrsm[flop]", (double)n * m * m);
   BLAS_TRY(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_upper,
                             trans ? rocblas_operation_transpose : rocblas_operation_none, rocblas_diagonal_non_unit, m,
                             (rocblas_int)n, &one, L, (rocblas_int)ldl, X, (rocblas_int)ldx));
+  return ISDF_OK;
+}
+}  // namespace
+
+// Large factors are solved block row by block row (LEFT-looking): block jb first receives the contribution of all
+// finished blocks in ONE deep dgemm (the shape rocBLAS runs at the MFMA rate, and it only reads finished rows), then a
+// small dtrsm with the diagonal block.  A monolithic rocBLAS trsm reaches 25-43 TF/s on these shapes, this form ~55-65.
+int tri_left(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx) {
+  if (h->trsm_substitution) return trsm_lower_left(h, trans, m, n, L, ldl, X, ldx);
+  ARG_CHECK(h, L && X && m > 0 && n > 0 && ldl >= m && ldx >= n && n < 2147483647LL && ldx < 2147483647LL && ldl < 2147483647LL);
+  const int NB = trsm_block_size();
+  if (m <= NB) return rb_left(h, trans, m, n, L, ldl, X, ldx);
+  const int nblk = (int)cdiv(m, NB);
+  int rc;
+  if (!trans) {
+    for (int b = 0; b < nblk; ++b) {
+      const int jb = b * NB, nb = std::min(NB, m - jb);
+      if (jb > 0) {   // X[jb:jb+nb] -= L[jb:jb+nb, :jb] X[:jb]
+        rc = gemm_rm(h, 'N', 'N', nb, n, jb, -1.0, L + (int64_t)jb * ldl, ldl, X, ldx, 1.0, X + (int64_t)jb * ldx, ldx);
+        if (rc) return rc;
+      }
+      rc = rb_left(h, false, nb, n, L + (int64_t)jb * ldl + jb, ldl, X + (int64_t)jb * ldx, ldx);
+      if (rc) return rc;
+    }
+  } else {
+    for (int b = nblk - 1; b >= 0; --b) {
+      const int jb = b * NB, nb = std::min(NB, m - jb), j1 = jb + nb;
+      if (j1 < m) {   // X[jb:j1] -= L[j1:, jb:j1]^T X[j1:]
+        rc = gemm_rm(h, 'T', 'N', nb, n, m - j1, -1.0, L + (int64_t)j1 * ldl + jb, ldl, X + (int64_t)j1 * ldx, ldx, 1.0,
+                     X + (int64_t)jb * ldx, ldx);
+        if (rc) return rc;
+      }
+      rc = rb_left(h, true, nb, n, L + (int64_t)jb * ldl + jb, ldl, X + (int64_t)jb * ldx, ldx);
+      if (rc) return rc;
+    }
+  }
+  return ISDF_OK;
+}
+
+// X (n x m) <- X op(L)^-1, block column by block column with the same left-looking idea
+int tri_right(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx) {
+  if (h->trsm_substitution) return trsm_lower_right(h, trans, m, n, L, ldl, X, ldx);
+  ARG_CHECK(h, L && X && m > 0 && n > 0 && ldl >= m && ldx >= m && n < 2147483647LL && ldx < 2147483647LL && ldl < 2147483647LL);
+  const int NB = trsm_block_size();
+  if (m <= NB) return rb_right(h, trans, m, n, L, ldl, X, ldx);
+  const int nblk = (int)cdiv(m, NB);
+  int rc;
+  if (!trans) {
+    // X L^-1: columns from the last block to the first; X[:, jb:j1] -= X[:, j1:] L[j1:, jb:j1]
+    for (int b = nblk - 1; b >= 0; --b) {
+      const int jb = b * NB, nb = std::min(NB, m - jb), j1 = jb + nb;
+      if (j1 < m) {
+        rc = gemm_rm(h, 'N', 'N', n, nb, m - j1, -1.0, X + j1, ldx, L + (int64_t)j1 * ldl + jb, ldl, 1.0, X + jb, ldx);
+        if (rc) return rc;
+      }
+      rc = rb_right(h, false, nb, n, L + (int64_t)jb * ldl + jb, ldl, X + jb, ldx);
+      if (rc) return rc;
+    }
+  } else {
+    // X L^-T: columns from the first block on; X[:, jb:j1] -= X[:, :jb] L[jb:j1, :jb]^T
+    for (int b = 0; b < nblk; ++b) {
+      const int jb = b * NB, nb = std::min(NB, m - jb);
+      if (jb > 0) {
+        rc = gemm_rm(h, 'N', 'T', n, nb, jb, -1.0, X, ldx, L + (int64_t)jb * ldl, ldl, 1.0, X + jb, ldx);
+        if (rc) return rc;
+      }
+      rc = rb_right(h, true, nb, n, L + (int64_t)jb * ldl + jb, ldl, X + jb, ldx);
+      if (rc) return rc;
+    }
+  }
   return ISDF_OK;
 }

@@ -313,11 +313,15 @@ class ISDF:
         mesh = np.asarray(self.mesh, dtype=np.int32)
         G = int(np.prod(mesh))
         a = np.asarray(cell.lattice_vectors(), dtype=float)
-        rng = np.random.default_rng(20240203)
-        R = rng.standard_normal((n, nao, nao))
-        R = R + R.transpose(0, 2, 1)
+        # the probe matrices R_j (random symmetric, fixed seed) are kept on the device: drawing n nao^2 normals
+        # costs 0.2 s at nao = 1664
+        cached = getattr(self, '_probe_R', None)
+        if cached is None or cached[0] != (n, nao):
+            rng = np.random.default_rng(20240203)
+            R = rng.standard_normal((n, nao, nao))
+            self._probe_R = ((n, nao), be.to_device(R + R.transpose(0, 2, 1)))
+        d_R = self._probe_R[1]
         T = be.zeros((n, P))
-        d_R = be.to_device(R)
         tmp = be.empty((n, P))
         for pl in planes:
             be.rho(pl, P, d_R, tmp)

@@ -488,10 +488,14 @@ def test_symmetrize_mean_and_probe_rows(be):
         d = be.to_device(M)
         be.symmetrize_mean(d, antisymmetric=True)
         assert np.array_equal(be.to_host(d), (M - M.T) / 2)
+    _check_probe_rows_and_factor_solve(be, rng, 37, 5, 90, np.array([0, 12, 12, 30, 37], dtype=np.int32))
+    _check_probe_rows_and_factor_solve(be, rng, 301, 8, 1003, np.array([0, 100, 170, 301], dtype=np.int32))   # skinny kernel:
+    _check_probe_rows_and_factor_solve(be, rng, 130, 11, 700, np.array([0, 65, 130], dtype=np.int32))        # ragged; n > 8 -> dgemm
+
+
+def _check_probe_rows_and_factor_solve(be, rng, P, n, ng, off):
     # probe rows: T <- A'^-1 D^-1 t (A' = D^-1 A D^-T), F = T Y'
-    P, n, ng = 37, 5, 90
-    off = np.array([0, 12, 12, 30, 37], dtype=np.int32)
-    Z = rng.standard_normal((P, 80))
+    Z = rng.standard_normal((P, 2 * P))
     A = Z.dot(Z.T) + 0.5 * np.eye(P)
     D = be.empty((P, P))
     dA = be.to_device(A)
@@ -500,7 +504,7 @@ def test_symmetrize_mean_and_probe_rows(be):
     Ap = be.to_host(dA)
     be.chol_inplace(dA, 0.0)
     Dh = np.zeros((P, P))
-    for b in range(4):
+    for b in range(len(off) - 1):
         sl = slice(off[b], off[b + 1])
         Dh[sl, sl] = np.linalg.cholesky(A[sl, sl]) if sl.stop > sl.start else 0
     T = rng.standard_normal((n, P)); Y = rng.standard_normal((P, ng))
