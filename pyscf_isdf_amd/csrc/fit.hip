@@ -402,6 +402,11 @@ extern "C" int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nbl
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_D && d_X && blk_off && P > 0 && nblk > 0 && n > 0 && (side == 0 || side == 1) && (trans == 0 || trans == 1));
   ARG_CHECK(h, n < 2147483647LL && ldx < 2147483647LL);
+  if (side == 0 && trans == 0 && !h->trsm_substitution) {
+    // the hot one (Y' = D^-1 B over the whole grid): all blocks in one launch of the hand-written kernel
+    ARG_CHECK(h, blk_off[0] == 0 && blk_off[nblk] == P);
+    return block_forward_solve(h, d_D, P, nblk, blk_off, d_X, ldx, n);
+  }
   for (int b = 0; b < nblk; ++b) {
     const int off = blk_off[b], nb = blk_off[b + 1] - off;
     if (nb <= 0) continue;

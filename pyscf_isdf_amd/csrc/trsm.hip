@@ -71,6 +71,58 @@ __global__ void transpose_kernel(const double* __restrict__ src, int64_t lds, in
   }
 }
 
+// Block-diagonal forward solve over many columns in ONE launch:  X[blk_b, :] <- D_b^-1 X[blk_b, :]  for every block b
+// (D_b row-major lower, leading dimension ldd, at D + off_b * ldd + off_b).  One grid column per lane, 64-row sub-blocks
+// in registers; the sub-block's coupling to the finished sub-blocks of the same block is applied by re-reading their
+// rows (written by this very lane a moment ago: L2), eight at a time, against rows of D_b that every lane shares and
+// that therefore come through the scalar cache; then forward substitution with the diagonal tile, as subst_kernel.
+// HBM traffic = one read and one write of X (rocBLAS dtrsm block by block moves the same data at about 1 TB/s).
+__global__ __launch_bounds__(256) void block_forward_kernel(const double* __restrict__ D, int64_t ldd,
+                                                            const int32_t* __restrict__ blk_off,
+                                                            double* __restrict__ X, int64_t ldx, int64_t n) {
+  const int b = blockIdx.y;
+  const int off = blk_off[b], m = blk_off[b + 1] - off;
+  if (m <= 0) return;
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  const double* Db = D + (int64_t)off * ldd + off;
+  double* Xb = X + (int64_t)off * ldx + c;
+  const int nsub = (m + 63) >> 6;
+  double x[SB];
+  for (int j = 0; j < nsub; ++j) {
+    const int nbj = min(SB, m - j * SB);
+    const double* Lj = Db + (int64_t)(j * SB) * ldd;        // rows of sub-block j
+#pragma unroll
+    for (int q = 0; q < SB; ++q) x[q] = (q < nbj) ? Xb[(int64_t)(j * SB + q) * ldx] : 0.0;
+    for (int r0 = 0; r0 < j * SB; r0 += 8) {               // finished rows of this block, eight at a time
+      double v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = Xb[(int64_t)(r0 + t) * ldx];
+#pragma unroll
+      for (int q = 0; q < SB; ++q) {
+        if (q < nbj) {
+          const double* Lq = Lj + (int64_t)q * ldd + r0;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) x[q] = fma(-Lq[t], v[t], x[q]);
+        }
+      }
+    }
+    const double* Ld = Lj + j * SB;                          // diagonal tile
+#pragma unroll
+    for (int q = 0; q < SB; ++q) {
+      if (q < nbj) {
+        double s_ = x[q];
+#pragma unroll
+        for (int k = 0; k < q; ++k) s_ = fma(-Ld[(int64_t)q * ldd + k], x[k], s_);
+        x[q] = s_ / Ld[(int64_t)q * ldd + q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < SB; ++q)
+      if (q < nbj) Xb[(int64_t)(j * SB + q) * ldx] = x[q];
+  }
+}
+
 int subst(isdf_handle h, bool trans, const double* L, int64_t ldl, int nb, double* X, int64_t ldx, int64_t n) {
   ProfScope ps(h, trans ? "trsm_subst_kernel<true>[flop]" : "trsm_subst_kernel<false>[flop]", (double)nb * nb * (double)n);
   const dim3 grid((unsigned)cdiv(n, 256));
@@ -81,6 +133,22 @@ int subst(isdf_handle h, bool trans, const double* L, int64_t ldl, int nb, doubl
 }
 
 }  // namespace
+
+int block_forward_solve(isdf_handle h, const double* D, int64_t ldd, int nblk, const int32_t* blk_off_host, double* X,
+                        int64_t ldx, int64_t n) {
+  ARG_CHECK(h, D && X && blk_off_host && nblk > 0 && n > 0 && nblk <= 65535);
+  int32_t* d_off = (int32_t*)isdf_ws(h, "trsm_blk_off", sizeof(int32_t) * (size_t)(nblk + 1));
+  if (!d_off) return ISDF_ERR_HIP;
+  HIP_TRY(h, hipMemcpyAsync(d_off, blk_off_host, sizeof(int32_t) * (size_t)(nblk + 1), hipMemcpyHostToDevice, h->stream));
+  double rows2 = 0.0;
+  for (int b = 0; b < nblk; ++b) rows2 += (double)(blk_off_host[b + 1] - blk_off_host[b]) * (blk_off_host[b + 1] - blk_off_host[b]);
+  ProfScope ps(h, "block_forward_kernel[byte]", 16.0 * (double)blk_off_host[nblk] * (double)n);
+  (void)rows2;
+  hipLaunchKernelGGL(block_forward_kernel, dim3((unsigned)cdiv(n, 256), (unsigned)nblk), dim3(256), 0, h->stream, D, ldd, d_off,
+                     X, ldx, n);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
 
 int transpose_rm(isdf_handle h, const double* src, int64_t lds, int64_t rows, int64_t cols, double* dst, int64_t ldd) {
   ARG_CHECK(h, src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= rows);
