@@ -1,0 +1,264 @@
+"""k-point build and J/K of ``isdf.ISDF``, including band k-points.  Host orchestration only."""
+import time
+import warnings
+import numpy as np
+import torch
+from . import gto
+from ._common import partition_grid_by_atom, _monkhorst_pack_size
+
+
+class KPointMixin:
+    # ---- k-points (BASELINE configs[3]); DESIGN.md "k-points" -----------------------------------------
+    def _build_kpts(self):
+        """Periodic parts u^k of all Bloch AOs -> real points/Theta (complex-mode S2/S3) -> one complex
+        W^q per difference vector q = k2 - k1.  The q list is split over the ranks (each rank holds the
+        fit, builds its share of the W^q and later the K terms that use them)."""
+        from . import pbc_tools
+        cell, be, comm = self.cell, self.backend, self.comm
+        self.timings = {}
+        t0 = time.perf_counter()
+        kpts_scf = np.asarray(self.kpts, dtype=float).reshape(-1, 3)
+        # band k-points (kpts_band of get_jk) join the stack: the fit must also represent conj(u^{kb}) u^{k}
+        band = kpts_scf if self.kpts_band is None else np.asarray(self.kpts_band, dtype=float).reshape(-1, 3)
+        kall = [k for k in kpts_scf]
+        self._band_index = []
+        for kb in band:
+            hit = [i for i, k in enumerate(kall) if abs(k - kb).max() < 1e-9]
+            if hit:
+                self._band_index.append(hit[0])
+            else:
+                kall.append(kb)
+                self._band_index.append(len(kall) - 1)
+        kpts = np.array(kall)
+        nk = len(kpts)                       # size of the stack; the first len(kpts_scf) entries carry density
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        nao = cell.nao_nr()
+        nh = nk * nao
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        coords = self.grids.coords
+        rcut = gto.estimate_rcut_per_shell(cell)
+        Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+        ao_args = (np.asarray(cell._atm), np.asarray(cell._bas), np.asarray(cell._env), Ls, rcut)
+        t0 = self._tick('host_setup', t0)
+
+        coords_soa = be.to_device(np.ascontiguousarray(coords.T))
+        X = self._buffer('aok', (2 * nh, G))
+        for k in range(nk):
+            be.eval_ao_k(*ao_args, kpts[k], True, coords_soa, X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao])
+        del coords_soa
+        self.ao = X
+        t0 = self._tick('S1_eval_ao', t0)
+
+        # S2 selection (complex mode); the number of points scales with the number of distinct pair
+        # families: c_isdf * nao * nk by default (capped by the grid)
+        kfac = self.k_ip_factor or min(nk, 2)
+        P_target = int(min(self.c_isdf * nao * kfac, G))
+        if self.select == 'global':
+            theta = self._buffer('theta', (P_target, G))
+            piv = be.empty((1, P_target), dtype=torch.int64)
+            rank = be.select_ip_cplx(X, nh, [0, G], [P_target], self.select_tol, self.tie_rtol, theta, piv)
+            ip_dev = piv[0, :int(rank[0])].contiguous()
+            self.ip = be.to_host(ip_dev).astype(np.int64)
+        else:
+            owner = partition_grid_by_atom(coords, cell.atom_coords(), a)
+            perm = np.argsort(owner, kind='stable').astype(np.int64)
+            counts = np.bincount(owner, minlength=cell.natm)
+            blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)
+            nip = np.minimum(self.nip_per_atom() * kfac, counts).astype(np.int32)
+            kmax = int(nip.max())
+            Xs = be.empty((2 * nh, G))
+            be.gather_cols(X, be.to_device(perm), Xs)
+            L = be.empty((kmax, G))
+            piv = be.empty((cell.natm, kmax), dtype=torch.int64)
+            rank = be.select_ip_cplx(Xs, nh, blk_off, nip, self.select_tol, self.tie_rtol, L, piv)
+            del Xs, L
+            piv_h = be.to_host(piv)
+            clusters = self._bj_clusters()
+            self.ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for cl in clusters for b in cl]).astype(np.int64)
+            ip_dev = be.to_device(self.ip)
+        P = len(self.ip)
+        t0 = self._tick('S2_select_ip', t0)
+
+        # S3 global fit, forward solve only (Y); the factor is applied to the (P, P) matrices
+        Y = self._buffer('theta', (max(P, P_target), G))[:P]
+        aoP_X = self._buffer('aoP', (P, 2 * nh))
+        # q list: W^{-q} = conj(W^q) (Theta is real, coulG_{-q}[-G] = coulG_q[G]): build one of each +-q pair,
+        # the primaries dealt round-robin over the ranks
+        self._qs, self._qindex = pbc_tools.unique_q(kpts_scf, band)      # index[k1 in band][k2 in kpts]
+        nq = len(self._qs)
+        w = cell.vol / G
+        batch = self.fft_batch or max(1, min(P, int((3 << 30) // (8 * G)) // 128 * 128 or 64))
+        partner = -np.ones(nq, dtype=int)
+        for iq in range(nq):
+            for jq in range(nq):
+                if abs(self._qs[iq] + self._qs[jq]).max() < 1e-9:
+                    partner[iq] = jq
+        primary = [iq for iq in range(nq) if partner[iq] < 0 or partner[iq] >= iq]
+        self._q_owner = np.zeros(nq, dtype=int)
+        for n, iq in enumerate(primary):
+            self._q_owner[iq] = n % comm.size
+            if partner[iq] >= 0:
+                self._q_owner[partner[iq]] = n % comm.size
+        r_ip = coords[self.ip]
+        Wre = self._buffer('Wre', (P, P))
+        Wim = self._buffer('Wim', (P, P))
+
+        # S3 + S4 + S5, route by route.  'auto' means the Cholesky route here unless bj_auto_kpts is set; then: block-
+        # Jacobi, verified on W^{q=0}, Cholesky when the check fails (the fit is replicated, so every rank takes the
+        # agreed decision after its share of the q list)
+        routes = self._fit_routes() if self.select != 'global' else ['cholesky']
+        if self.fit_route == 'auto' and not self.bj_auto_kpts:
+            routes = ['cholesky']
+        for route in routes:
+            if route == 'blockjacobi':
+                ip_off = self._bj_blocks(rank, clusters)
+                Afac, Dblk = self._bj_prepare(X, nh, ip_dev, ip_off, aoP_X)
+                self._bj_rows(aoP_X, nh, X, G, Dblk, ip_off, Y)
+            else:
+                chol = self._buffer('factor', (P, P))
+                self.reg_used = be.fit_prepare_cplx(X, nh, ip_dev, self.reg_rel, aoP_X, chol)
+                be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=not self.explicit_theta)
+            t0 = self._tick('S3_fit', t0)
+            self._Wq = {}
+            check = 0.0
+            for iq in primary:
+                if self._q_owner[iq] != comm.rank:
+                    continue
+                q = self._qs[iq]
+                coulG = be.to_device(pbc_tools.get_coulG(cell, q, mesh))
+                be.coulomb_Wq(Y, mesh, coulG, w, 0, P, batch, Wre, Wim, upper_only=True)
+                be.symmetrize_hermitian(Wre, Wim)
+                if route == 'blockjacobi':
+                    self._bj_finish(Afac, Dblk, ip_off, Wre)
+                    self._bj_finish(Afac, Dblk, ip_off, Wim, antisymmetric=True)
+                    if self.fit_route == 'auto' and abs(q).max() < 1e-9:
+                        # W^0 is real: the Gamma-point probe check with the densities sum_k u^k* R u^k
+                        t1 = self._tick('S4S5_coulomb_W', t0)
+                        planes = [aoP_X[:, o:o + nao].T.contiguous() for o in range(0, 2 * nh, nao)]
+                        check = self._bj_probe_mismatch(planes, Afac, Dblk, ip_off, Y, G, None, W=Wre)
+                        del planes
+                        t0 = self._tick('S5_route_check', t1)
+                elif not self.explicit_theta:
+                    be.W_from_factor(chol, 0, Wre)
+                    be.W_from_factor(chol, 0, Wim)
+                Wc = be.empty((P, P), dtype=torch.complex128)
+                be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * r_ip.dot(q))), Wc)
+                self._Wq[iq] = Wc
+            self.fit_route_used = route
+            if route == 'blockjacobi' and self.fit_route == 'auto':
+                self.bj_check = comm.agree_max(check)
+                if self.bj_check <= self.bj_check_tol:
+                    break
+                warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e); '
+                              'rebuilding the W^q with the Cholesky route' % (self.bj_check, self.bj_check_tol))
+                t0 = self._tick('S4S5_coulomb_W', t0)
+
+        # Bloch AOs at the points: phi^k(r_P) = exp(i k.r_P) u^k(r_P), (P, nao) complex per k
+        uP = be.to_host(aoP_X)                                   # (P, 2 nh)
+        self._aoP_k = []
+        for k in range(nk):
+            u = uP[:, k * nao:(k + 1) * nao] + 1j * uP[:, nh + k * nao:nh + (k + 1) * nao]
+            self._aoP_k.append(be.to_device(np.ascontiguousarray(u * np.exp(1j * r_ip.dot(kpts[k]))[:, None])))
+        self._q_partner = partner
+        t0 = self._tick('S4S5_coulomb_W', t0)
+        self._built = True
+        self._k_built = kpts_scf.copy()
+        self._band_built = None if self.kpts_band is None else band.copy()
+        self._nk_stack = nk
+        return self
+
+    def _get_jk_kpts(self, dm, hermi, kpts, kpts_band, with_j, with_k, exxdiv):
+        """k-point J and K (pyscf/pbc/df/fft_jk.py:33-109,177-302 semantics).  dm (nk, N, N) or (nset, nk, N, N); with
+        kpts_band the result lives on the band k-points, (nband, N, N) [(N, N) for a single (3,) band vector], as
+        df_jk._format_jks shapes it (pyscf/pbc/df/df_jk.py:1426-1444)."""
+        ex = exxdiv if exxdiv is not None else self.exxdiv
+        if ex not in (None, 'None', 'ewald'):
+            raise NotImplementedError("k-point ISDF: only exxdiv=None and 'ewald' are implemented")
+        cell, be, comm = self.cell, self.backend, self.comm
+        kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
+        band_in = None if kpts_band is None else np.asarray(kpts_band, dtype=float)
+        band = None if band_in is None else band_in.reshape(-1, 3)
+
+        def same(x, y):
+            if x is None or y is None:
+                return x is None and y is None
+            return x.shape == y.shape and abs(x - y).max() < 1e-9
+        if not self._built or getattr(self, '_k_built', None) is None or not same(kpts, self._k_built) \
+                or not same(band, getattr(self, '_band_built', None)):
+            self.kpts = kpts
+            self.kpts_band = band
+            self.build()
+        nk = len(kpts)
+        nks = self._nk_stack                                     # k-points in the stacked periodic parts
+        bidx = list(range(nk)) if band is None else list(self._band_index)
+        nband = len(bidx)
+        nao = cell.nao_nr()
+        nh = nks * nao
+        dm_in = np.asarray(dm)
+        dms = np.asarray(dm_in, dtype=np.complex128).reshape(-1, nk, nao, nao)
+        nset = dms.shape[0]
+        if hermi != 1 and with_j:
+            if abs(dms - dms.conj().transpose(0, 1, 3, 2)).max() > 1e-10:
+                raise NotImplementedError('non-Hermitian density matrices (complex density) are not implemented for J')
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        X = self.ao
+
+        def planes(k):
+            return X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao]
+        out_shape = dm_in.shape if band is None else \
+            (dm_in.shape[:-3] + ((nband,) if band_in.ndim > 1 else ()) + (nao, nao))
+        vj = vk = None
+        t0 = time.perf_counter()
+        if with_j:
+            vj = np.zeros((nset, nband, nao, nao), dtype=np.complex128)
+            for s in range(nset):
+                rho = be.zeros((1, G))
+                for k in range(nk):
+                    dT = dms[s, k].T
+                    be.rho_k(*planes(k), G, be.to_device(np.ascontiguousarray(dT.real)),
+                             be.to_device(np.ascontiguousarray(dT.imag)), 1.0 / nk, rho)
+                be.coulomb_potential(rho, mesh, a)
+                for ib, kb in enumerate(bidx):
+                    vre = be.empty((nao, nao))
+                    vim = be.empty((nao, nao))
+                    be.vj_k(*planes(kb), G, rho, vre, vim)
+                    vj[s, ib] = be.to_host(vre) + 1j * be.to_host(vim)
+            t0 = self._tick('S6_get_j', t0)
+            vj = vj.reshape(out_shape)
+        if with_k:
+            d_vk = be.zeros((nset, nband, nao, nao), dtype=torch.complex128)
+            for s in range(nset):
+                d_dm = [be.to_device(np.ascontiguousarray(dms[s, k])) for k in range(nk)]
+                for i1, k1 in enumerate(bidx):
+                    for k2 in range(nk):
+                        iq = self._qindex[i1, k2]
+                        if self._q_owner[iq] != comm.rank:
+                            continue
+                        if iq in self._Wq:
+                            Wq = self._Wq[iq]
+                        else:                      # stored as its time-reversal partner: W^{-q} = conj(W^q)
+                            Wq = torch.conj_physical(self._Wq[self._q_partner[iq]])
+                        be.get_k_pair(self._aoP_k[k1], self._aoP_k[k2], d_dm[k2], Wq, 1.0 / nk, d_vk[s, i1])
+            if comm.size > 1:
+                flat = torch.view_as_real(d_vk)
+                comm.all_reduce_sum(flat)
+            vk = be.to_host(d_vk)
+            if ex == 'ewald':
+                # vk[k] += madelung * S^k D^k S^k (pyscf/pbc/df/df_jk.py:1446-1465) for the band k-points that are
+                # k-points of the density; S^k by quadrature on the grid from the periodic parts (the phases cancel)
+                mad = gto.madelung(cell, _monkhorst_pack_size(cell, kpts))
+                w_const = be.to_device(np.full((1, G), cell.vol / G))
+                for ib, kb in enumerate(bidx):
+                    if kb >= nk:
+                        continue
+                    sre, sim = be.empty((nao, nao)), be.empty((nao, nao))
+                    be.vj_k(*planes(kb), G, w_const, sre, sim)
+                    Sk = be.to_host(sre) + 1j * be.to_host(sim)
+                    for s in range(nset):
+                        vk[s, ib] += mad * Sk.dot(dms[s, kb]).dot(Sk)
+            t0 = self._tick('S7_get_k', t0)
+            vk = vk.reshape(out_shape)
+        return vj, vk

@@ -1,0 +1,234 @@
+"""Grid-sharded multi-GPU build and J/K of ``isdf.ISDF``: one process per GPU, collectives through
+``parallel.Comm`` (RCCL on GPUs, gloo in CPU tests).  Host orchestration only."""
+import time
+import warnings
+import numpy as np
+import torch
+from . import gto
+from ._common import partition_grid_by_atom, _default_fft_batch
+
+
+class ShardedMixin:
+    def _bj_finish_sharded(self, Afac, Dblk, ip_off, W):
+        """_bj_finish with the two-sided P x P solves split over the ranks by column blocks C_r (they are 4 P^3 flop,
+        0.7 s at P = 16640, and would otherwise be replicated):  Z[:, C_r] = A'^-1 M'[:, C_r];  all_reduce;
+        W'[:, C_r] = A'^-1 Z[C_r, :]^T (M' is symmetric) and the left block solve;  all_reduce;  the right block solve
+        (block diagonal, cheap) and the symmetrisation replicated."""
+        be, comm = self.backend, self.comm
+        P = W.shape[0]
+        c0, c1 = comm.split_range(P)
+        X = W[:, c0:c1].clone()                      # (P, c) columns of M'
+        W.zero_()
+        if c1 > c0:
+            be.factor_solve(Afac, X)
+            W[:, c0:c1] = X
+        comm.all_reduce_sum(W)                       # Z = A'^-1 M' on every rank
+        if c1 > c0:
+            X.copy_(W[c0:c1, :].T)                   # Z[C_r, :]^T = (M' A'^-1)[:, C_r]
+        W.zero_()
+        if c1 > c0:
+            be.factor_solve(Afac, X)                 # A'^-1 M' A'^-1 [:, C_r]
+            be.block_solve(Dblk, ip_off, 0, 1, X)    # D^-T (.)
+            W[:, c0:c1] = X
+        comm.all_reduce_sum(W)
+        del X
+        be.block_solve(Dblk, ip_off, 1, 0, W)        # (.) D^-1
+        be.symmetrize_mean(W)
+
+    # ---- multi-GPU: grid-sharded build, row-sharded K (DESIGN.md "Multi-GPU") -------------------------
+    def _build_sharded(self):
+        """Every rank owns a contiguous slice S_r of the grid (natural order).
+
+        S1  collocation on the slice                               no communication
+        S2  per-atom selection, atom blocks dealt round-robin       all_gather of the point lists (P ints)
+        S3  A_PP Cholesky replicated (P^3/3, small); fit on slice   no communication
+        S4  rows of Theta assembled by all-to-all, FFT convolution, scattered back by all-to-all
+        S5  W_r = w V[:, S_r] Theta[:, S_r]^T                       all_reduce(W)  (RCCL over xGMI)
+        Streaming over row batches bounds memory at any rank count.
+        """
+        cell, be, comm = self.cell, self.backend, self.comm
+        if self.select != 'local':
+            raise NotImplementedError("multi-GPU build needs select='local'")
+        R, rk = comm.size, comm.rank
+        self.timings = {}
+        t0 = time.perf_counter()
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        nao = cell.nao_nr()
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        coords = self.grids.coords
+        rcut = gto.estimate_rcut_per_shell(cell)
+        Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+        ao_args = (np.asarray(cell._atm), np.asarray(cell._bas), np.asarray(cell._env), Ls, rcut)
+        g0, g1 = comm.split_range(G)
+        self._slice = (g0, g1)
+        ng = g1 - g0
+        t0 = self._tick('host_setup', t0)
+
+        # S1 on the slice
+        self.ao = self._buffer('ao', (nao, ng))
+        be.eval_ao(*ao_args, be.to_device(np.ascontiguousarray(coords[g0:g1].T)), self.ao)
+        t0 = self._tick('S1_eval_ao', t0)
+
+        # S2 selection on this rank's atom blocks
+        owner = partition_grid_by_atom(coords, cell.atom_coords(), a)
+        perm = np.argsort(owner, kind='stable').astype(np.int64)
+        counts = np.bincount(owner, minlength=cell.natm)
+        blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)
+        nip = np.minimum(self.nip_per_atom(), counts).astype(np.int32)
+        mine = [b for b in range(cell.natm) if b % R == rk and nip[b] > 0]
+        t0 = self._tick('host_partition', t0)
+        my_ips = {}
+        if mine:
+            idx = np.concatenate([perm[blk_off[b]:blk_off[b + 1]] for b in mine])
+            loc_off = np.append(0, np.cumsum([counts[b] for b in mine])).astype(np.int64)
+            ao_sel = be.empty((nao, len(idx)))
+            be.eval_ao(*ao_args, be.to_device(np.ascontiguousarray(coords[idx].T)), ao_sel)
+            kmax = int(max(nip[b] for b in mine))
+            L = be.empty((kmax, len(idx)))
+            piv = be.empty((len(mine), kmax), dtype=torch.int64)
+            rank = be.select_ip(ao_sel, loc_off, [nip[b] for b in mine], self.select_tol, self.tie_rtol, L, piv)
+            piv_h = be.to_host(piv)
+            for k, b in enumerate(mine):
+                my_ips[b] = idx[loc_off[k] + piv_h[k, :rank[k]]]
+            del ao_sel, L, piv
+        all_ips = comm.all_gather_object(my_ips)
+        merged = {}
+        for d in all_ips:
+            merged.update(d)
+        clusters = self._bj_clusters()
+        self.ip = np.concatenate([merged[b] for cl in clusters for b in cl]).astype(np.int64)
+        P = len(self.ip)
+        t0 = self._tick('S2_select_ip', t0)
+
+        # S3: phi at the points = columns of the slice collocations (every point lies in exactly one slice; zero-padded
+        # all_reduce of 8 P N bytes).  Taking them from the SAME evaluation as the fit's right-hand sides keeps
+        # B[:, ip] == A_PP to the last bit (a separate collocation differs by the image-screening tolerance, which
+        # the fit amplifies by cond(A)).  P x P factorisations replicated, rows of the fit on the slice.
+        aoP_T = be.zeros((nao, P))
+        mine_p = np.nonzero((self.ip >= g0) & (self.ip < g1))[0]
+        if len(mine_p):
+            loc = be.empty((nao, len(mine_p)))
+            be.gather_cols(self.ao, be.to_device(self.ip[mine_p] - g0), loc)
+            aoP_T[:, be.to_device(mine_p)] = loc
+            del loc
+        comm.all_reduce_sum(aoP_T)
+        self.aoP = self._buffer('aoP', (P, nao))
+        theta = self._buffer('theta', (P, ng))
+        ar = be.to_device(np.arange(P, dtype=np.int64))
+        ip_off = self._bj_blocks([len(merged[b]) for b in range(cell.natm)], clusters)
+        for route in self._fit_routes():
+            # the P x P factorisations run on rank 0 and are broadcast (2 x 8 P^2 bytes): every rank then holds the
+            # same bits, and the shift ladders' decisions cannot diverge between ranks
+            if route == 'blockjacobi':
+                Afac = self._buffer('factor', (P, P))
+                Dblk = self._buffer('Dblk', (P, P))
+                def root_factorise():
+                    self._bj_prepare(aoP_T, 0, ar, ip_off, self.aoP, scratch=self._buffer('W', (P, P)))
+                    return self.reg_used
+                reg = comm.run_on_root(root_factorise)
+                if comm.rank != 0:
+                    be.gather_aoP(aoP_T, ar, self.aoP)
+                comm.broadcast(Afac)
+                comm.broadcast(Dblk)
+                self.reg_used = comm.agree_max(reg or 0.0)
+                self._bj_rows(self.aoP, 0, self.ao, ng, Dblk, ip_off, theta)
+            else:
+                chol = self._buffer('factor', (P, P))
+                reg = comm.run_on_root(lambda: be.fit_prepare(aoP_T, ar, self.reg_rel, self.aoP, chol))
+                if comm.rank != 0:
+                    be.gather_aoP(aoP_T, ar, self.aoP)
+                comm.broadcast(chol)
+                self.reg_used = comm.agree_max(reg or 0.0)
+                be.fit_apply(chol, self.aoP, self.ao, ng, theta, forward_only=not self.explicit_theta)
+            t0 = self._tick('S3_fit', t0)
+
+            # S4 + S5 streamed over row batches: rank q convolves rows P_q[t*nb : (t+1)*nb] in step t
+            w = cell.vol / G
+            self.W = self._buffer('W', (P, P))
+            self.W.zero_()
+            slices = [comm.split_range(G, r) for r in range(R)]
+            rows = [comm.split_range(P, r) for r in range(R)]
+            nb = self.fft_batch or _default_fft_batch(G, max(1, P // R))
+            nsteps = max(-(-(hi - lo) // nb) for lo, hi in rows)
+            for t in range(nsteps):
+                bat = [(min(lo + t * nb, hi), min(lo + (t + 1) * nb, hi)) for lo, hi in rows]   # rows handled by rank q
+                nrow = [hi - lo for lo, hi in bat]
+                # all-to-all 1: send Theta[bat_q, S_r] to q; receive Theta[bat_r, S_q] from q
+                send = [theta[lo:hi] for lo, hi in bat]
+                recv = [be.empty((nrow[rk], s1 - s0)) for s0, s1 in slices]
+                comm.all_to_all(recv, send)
+                full = be.empty((nrow[rk], G))
+                for (s0, s1), piece in zip(slices, recv):
+                    full[:, s0:s1] = piece
+                del recv
+                if nrow[rk]:
+                    be.coulomb_rows(full, mesh, a, max(1, nrow[rk]))
+                # all-to-all 2: send V[bat_r, S_q] to q; receive V[bat_q, S_r] from q
+                send = [full[:, s0:s1].contiguous() for s0, s1 in slices]
+                recv = [be.empty((nrow[q], ng)) for q in range(R)]
+                comm.all_to_all(recv, send)
+                del full, send
+                for q in range(R):
+                    if nrow[q]:
+                        # W[bat_q, c0:] = w V[bat_q, S_r] Theta[c0:, S_r]^T  (partial over this rank's slice).
+                        # W is symmetric: only the columns from the batch's first row on are computed and
+                        # the lower part is mirrored after the all-reduce (half the flops).
+                        c0 = bat[q][0]
+                        be.gemm_nt(recv[q], theta[c0:], self.W[bat[q][0]:bat[q][1], c0:], alpha=w, beta=0.0)
+                del recv
+            comm.all_reduce_sum(self.W)
+            be.symmetrize_upper(self.W)
+            if route == 'blockjacobi':
+                self._bj_finish_sharded(Afac, Dblk, ip_off, self.W)
+            elif not self.explicit_theta:
+                be.W_from_factor(chol, 0, self.W)
+            t0 = self._tick('S4S5_coulomb_W', t0)
+            self.fit_route_used = route
+            if route == 'blockjacobi' and self.fit_route == 'auto':
+                # replicated W, all-reduced probe energies; the max over ranks makes the decision identical everywhere
+                self.bj_check = comm.agree_max(self._bj_probe_mismatch(aoP_T, Afac, Dblk, ip_off, theta, ng, (g0, g1)))
+                t0 = self._tick('S5_route_check', t0)
+                if self.bj_check <= self.bj_check_tol:
+                    break
+                warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e); '
+                              'rebuilding W with the Cholesky route' % (self.bj_check, self.bj_check_tol))
+        del theta, aoP_T
+        self._built = True
+        return self
+
+    def _get_jk_sharded(self, d_dm, out_shape, with_j, with_k, exxdiv=None):
+        cell, be, comm = self.cell, self.backend, self.comm
+        nao = cell.nao_nr()
+        nset = d_dm.shape[0]
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        g0, g1 = self._slice
+        vj = vk = None
+        t0 = time.perf_counter()
+        if with_j:
+            # rho on the slice -> all_reduce of the zero-padded density -> potential (replicated FFT) ->
+            # vj partial from the slice -> all_reduce
+            rho = be.zeros((nset, G))
+            rho_loc = be.empty((nset, g1 - g0))
+            be.rho(self.ao, g1 - g0, d_dm, rho_loc)
+            rho[:, g0:g1] = rho_loc
+            comm.all_reduce_sum(rho)
+            be.coulomb_potential(rho, mesh, a)
+            d_vj = be.empty((nset, nao, nao))
+            be.vj_from_vR(self.ao, g1 - g0, rho[:, g0:g1].contiguous(), d_vj)
+            comm.all_reduce_sum(d_vj)
+            t0 = self._tick('S6_get_j', t0)
+            vj = be.to_host(d_vj).reshape(out_shape)
+        if with_k:
+            P = self.W.shape[0]
+            r0, r1 = comm.split_range(P)
+            d_vk = be.empty((nset, nao, nao))
+            be.get_k(self.aoP, self.W, r0, r1 - r0, d_dm, d_vk)
+            comm.all_reduce_sum(d_vk)
+            if exxdiv == 'ewald':
+                self._add_ewald_exxdiv(d_dm, d_vk)
+            t0 = self._tick('S7_get_k', t0)
+            vk = be.to_host(d_vk).reshape(out_shape)
+        return vj, vk
