@@ -411,8 +411,10 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
     # ---- ERIs from the factorisation (small systems; reached from SCF.get_jk's incore branch,
     #      pyscf/pbc/scf/hf.py:670-679) ------------------------------------------------------------
     def get_ao_eri(self, kpts=None, compact=True):
-        if not self._is_gamma(kpts):
-            raise NotImplementedError
+        """AO ERIs from the factorisation (FFTDF.get_ao_eri surface, pyscf/pbc/df/fft.py:317).  Gamma point: real, s4-compact
+        (nao(nao+1)/2 squared) or s1; with k-points (one, or four that conserve momentum): complex s1, see kpoints.py."""
+        if not self._is_gamma(kpts) or not self._is_gamma(self.kpts):
+            return self._get_ao_eri_kpts(self.kpts if kpts is None else kpts)
         if not self._built:
             self.build()
         aoP = self.backend.to_host(self.aoP)

@@ -262,3 +262,42 @@ class KPointMixin:
             t0 = self._tick('S7_get_k', t0)
             vk = vk.reshape(out_shape)
         return vj, vk
+
+    def _get_ao_eri_kpts(self, kpts):
+        """(i^{k1} j^{k2} | k^{k3} l^{k4}) = sum_PQ conj(phi^{k1}_i) phi^{k2}_j (P)  W^{q}_PQ  conj(phi^{k3}_k) phi^{k4}_l (Q),
+        q = k2 - k1 = k3 - k4, as FFTDF.get_ao_eri (pyscf/pbc/df/fft_ao2mo.py:45-99) returns it: complex (nao^2, nao^2), s1.
+        kpts: one k-point (all four equal) or four with k1 - k2 + k3 - k4 = 0.  Small systems (host contraction)."""
+        be = self.backend
+        kk = np.asarray(kpts, dtype=float).reshape(-1, 3)
+        if len(kk) == 1:
+            kk = np.tile(kk, (4, 1))
+        if len(kk) != 4:
+            raise ValueError('get_ao_eri needs one or four k-points')
+        if abs(kk[0] - kk[1] + kk[2] - kk[3]).max() > 1e-7:
+            raise ValueError('k-points do not conserve momentum (k1 - k2 + k3 - k4 != 0)')
+        if self.comm.size > 1:
+            raise NotImplementedError('k-point ERIs are a single-process path')
+        uniq, idx = [], []
+        for k in kk:
+            hit = [i for i, u in enumerate(uniq) if abs(u - k).max() < 1e-7]
+            if hit:
+                idx.append(hit[0])
+            else:
+                uniq.append(k)
+                idx.append(len(uniq) - 1)
+        uniq = np.array(uniq)
+        built = getattr(self, '_k_built', None)
+        if not self._built or built is None or built.shape != uniq.shape or abs(built - uniq).max() > 1e-9 \
+                or getattr(self, '_band_built', None) is not None:
+            self.kpts = uniq
+            self.kpts_band = None
+            self._build_kpts()
+        iq = self._qindex[idx[0], idx[1]]
+        Wq = self._Wq[iq] if iq in self._Wq else torch.conj_physical(self._Wq[self._q_partner[iq]])
+        Wq = be.to_host(Wq)
+        a = [be.to_host(self._aoP_k[i]) for i in idx]
+        P = len(self.ip)
+        left = (a[0].conj()[:, :, None] * a[1][:, None, :]).reshape(P, -1)
+        right = (a[2].conj()[:, :, None] * a[3][:, None, :]).reshape(P, -1)
+        return left.T.dot(Wq).dot(right)
+

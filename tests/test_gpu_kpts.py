@@ -197,6 +197,31 @@ def test_kpts_band_reproduces_the_reference_pin():
     assert v2k.shape == (4, nao, nao) and abs(v2k[:2] - vk).max() < 1e-4 * abs(vk).max()
 
 
+def test_kpoint_ao_eri_reproduces_the_reference_pins():
+    """get_ao_eri with k-points from the factorisation: the reference's constants for one k-point and for four k-points
+    that conserve momentum (pyscf/pbc/df/test/test_fft.py:555-557,690-703) at full rank of the pair space."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    np.random.seed(1)
+    kpts = np.random.random((4, 3))
+    kpts[3] = kpts[0] - kpts[1] + kpts[2]
+    nao = cell.nao_nr()
+    df = ISDF(cell, kpts=kpts, c_isdf=60, select='global')
+    df.select_tol = 0.0
+    df.reg_rel = 1e-13
+    df.k_ip_factor = 2
+    eri4 = df.get_ao_eri(kpts)
+    assert eri4.shape == (nao * nao, nao * nao) and eri4.dtype == np.complex128
+    assert abs(otools.fp(eri4) - (0.33709288394542991 - 0.94185725001175313j)) < 5e-6
+    d1 = ISDF(cell, kpts=kpts[:1], c_isdf=40, select='global')
+    d1.select_tol = 0.0
+    d1.reg_rel = 1e-13
+    eri1 = d1.get_ao_eri(kpts[0])
+    assert abs(otools.fp(eri1) - (2.9346374584901898 - 0.20479054936744959j)) < 1e-6
+    with pytest.raises(ValueError):
+        df.get_ao_eri(np.array([kpts[0], kpts[1], kpts[2], kpts[2]]))          # momentum not conserved
+
+
 def test_select_complex_mode_panel_from_global_memory(be):
     """Many AOs x k-points: the pivot panel (2 x 9000 doubles) no longer fits the LDS staging budget and
     is broadcast from global memory; pivots must still equal the plain-C oracle's."""

@@ -1,6 +1,7 @@
 """k-point ISDF oracle against the reference's exact k-point exchange (oracle/fftdf.get_jk_kpts, which
 is pinned to pyscf/pbc/df/test/test_fft.py:670-676).  No GPU."""
 import numpy as np
+import pytest
 import cells
 from pyscf_isdf_amd import gto
 from oracle import ao as oao, fftdf, kisdf
@@ -84,3 +85,24 @@ def test_kpts_band_host_logic_with_checker_backend():
     assert abs(otools.fp(vk) - (10.239828255099447 + 2.1190549216896182j)) < 1e-4
     v1j, v1k = df.get_jk(dms, kpts=kpts, kpts_band=np.array([0.1, 0.2, 0.3]), with_j=False)
     assert v1j is None and v1k.shape == (nao, nao) and df._nk_stack == 5
+
+
+def test_kpoint_ao_eri_host_logic_with_checker_backend():
+    """k-point AO ERIs from the factorisation through the host driver (no GPU): converge to the reference's constant for four
+    momentum-conserving k-points (pyscf/pbc/df/test/test_fft.py:702-703)."""
+    import cells
+    from oracle_backend import OracleBackend
+    from oracle import pbc_tools as otools
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    np.random.seed(1)
+    kpts = np.random.random((4, 3))
+    kpts[3] = kpts[0] - kpts[1] + kpts[2]
+    df = ISDF(cell, kpts=kpts, c_isdf=20, select='global', backend=OracleBackend())
+    df.select_tol = 0.0
+    df.k_ip_factor = 2
+    eri4 = df.get_ao_eri(kpts)
+    assert eri4.shape == (36, 36)
+    assert abs(otools.fp(eri4) - (0.33709288394542991 - 0.94185725001175313j)) < 2e-4
+    with pytest.raises(ValueError):
+        df.get_ao_eri(kpts[:3])
