@@ -431,15 +431,17 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
 
     def ao2mo(self, mo_coeffs, kpts=None, compact=False):
         """(ij|kl) in the MO basis from the factorisation (FFTDF.ao2mo surface, pyscf/pbc/df/fft.py:319):
-        sum_PQ X_ij,P W_PQ X_kl,Q with X_ij,P = (aoP C_i)_P (aoP C_j)_P.  Gamma point, s1 layout."""
+        sum_PQ X_ij,P W_PQ X_kl,Q with X_ij,P = (aoP C_i)_P (aoP C_j)_P.  s1 layout; Gamma point (real) or k-points (kpoints.py)."""
+        if isinstance(mo_coeffs, np.ndarray) and mo_coeffs.ndim == 2:
+            mo_coeffs = (mo_coeffs,) * 4
         if not self._is_gamma(kpts) or not self._is_gamma(self.kpts):
-            raise NotImplementedError
+            if compact:
+                raise NotImplementedError('k-point MO integrals have no compact form')
+            return self._get_ao_eri_kpts(self.kpts if kpts is None else kpts, mo_coeffs=mo_coeffs)
         if compact:
             raise NotImplementedError('compact MO integrals are not implemented; use compact=False')
         if not self._built:
             self.build()
-        if isinstance(mo_coeffs, np.ndarray) and mo_coeffs.ndim == 2:
-            mo_coeffs = (mo_coeffs,) * 4
         aoP = self.backend.to_host(self.aoP)
         W = self.backend.to_host(self.W)
         ci, cj, ck, cl = [aoP.dot(np.asarray(c)) for c in mo_coeffs]

@@ -263,10 +263,12 @@ class KPointMixin:
             vk = vk.reshape(out_shape)
         return vj, vk
 
-    def _get_ao_eri_kpts(self, kpts):
+    def _get_ao_eri_kpts(self, kpts, mo_coeffs=None):
         """(i^{k1} j^{k2} | k^{k3} l^{k4}) = sum_PQ conj(phi^{k1}_i) phi^{k2}_j (P)  W^{q}_PQ  conj(phi^{k3}_k) phi^{k4}_l (Q),
         q = k2 - k1 = k3 - k4, as FFTDF.get_ao_eri (pyscf/pbc/df/fft_ao2mo.py:45-99) returns it: complex (nao^2, nao^2), s1.
-        kpts: one k-point (all four equal) or four with k1 - k2 + k3 - k4 = 0.  Small systems (host contraction)."""
+        kpts: one k-point (all four equal) or four with k1 - k2 + k3 - k4 = 0.  Small systems (host contraction).
+        mo_coeffs (four (nao, n_i) arrays): the same in the MO basis, phi^{k}_i -> sum_mu phi^{k}_mu C_mu,i
+        (FFTDF.ao2mo / get_mo_eri, fft_ao2mo.py:101-152)."""
         be = self.backend
         kk = np.asarray(kpts, dtype=float).reshape(-1, 3)
         if len(kk) == 1:
@@ -296,6 +298,8 @@ class KPointMixin:
         Wq = self._Wq[iq] if iq in self._Wq else torch.conj_physical(self._Wq[self._q_partner[iq]])
         Wq = be.to_host(Wq)
         a = [be.to_host(self._aoP_k[i]) for i in idx]
+        if mo_coeffs is not None:
+            a = [x.dot(np.asarray(c)) for x, c in zip(a, mo_coeffs)]
         P = len(self.ip)
         left = (a[0].conj()[:, :, None] * a[1][:, None, :]).reshape(P, -1)
         right = (a[2].conj()[:, :, None] * a[3][:, None, :]).reshape(P, -1)

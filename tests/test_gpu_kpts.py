@@ -220,6 +220,14 @@ def test_kpoint_ao_eri_reproduces_the_reference_pins():
     assert abs(otools.fp(eri1) - (2.9346374584901898 - 0.20479054936744959j)) < 1e-6
     with pytest.raises(ValueError):
         df.get_ao_eri(np.array([kpts[0], kpts[1], kpts[2], kpts[2]]))          # momentum not conserved
+    # MO integrals = the AO integrals transformed (test_fft.py:766-775 checks the same identity on the reference)
+    np.random.seed(5)
+    mo = np.random.random((nao, nao)) + np.random.random((nao, nao)) * 1j
+    mo1 = mo[:, :nao // 2 + 1]
+    eri_mo = df.ao2mo((mo1, mo, mo, mo1), kpts)
+    ref = np.einsum('pqrs,pi,qj,rk,sl->ijkl', eri4.reshape((nao,) * 4), mo1.conj(), mo, mo.conj(), mo1)
+    assert eri_mo.shape == (mo1.shape[1] * nao, nao * mo1.shape[1])
+    assert abs(eri_mo - ref.reshape(eri_mo.shape)).max() < 1e-9 * abs(ref).max()
 
 
 def test_select_complex_mode_panel_from_global_memory(be):
