@@ -198,9 +198,8 @@ class KPointMixin:
         dm_in = np.asarray(dm)
         dms = np.asarray(dm_in, dtype=np.complex128).reshape(-1, nk, nao, nao)
         nset = dms.shape[0]
-        if hermi != 1 and with_j:
-            if abs(dms - dms.conj().transpose(0, 1, 3, 2)).max() > 1e-10:
-                raise NotImplementedError('non-Hermitian density matrices (complex density) are not implemented for J')
+        # a non-Hermitian density matrix gives a complex density: J is then built from its real and imaginary parts
+        herm_dm = abs(dms - dms.conj().transpose(0, 1, 3, 2)).max() <= 1e-10
         mesh = np.asarray(self.mesh, dtype=np.int32)
         G = int(np.prod(mesh))
         a = np.asarray(cell.lattice_vectors(), dtype=float)
@@ -215,17 +214,21 @@ class KPointMixin:
         if with_j:
             vj = np.zeros((nset, nband, nao, nao), dtype=np.complex128)
             for s in range(nset):
-                rho = be.zeros((1, G))
-                for k in range(nk):
-                    dT = dms[s, k].T
-                    be.rho_k(*planes(k), G, be.to_device(np.ascontiguousarray(dT.real)),
-                             be.to_device(np.ascontiguousarray(dT.imag)), 1.0 / nk, rho)
-                be.coulomb_potential(rho, mesh, a)
-                for ib, kb in enumerate(bidx):
-                    vre = be.empty((nao, nao))
-                    vim = be.empty((nao, nao))
-                    be.vj_k(*planes(kb), G, rho, vre, vim)
-                    vj[s, ib] = be.to_host(vre) + 1j * be.to_host(vim)
+                # rho = 1/nk sum_k sum_ij D_ij u_i conj(u_j); isdf_rho_k gives Re(rho); Im(rho) = Re of the same with -i D
+                for part, fac in ((0, 1.0), (1, -1j)):
+                    if part == 1 and herm_dm:
+                        break
+                    rho = be.zeros((1, G))
+                    for k in range(nk):
+                        dT = (fac * dms[s, k]).T
+                        be.rho_k(*planes(k), G, be.to_device(np.ascontiguousarray(dT.real)),
+                                 be.to_device(np.ascontiguousarray(dT.imag)), 1.0 / nk, rho)
+                    be.coulomb_potential(rho, mesh, a)
+                    for ib, kb in enumerate(bidx):
+                        vre = be.empty((nao, nao))
+                        vim = be.empty((nao, nao))
+                        be.vj_k(*planes(kb), G, rho, vre, vim)
+                        vj[s, ib] += (1.0 if part == 0 else 1j) * (be.to_host(vre) + 1j * be.to_host(vim))
             t0 = self._tick('S6_get_j', t0)
             vj = vj.reshape(out_shape)
         if with_k:

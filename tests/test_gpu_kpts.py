@@ -157,6 +157,22 @@ def test_isdf_kpts_fit_routes_agree():
     assert abs(vk - out['cholesky'][0]).max() < 1e-12 * abs(vk).max()
 
 
+def test_non_hermitian_density_matrices():
+    """hermi=0: the density is complex; J from its real and imaginary parts equals the reference formula (fft_jk.py:63-107),
+    K (which never assumed a Hermitian D) the oracle's k-ISDF on the same points."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell, coords, Ls, rcut, kpts, aos, dms = _setup()
+    rng = np.random.default_rng(3)
+    dmn = dms + 0.3 * (rng.standard_normal(dms.shape) + 1j * rng.standard_normal(dms.shape))
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    vj_ref, vk_ref = fftdf.get_jk_kpts(aos, dmn, a, mesh, coords, kpts)
+    df = ISDF(cell, kpts=kpts, c_isdf=20, select='global')
+    df.k_ip_factor = 2
+    vj, vk = df.get_jk(dmn, hermi=0, kpts=kpts)
+    assert abs(vj - vj_ref).max() < 1e-10
+    assert abs(vk - vk_ref).max() < 5e-5 * abs(vk_ref).max()
+
+
 def test_kpts_band_reproduces_the_reference_pin():
     """get_jk(kpts=4 random k, kpts_band=2 k): the reference's own constant for this call (pyscf/pbc/df/test/
     test_fft.py:555-557,663-676, exact FFTDF exchange) is reproduced by the ISDF path once the point set reaches the
