@@ -323,7 +323,10 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         dm_in = np.asarray(dm)
         if np.iscomplexobj(dm_in):
             if abs(dm_in.imag).max() > 1e-12:
-                raise NotImplementedError('complex density matrices at the Gamma point are not supported')
+                # J and K are linear in D and the Gamma-point AOs are real: real and imaginary parts separately
+                re = self.get_jk(dm_in.real, hermi, kpts, kpts_band, with_j, with_k, omega, exxdiv)
+                im = self.get_jk(dm_in.imag, hermi, kpts, kpts_band, with_j, with_k, omega, exxdiv)
+                return tuple(None if r is None else r + 1j * i for r, i in zip(re, im))
             dm_in = dm_in.real
         nao = self.cell.nao_nr()
         dms = np.ascontiguousarray(dm_in.reshape(-1, nao, nao), dtype=np.float64)

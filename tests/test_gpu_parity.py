@@ -240,6 +240,12 @@ def test_isdf_object_end_to_end(select):
     # shapes: (nset, nao, nao) in -> same out; with_k=False -> None
     vj2, vk2 = df.get_jk(np.stack([dm, 2 * dm]), with_k=False)
     assert vk2 is None and vj2.shape == (2, nao, nao) and abs(vj2[1] - 2 * vj).max() < 1e-10
+    # complex density matrix at the Gamma point: J, K are linear in D (real AOs) -> complex128 results
+    rng = np.random.default_rng(0)
+    di = rng.standard_normal((nao, nao))
+    vjc, vkc = df.get_jk(dm + 1j * di, hermi=0)
+    vji, vki = df.get_jk(di, hermi=0)
+    assert vjc.dtype == np.complex128 and abs(vjc - (vj + 1j * vji)).max() < 1e-12 and abs(vkc - (vk + 1j * vki)).max() < 1e-12
 
 
 def test_isdf_object_vs_oracle_pipeline_diamond():
