@@ -56,6 +56,10 @@ int isdf_release_workspace(isdf_handle h);
  * dgemm updates: slower, no inverted diagonal blocks; also the way to profile with rocprofv3 --pmc, which crashes inside
  * rocBLAS's trsm on the 1.7M-column right-hand sides).  Unknown keys are an error. */
 int isdf_set_option(isdf_handle h, const char* key, int value);
+/* Range separation of the Gamma-point Coulomb kernel used by isdf_coulomb_W / _rows / _potential / isdf_get_j, as
+ * pyscf/pbc/tools/pbc.py:408-418: omega > 0 long range (erf(omega r)/r), omega < 0 short range, 0 (default) plain 1/r.
+ * (The k-point entry points take their kernel table from the caller.) */
+int isdf_set_coulomb_omega(isdf_handle h, double omega);
 
 /* Optional in-library profiling (bench.py's roofline leg): when enabled, the library brackets its
  * hot kernel launches with HIP events on the work stream and accumulates, per kernel name, the number

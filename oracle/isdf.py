@@ -76,16 +76,16 @@ def fit_theta_normal_equations(aoT, piv):
     return np.linalg.lstsq(A, B, rcond=None)[0]
 
 
-def coulomb_V(theta, a, mesh):
-    """V_P = ifft(coulG * fft(Theta_P)).real, rows over P (k, G)."""
-    coulG = tools.get_coulG(a, mesh)
+def coulomb_V(theta, a, mesh, omega=None):
+    """V_P = ifft(coulG * fft(Theta_P)).real, rows over P (k, G); omega: range separation (pbc.py:408-418)."""
+    coulG = tools.get_coulG(a, mesh, omega=omega)
     return tools.ifft(tools.fft(theta, mesh) * coulG, mesh).real
 
 
-def build_W(theta, a, mesh):
+def build_W(theta, a, mesh, omega=None):
     G = theta.shape[1]
     w = abs(np.linalg.det(a)) / G
-    V = coulomb_V(theta, a, mesh)
+    V = coulomb_V(theta, a, mesh, omega)
     return w * V.dot(theta.T)
 
 
@@ -227,14 +227,14 @@ def theta_dense_from_blocks(blocks, G):
 
 
 # ---- J / K -------------------------------------------------------------------------------------
-def get_j(aoT, dm, a, mesh):
+def get_j(aoT, dm, a, mesh, omega=None):
     """Exact J (FFTDF formula) in the (nao, G) layout."""
     dms = np.asarray(dm, dtype=float)
     shape = dms.shape
     dms = dms.reshape(-1, shape[-2], shape[-1])
     G = aoT.shape[1]
     w = abs(np.linalg.det(a)) / G
-    coulG = tools.get_coulG(a, mesh)
+    coulG = tools.get_coulG(a, mesh, omega=omega)
     vj = np.empty_like(dms)
     for i, d in enumerate(dms):
         rho = np.einsum('ig,ig->g', d.dot(aoT), aoT)

@@ -44,7 +44,7 @@ def get_Gv(b, mesh):
     return Gv.reshape(-1, 3)
 
 
-def get_coulG(a, mesh, k=np.zeros(3), wrap_around=True):
+def get_coulG(a, mesh, k=np.zeros(3), wrap_around=True, omega=None):
     """Coulomb kernel on the FFT mesh for lattice ``a`` (3,3 Bohr); exxdiv=None semantics."""
     a = np.asarray(a, dtype=float)
     b = 2 * np.pi * np.linalg.inv(a.T)
@@ -72,6 +72,9 @@ def get_coulG(a, mesh, k=np.zeros(3), wrap_around=True):
     coulG[absG2 == 0] = 0
     if equal2boundary is not None:
         coulG[equal2boundary] = 0
+    if omega:                                   # range separation, pyscf/pbc/tools/pbc.py:408-418
+        e = np.exp(-.25 / omega ** 2 * absG2)
+        coulG = coulG * (e if omega > 0 else 1 - e)
     return coulG
 
 

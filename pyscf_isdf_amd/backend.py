@@ -46,6 +46,9 @@ class HipBackend:
     def to_host(self, t):
         return t.detach().cpu().numpy()
 
+    def set_coulomb_omega(self, omega):
+        self.handle.call('isdf_set_coulomb_omega', float(omega or 0.0))
+
     def set_option(self, key, value):
         self.handle.call('isdf_set_option', key.encode(), int(value))
 

@@ -43,6 +43,8 @@ struct isdf_ctx {
   int num_cu = 256;
   // triangular solves of the fit: 0 = rocBLAS dtrsm (default, faster), 1 = substitution blocks of trsm.hip
   int trsm_substitution = 0;
+  // range-separation parameter of the Gamma-point Coulomb kernel table (0 = plain 1/r); isdf_set_coulomb_omega
+  double coul_omega = 0.0;
 };
 
 int isdf_fail(isdf_handle h, int code, const char* fmt, ...);

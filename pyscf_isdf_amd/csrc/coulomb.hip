@@ -27,8 +27,16 @@ __device__ inline double g2_of(int ix, int iy, int iz, int n0, int n1, int n2, c
 // c_sym(G) = (c(idx) + c(mirror idx)) / 2.  On even meshes the Nyquist index keeps frequency -n/2
 // in both idx and its mirror, so c is not inversion symmetric there for non-orthogonal lattices;
 // symmetrising makes the real-to-complex / complex-to-real pair reproduce the reference exactly.
+// omega != 0: range separation as pyscf/pbc/tools/pbc.py:408-418 applies it to the kernel, 4 pi/G^2 * exp(-G^2/(4 omega^2))
+// for omega > 0 (long range, erf(omega r)/r), 4 pi/G^2 * (1 - exp(-G^2/(4 omega^2))) for omega < 0 (short range); G = 0 stays 0.
+__device__ inline double range_factor(double g2, double omega) {
+  if (omega == 0.0) return 1.0;
+  const double e = exp(-0.25 * g2 / (omega * omega));
+  return omega > 0.0 ? e : 1.0 - e;
+}
+
 __global__ void coulG_half_kernel(double* __restrict__ out, int n0, int n1, int n2, Recip r,
-                                  double scale) {
+                                  double scale, double omega) {
   const int n2h = n2 / 2 + 1;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t tot = (int64_t)n0 * n1 * n2h;
@@ -38,8 +46,10 @@ __global__ void coulG_half_kernel(double* __restrict__ out, int n0, int n1, int 
   const int ix = (int)(idx / ((int64_t)n2h * n1));
   if (ix == 0 && iy == 0 && iz == 0) { out[idx] = 0.0; return; }
   const double fourpi = 4.0 * 3.14159265358979323846;
-  const double c1 = fourpi / g2_of(ix, iy, iz, n0, n1, n2, r);
-  const double c2 = fourpi / g2_of((n0 - ix) % n0, (n1 - iy) % n1, (n2 - iz) % n2, n0, n1, n2, r);
+  const double g1 = g2_of(ix, iy, iz, n0, n1, n2, r);
+  const double g2 = g2_of((n0 - ix) % n0, (n1 - iy) % n1, (n2 - iz) % n2, n0, n1, n2, r);
+  const double c1 = fourpi / g1 * range_factor(g1, omega);
+  const double c2 = fourpi / g2 * range_factor(g2, omega);
   out[idx] = scale * 0.5 * (c1 + c2);
 }
 
@@ -77,7 +87,7 @@ static int get_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9
   Recip rr;
   for (int i = 0; i < 9; ++i) rr.b[i] = b[i];
   hipLaunchKernelGGL(coulG_half_kernel, dim3((unsigned)cdiv(gc, 256)), dim3(256), 0, h->stream, cg, mesh[0],
-                     mesh[1], mesh[2], rr, extra_scale / (double)G);
+                     mesh[1], mesh[2], rr, extra_scale / (double)G, h->coul_omega);
   KERNEL_CHECK(h);
   *out = cg;
   return ISDF_OK;

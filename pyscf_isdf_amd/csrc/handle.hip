@@ -59,6 +59,12 @@ extern "C" {
 
 int isdf_abi_version(void) { return 10; }
 
+int isdf_set_coulomb_omega(isdf_handle h, double omega) {
+  if (!h) return ISDF_ERR_ARG;
+  h->coul_omega = omega;
+  return ISDF_OK;
+}
+
 int isdf_set_option(isdf_handle h, const char* key, int value) {
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, key != nullptr);

@@ -69,6 +69,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         self._comm = comm
         self._rsh_df = {}
         self._built = False
+        self._W_omega = {}               # range-separated W per omega (get_jk(omega=...)), valid until the next build
+        self._fit_state = None
         self._bufs = {}
         self._ovlp = None
         self.timings = {}
@@ -172,6 +174,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
 
     def build(self):
         self.check_sanity()
+        self._W_omega = {}
         if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
             return self._build_kpts()
         if self.comm.size > 1 or self.force_sharded:
@@ -261,13 +264,11 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
                     # forward solve only (Y = Lr^-1 B); the backward solve is applied to the (P, P) matrix below
                     be.fit_apply(chol, self.aoP, self.ao, G, theta, forward_only=not self.explicit_theta)
                 t0 = self._tick('S3_fit', t0)
-                batch = self.fft_batch or _default_fft_batch(G, P, be.free_bytes())
-                be.coulomb_W(theta, mesh, a, 0, P, batch, self.W, upper_only=True)
-                be.symmetrize_upper(self.W)
                 if route == 'blockjacobi':
-                    self._bj_finish(Afac, Dblk, ip_off, self.W)
-                elif not self.explicit_theta:
-                    be.W_from_factor(chol, 0, self.W)
+                    self._fit_state = dict(kind='blockjacobi', theta=theta, Afac=Afac, Dblk=Dblk, ip_off=ip_off)
+                else:
+                    self._fit_state = dict(kind='explicit' if self.explicit_theta else 'cholesky', theta=theta, chol=chol)
+                self._finish_W(self.W)
                 t0 = self._tick('S4S5_coulomb_W', t0)
                 self.fit_route_used = route
                 if route == 'blockjacobi' and self.fit_route == 'auto':
@@ -288,24 +289,72 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
 
         # S4 + S5 Coulomb convolution and W (global selection)
         self.W = self._buffer('W', (P, P))
-        batch = self.fft_batch or _default_fft_batch(G, P)
-        be.coulomb_W(theta, mesh, a, 0, P, batch, self.W, upper_only=True)
-        be.symmetrize_upper(self.W)
-        if factor is not None:
-            be.W_from_factor(factor[0], factor[1], self.W)
+        self._fit_state = dict(kind='explicit', theta=theta) if factor is None else \
+            dict(kind='selection', theta=theta, T=factor[0])
+        self._finish_W(self.W)
         self.fit_route_used = 'selection-cholesky'
         del theta
         t0 = self._tick('S4S5_coulomb_W', t0)
         self._built = True
         return self
 
+    def _finish_W(self, W):
+        """S4 + S5 for the fit held in self._fit_state (rows Y / Y' / Theta in the fit buffer + the factors that go with
+        them): W <- w conv(rows) rows^T, then the route's P x P finishing.  Uses the Coulomb kernel the backend is set to
+        (plain, or range-separated for get_jk(omega=...): the fit itself does not depend on the kernel)."""
+        be, st = self.backend, self._fit_state
+        theta = st['theta']
+        P, G = theta.shape
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        a = np.asarray(self.cell.lattice_vectors(), dtype=float)
+        batch = self.fft_batch or _default_fft_batch(G, P, be.free_bytes())
+        be.coulomb_W(theta, mesh, a, 0, P, batch, W, upper_only=True)
+        be.symmetrize_upper(W)
+        if st['kind'] == 'blockjacobi':
+            self._bj_finish(st['Afac'], st['Dblk'], st['ip_off'], W)
+        elif st['kind'] == 'cholesky':
+            be.W_from_factor(st['chol'], 0, W)
+        elif st['kind'] == 'selection':
+            be.W_from_factor(st['T'], 1, W)
+
+    def _get_jk_omega(self, dm, hermi, kpts, kpts_band, with_j, with_k, omega, exxdiv):
+        """Range-separated J/K (FFTDF.get_jk(omega=...), pyscf/pbc/df/fft.py:298-303): the Coulomb kernel carries
+        exp(-G^2/4 omega^2) (omega > 0, long range) or 1 - exp(...) (omega < 0, short range) as pbc.py:408-418 has it.
+        The fit does not depend on the kernel: only S4/S5 are redone, once per omega (cached until the next build)."""
+        ex = exxdiv if exxdiv is not None else self.exxdiv
+        if ex not in (None, 'None'):
+            raise NotImplementedError('range-separated J/K: only exxdiv=None is implemented')
+        if self.comm.size > 1 or self.force_sharded:
+            raise NotImplementedError('range-separated J/K is not implemented for the grid-sharded multi-GPU build')
+        be = self.backend
+        if not self._built:
+            self.build()
+        key = round(float(omega), 10)
+        be.set_coulomb_omega(omega)
+        try:
+            if key not in self._W_omega:
+                t0 = time.perf_counter()
+                W = be.empty(tuple(self.W.shape))
+                self._finish_W(W)
+                self._W_omega[key] = W
+                self._tick('S4S5_coulomb_W_omega', t0)
+            W_plain, self.W = self.W, self._W_omega[key]
+            try:
+                return self.get_jk(dm, hermi, kpts, kpts_band, with_j, with_k, None, exxdiv)
+            finally:
+                self.W = W_plain
+        finally:
+            be.set_coulomb_omega(0.0)
+
     # ---- J / K ---------------------------------------------------------------------------------
     def get_jk(self, dm, hermi=1, kpts=None, kpts_band=None, with_j=True, with_k=True, omega=None,
                exxdiv=None):
-        if omega is not None:
-            raise NotImplementedError('range-separated Coulomb kernel (omega) is not implemented for ISDF')
         if kpts is None:
             kpts = self.kpts
+        if omega is not None and abs(omega) > 0:
+            if not self._is_gamma(kpts) or not self._is_gamma(self.kpts) or not self._is_gamma(kpts_band):
+                raise NotImplementedError('range-separated J/K is implemented at the Gamma point only')
+            return self._get_jk_omega(dm, hermi, kpts, kpts_band, with_j, with_k, omega, exxdiv)
         if not self._is_gamma(kpts) or not self._is_gamma(self.kpts) or not self._is_gamma(kpts_band):
             if self._is_gamma(kpts) and np.asarray(dm).ndim == 2:
                 dm = np.asarray(dm)[None]                       # Gamma-point density, band structure requested

@@ -5,7 +5,7 @@ including the wrap-around of k+G beyond the mesh edge :272-302 and the zeroing o
 import numpy as np
 
 
-def get_coulG(cell, q=np.zeros(3), mesh=None, wrap_around=True):
+def get_coulG(cell, q=np.zeros(3), mesh=None, wrap_around=True, omega=None):
     if mesh is None:
         mesh = cell.mesh
     a = np.asarray(cell.lattice_vectors(), dtype=float)
@@ -36,6 +36,9 @@ def get_coulG(cell, q=np.zeros(3), mesh=None, wrap_around=True):
     coulG[absG2 == 0] = 0
     if equal2boundary is not None:
         coulG[equal2boundary] = 0
+    if omega:                                   # range separation, pyscf/pbc/tools/pbc.py:408-418
+        e = np.exp(-.25 / omega ** 2 * absG2)
+        coulG = coulG * (e if omega > 0 else 1 - e)
     return coulG
 
 

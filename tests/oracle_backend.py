@@ -10,6 +10,13 @@ from oracle import ao as oao, isdf as oisdf, kisdf as okisdf, pbc_tools as tools
 class OracleBackend:
     name = 'oracle-cpu'
     device = torch.device('cpu')
+    omega = None
+
+    def set_coulomb_omega(self, omega):
+        self.omega = omega or None
+
+    def set_option(self, key, value):
+        pass
 
     def empty(self, shape, dtype=torch.float64):
         return torch.zeros(shape, dtype=dtype)
@@ -178,13 +185,13 @@ class OracleBackend:
 
     def coulomb_rows(self, rows, mesh, a, batch, out=None):
         out = rows if out is None else out
-        out.copy_(torch.from_numpy(oisdf.coulomb_V(rows.numpy(), a, mesh)))
+        out.copy_(torch.from_numpy(oisdf.coulomb_V(rows.numpy(), a, mesh, self.omega)))
 
     def coulomb_W(self, theta, mesh, a, row0, nrows, batch, W, upper_only=False):
         G = int(np.prod(mesh))
         w = abs(np.linalg.det(a)) / G
         th = theta.numpy()
-        V = oisdf.coulomb_V(th[row0:row0 + nrows], a, mesh)
+        V = oisdf.coulomb_V(th[row0:row0 + nrows], a, mesh, self.omega)
         W[row0:row0 + nrows, :th.shape[0]] = torch.from_numpy(w * V.dot(th.T))
 
     def symmetrize_upper(self, W):
@@ -207,7 +214,7 @@ class OracleBackend:
     def coulomb_potential(self, rho, mesh, a):
         G = int(np.prod(mesh))
         w = abs(np.linalg.det(a)) / G
-        rho.copy_(torch.from_numpy(w * oisdf.coulomb_V(rho.numpy(), a, mesh)))
+        rho.copy_(torch.from_numpy(w * oisdf.coulomb_V(rho.numpy(), a, mesh, self.omega)))
 
     def vj_from_vR(self, ao, ng, vR, vj):
         a = ao.numpy()[:, :ng]
@@ -215,7 +222,7 @@ class OracleBackend:
             vj[i] = torch.from_numpy((a * vR[i, :ng].numpy()).dot(a.T))
 
     def get_j(self, ao, ngrids, mesh, a, dm, vj):
-        vj.copy_(torch.from_numpy(oisdf.get_j(ao.numpy()[:, :ngrids], dm.numpy(), a, mesh)))
+        vj.copy_(torch.from_numpy(oisdf.get_j(ao.numpy()[:, :ngrids], dm.numpy(), a, mesh, self.omega)))
 
     def get_k(self, aoP, W, row0, nrows, dm, vk):
         ap, w = aoP.numpy(), W.numpy()

@@ -381,6 +381,34 @@ def test_sharded_code_path_on_one_gpu(route):
     assert abs(vj0 - vj1).max() < 1e-10 and abs(vk0 - vk1).max() < tol * abs(vk0).max()
 
 
+@pytest.mark.parametrize('omega', [0.4, -0.4, 0.11])
+def test_range_separated_get_jk(omega):
+    """get_jk(omega=...) (FFTDF.get_jk with range_coulomb, pyscf/pbc/df/fft.py:298-303): the device kernel table carries the
+    factor of pyscf/pbc/tools/pbc.py:408-418.  J against the reference formula, K against the oracle's W built with the
+    attenuated kernel on the same points, on the triclinic He2 cell (even, non-orthogonal mesh: symmetrised half spectrum);
+    long range + short range = full."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he2_triclinic()
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(2)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    aoT = _oracle_ao(cell)[0]
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    df = ISDF(cell, c_isdf=4, select='local')
+    df.fit_route = 'cholesky'
+    vj0, vk0 = df.get_jk(dm)
+    vj, vk = df.get_jk(dm, omega=omega)
+    assert vj.dtype == np.float64 and abs(vj - oisdf.get_j(aoT, dm, a, mesh, omega=omega)).max() < 1e-10
+    th = oisdf.fit_theta_global_chol(aoT, df.ip, reg_rel=df.reg_used)
+    k_or = oisdf.get_k(np.ascontiguousarray(aoT[:, df.ip].T), oisdf.build_W(th, a, mesh, omega=omega), dm)
+    assert abs(vk - k_or).max() < 1e-8 * abs(k_or).max()
+    vj2, vk2 = df.get_jk(dm, omega=-omega)
+    assert abs(vj + vj2 - vj0).max() < 1e-11 and abs(vk + vk2 - vk0).max() < 1e-9 * abs(vk0).max()
+    assert sorted(df._W_omega) == sorted([round(omega, 10), round(-omega, 10)])
+    auto = ISDF(cell, c_isdf=4, select='local')                       # block-Jacobi route: same W up to its noise
+    assert abs(auto.get_jk(dm, omega=omega)[1] - vk).max() < 1e-6 * abs(vk).max()
+
+
 def test_exxdiv_ewald_adds_madelung_SDS():
     """exxdiv='ewald' = exxdiv=None + madelung * S D S (df_jk.py:1446-1452) with the grid-quadrature overlap."""
     from pyscf_isdf_amd.isdf import ISDF

@@ -134,3 +134,37 @@ def test_auto_route_logic_with_checker_backend():
     assert ISDF(cell, c_isdf=15, select='local', backend=OracleBackend())._fit_routes() == ['cholesky']
     with pytest.raises(ValueError):
         bad = ISDF(cell, c_isdf=4, select='local', backend=OracleBackend()); bad.fit_route = 'nonsense'; bad.build()
+
+
+def test_range_separated_get_jk_host_logic_with_checker_backend():
+    """get_jk(omega=...): long-range + short-range = full Coulomb for J and K, W rebuilt once per omega from the same
+    fit and cached, cache dropped by the next build; the oracle's kernel follows pyscf/pbc/tools/pbc.py:408-418."""
+    import cells
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_diamond_prim('gth-szv', (12, 12, 12))
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(1)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    aoT = oao.eval_ao(cell._atm, cell._bas, cell._env, cell.get_uniform_grids(), gto.get_lattice_Ls(cell, rcut=gto.estimate_rcut_per_shell(cell).max()),
+                      gto.estimate_rcut_per_shell(cell), rule='point').T
+    for route in ('cholesky', 'auto'):
+        df = ISDF(cell, c_isdf=6, select='local', backend=OracleBackend())
+        df.fit_route = route
+        vj, vk = df.get_jk(dm)
+        vjl, vkl = df.get_jk(dm, omega=0.4)
+        vjs, vks = df.get_jk(dm, omega=-0.4)
+        assert sorted(df._W_omega) == [-0.4, 0.4]
+        assert abs(vjl + vjs - vj).max() < 1e-12 and abs(vkl + vks - vk).max() < 1e-7 * abs(vk).max()
+        assert 1e-3 < abs(vkl).max() / abs(vk).max() < 0.5                       # the long-range part is a real fraction
+        # J against the reference formula with the attenuated kernel
+        assert abs(vjl - oisdf.get_j(aoT, dm, cell.lattice_vectors(), cell.mesh, omega=0.4)).max() < 1e-10
+        # K against the oracle's W with the attenuated kernel on the same points (Cholesky route: same regularised fit)
+        if route == 'cholesky':
+            th = oisdf.fit_theta_global_chol(aoT, df.ip, reg_rel=df.reg_used) if hasattr(oisdf, 'fit_theta_global_chol') else None
+            if th is not None:
+                W = oisdf.build_W(th, cell.lattice_vectors(), cell.mesh, omega=0.4)
+                k_or = oisdf.get_k(np.ascontiguousarray(aoT[:, df.ip].T), W, dm)
+                assert abs(vkl - k_or).max() < 1e-8 * abs(k_or).max()
+        df.build()
+        assert df._W_omega == {}
