@@ -353,7 +353,9 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
             kpts = self.kpts
         if omega is not None and abs(omega) > 0:
             if not self._is_gamma(kpts) or not self._is_gamma(self.kpts) or not self._is_gamma(kpts_band):
-                raise NotImplementedError('range-separated J/K is implemented at the Gamma point only')
+                if self._is_gamma(kpts) and np.asarray(dm).ndim == 2:
+                    dm = np.asarray(dm)[None]
+                return self._get_jk_kpts(dm, hermi, kpts, kpts_band, with_j, with_k, exxdiv, omega=omega)
             return self._get_jk_omega(dm, hermi, kpts, kpts_band, with_j, with_k, omega, exxdiv)
         if not self._is_gamma(kpts) or not self._is_gamma(self.kpts) or not self._is_gamma(kpts_band):
             if self._is_gamma(kpts) and np.asarray(dm).ndim == 2:

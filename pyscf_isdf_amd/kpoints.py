@@ -101,8 +101,6 @@ class KPointMixin:
             if partner[iq] >= 0:
                 self._q_owner[partner[iq]] = n % comm.size
         r_ip = coords[self.ip]
-        Wre = self._buffer('Wre', (P, P))
-        Wim = self._buffer('Wim', (P, P))
 
         # S3 + S4 + S5, route by route.  'auto' means the Cholesky route here unless bj_auto_kpts is set; then: block-
         # Jacobi, verified on W^{q=0}, Cholesky when the check fails (the fit is replicated, so every rank takes the
@@ -120,31 +118,10 @@ class KPointMixin:
                 self.reg_used = be.fit_prepare_cplx(X, nh, ip_dev, self.reg_rel, aoP_X, chol)
                 be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=not self.explicit_theta)
             t0 = self._tick('S3_fit', t0)
-            self._Wq = {}
-            check = 0.0
-            for iq in primary:
-                if self._q_owner[iq] != comm.rank:
-                    continue
-                q = self._qs[iq]
-                coulG = be.to_device(pbc_tools.get_coulG(cell, q, mesh))
-                be.coulomb_Wq(Y, mesh, coulG, w, 0, P, batch, Wre, Wim, upper_only=True)
-                be.symmetrize_hermitian(Wre, Wim)
-                if route == 'blockjacobi':
-                    self._bj_finish(Afac, Dblk, ip_off, Wre)
-                    self._bj_finish(Afac, Dblk, ip_off, Wim, antisymmetric=True)
-                    if self.fit_route == 'auto' and abs(q).max() < 1e-9:
-                        # W^0 is real: the Gamma-point probe check with the densities sum_k u^k* R u^k
-                        t1 = self._tick('S4S5_coulomb_W', t0)
-                        planes = [aoP_X[:, o:o + nao].T.contiguous() for o in range(0, 2 * nh, nao)]
-                        check = self._bj_probe_mismatch(planes, Afac, Dblk, ip_off, Y, G, None, W=Wre)
-                        del planes
-                        t0 = self._tick('S5_route_check', t1)
-                elif not self.explicit_theta:
-                    be.W_from_factor(chol, 0, Wre)
-                    be.W_from_factor(chol, 0, Wim)
-                Wc = be.empty((P, P), dtype=torch.complex128)
-                be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * r_ip.dot(q))), Wc)
-                self._Wq[iq] = Wc
+            self._kfit_state = dict(route=route, Y=Y, primary=primary, r_ip=r_ip, batch=batch, nao=nao, nh=nh, aoP_X=aoP_X,
+                                    chol=None if route == 'blockjacobi' else chol,
+                                    bj=(Afac, Dblk, ip_off) if route == 'blockjacobi' else None)
+            self._Wq, check, t0 = self._build_Wq(None, t0, probe=(route == 'blockjacobi' and self.fit_route == 'auto'))
             self.fit_route_used = route
             if route == 'blockjacobi' and self.fit_route == 'auto':
                 self.bj_check = comm.agree_max(check)
@@ -168,13 +145,55 @@ class KPointMixin:
         self._nk_stack = nk
         return self
 
-    def _get_jk_kpts(self, dm, hermi, kpts, kpts_band, with_j, with_k, exxdiv):
+    def _build_Wq(self, omega, t0, probe=False):
+        """S4 + S5 for this rank's share of the q list from the fit held in self._kfit_state: {iq: W^q (P, P) complex}.
+        omega: range separation of the kernel (pyscf/pbc/tools/pbc.py:408-418) - the fit does not depend on it."""
+        from . import pbc_tools
+        cell, be, comm = self.cell, self.backend, self.comm
+        st = self._kfit_state
+        Y, r_ip = st['Y'], st['r_ip']
+        P, G = Y.shape
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        w = cell.vol / G
+        Wre = self._buffer('Wre', (P, P))
+        Wim = self._buffer('Wim', (P, P))
+        out, check = {}, 0.0
+        for iq in st['primary']:
+            if self._q_owner[iq] != comm.rank:
+                continue
+            q = self._qs[iq]
+            coulG = be.to_device(pbc_tools.get_coulG(cell, q, mesh, omega=omega))
+            be.coulomb_Wq(Y, mesh, coulG, w, 0, P, st['batch'], Wre, Wim, upper_only=True)
+            be.symmetrize_hermitian(Wre, Wim)
+            if st['route'] == 'blockjacobi':
+                Afac, Dblk, ip_off = st['bj']
+                self._bj_finish(Afac, Dblk, ip_off, Wre)
+                self._bj_finish(Afac, Dblk, ip_off, Wim, antisymmetric=True)
+                if probe and abs(q).max() < 1e-9:
+                    # W^0 is real: the Gamma-point probe check with the densities sum_k u^k* R u^k
+                    t1 = self._tick('S4S5_coulomb_W', t0)
+                    nao, nh, aoP_X = st['nao'], st['nh'], st['aoP_X']
+                    planes = [aoP_X[:, o:o + nao].T.contiguous() for o in range(0, 2 * nh, nao)]
+                    check = self._bj_probe_mismatch(planes, Afac, Dblk, ip_off, Y, G, None, W=Wre)
+                    del planes
+                    t0 = self._tick('S5_route_check', t1)
+            elif not self.explicit_theta:
+                be.W_from_factor(st['chol'], 0, Wre)
+                be.W_from_factor(st['chol'], 0, Wim)
+            Wc = be.empty((P, P), dtype=torch.complex128)
+            be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * r_ip.dot(q))), Wc)
+            out[iq] = Wc
+        return out, check, t0
+
+    def _get_jk_kpts(self, dm, hermi, kpts, kpts_band, with_j, with_k, exxdiv, omega=None):
         """k-point J and K (pyscf/pbc/df/fft_jk.py:33-109,177-302 semantics).  dm (nk, N, N) or (nset, nk, N, N); with
         kpts_band the result lives on the band k-points, (nband, N, N) [(N, N) for a single (3,) band vector], as
         df_jk._format_jks shapes it (pyscf/pbc/df/df_jk.py:1426-1444)."""
         ex = exxdiv if exxdiv is not None else self.exxdiv
         if ex not in (None, 'None', 'ewald'):
             raise NotImplementedError("k-point ISDF: only exxdiv=None and 'ewald' are implemented")
+        if omega and ex == 'ewald':
+            raise NotImplementedError('range-separated J/K: only exxdiv=None is implemented')
         cell, be, comm = self.cell, self.backend, self.comm
         kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
         band_in = None if kpts_band is None else np.asarray(kpts_band, dtype=float)
@@ -211,6 +230,29 @@ class KPointMixin:
             (dm_in.shape[:-3] + ((nband,) if band_in.ndim > 1 else ()) + (nao, nao))
         vj = vk = None
         t0 = time.perf_counter()
+        Wq_set = self._Wq
+        if omega:
+            # range separation: same fit, the W^q rebuilt with the attenuated kernel once per omega (until the next build)
+            key = round(float(omega), 10)
+            if key not in self._W_omega:
+                self._W_omega[key], _, t0 = self._build_Wq(omega, t0)
+                t0 = self._tick('S4S5_coulomb_W_omega', t0)
+            Wq_set = self._W_omega[key]
+            be.set_coulomb_omega(omega)                          # the J kernel table lives on the device
+        try:
+            vj, vk = self._jk_from_Wq(Wq_set, dms, nk, bidx, planes, out_shape, with_j, with_k, ex, herm_dm, kpts, t0)
+        finally:
+            if omega:
+                be.set_coulomb_omega(0.0)
+        return vj, vk
+
+    def _jk_from_Wq(self, Wq_set, dms, nk, bidx, planes, out_shape, with_j, with_k, ex, herm_dm, kpts, t0):
+        cell, be, comm = self.cell, self.backend, self.comm
+        nset, nband, nao = dms.shape[0], len(bidx), cell.nao_nr()
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        vj = vk = None
         if with_j:
             vj = np.zeros((nset, nband, nao, nao), dtype=np.complex128)
             for s in range(nset):
@@ -240,10 +282,10 @@ class KPointMixin:
                         iq = self._qindex[i1, k2]
                         if self._q_owner[iq] != comm.rank:
                             continue
-                        if iq in self._Wq:
-                            Wq = self._Wq[iq]
+                        if iq in Wq_set:
+                            Wq = Wq_set[iq]
                         else:                      # stored as its time-reversal partner: W^{-q} = conj(W^q)
-                            Wq = torch.conj_physical(self._Wq[self._q_partner[iq]])
+                            Wq = torch.conj_physical(Wq_set[self._q_partner[iq]])
                         be.get_k_pair(self._aoP_k[k1], self._aoP_k[k2], d_dm[k2], Wq, 1.0 / nk, d_vk[s, i1])
             if comm.size > 1:
                 flat = torch.view_as_real(d_vk)

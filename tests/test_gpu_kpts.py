@@ -157,6 +157,27 @@ def test_isdf_kpts_fit_routes_agree():
     assert abs(vk - out['cholesky'][0]).max() < 1e-12 * abs(vk).max()
 
 
+def test_range_separated_kpoint_jk():
+    """get_jk(omega=...) with k-points: W^q rebuilt with the attenuated kernel (pbc.py:408-418) from the same fit; J against
+    the reference formula with that kernel, long range + short range = full for J and K."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell, coords, Ls, rcut, kpts, aos, dms = _setup()
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    df = ISDF(cell, kpts=kpts, c_isdf=6, select='local')
+    vj, vk = df.get_jk(dms, kpts=kpts)
+    vjl, vkl = df.get_jk(dms, kpts=kpts, omega=0.5)
+    vjs, vks = df.get_jk(dms, kpts=kpts, omega=-0.5)
+    assert sorted(df._W_omega) == [-0.5, 0.5]
+    assert abs(vjl + vjs - vj).max() < 1e-11 and abs(vkl + vks - vk).max() < 1e-10 * abs(vk).max()
+    assert 0.05 < abs(vkl).max() / abs(vk).max() < 0.9
+    # J with the attenuated kernel, reference formula (fft_jk.py:63-107)
+    G = len(coords)
+    rho = sum(np.einsum('gi,ij,gj->g', ao, d, ao.conj()) for ao, d in zip(aos, dms)) / len(kpts)
+    vR = otools.ifft(otools.get_coulG(a, mesh, omega=0.5) * otools.fft(rho, mesh), mesh) * (cell.vol / G)
+    vj_ref = np.array([ao.conj().T.dot(vR[:, None] * ao) for ao in aos])
+    assert abs(vjl - vj_ref).max() < 1e-10
+
+
 def test_non_hermitian_density_matrices():
     """hermi=0: the density is complex; J from its real and imaginary parts equals the reference formula (fft_jk.py:63-107),
     K (which never assumed a Hermitian D) the oracle's k-ISDF on the same points."""

@@ -54,8 +54,8 @@ def test_isdf_surface_and_errors():
         assert callable(getattr(df, name))
     assert list(df.mesh) == [21, 21, 21] and df.grids.weights.shape == (9261,)
     assert abs(df.grids.weights.sum() - cell.vol) < 1e-9
-    with pytest.raises(NotImplementedError):                       # range separation: Gamma point only
-        ISDF(cell, kpts=np.array([[0.1, 0., 0.], [0., 0., 0.]])).get_jk(np.zeros((2, 6, 6)), omega=0.3)
+    with pytest.raises(NotImplementedError):                       # range separation: exxdiv=None only
+        ISDF(cell, kpts=np.array([[0.1, 0., 0.], [0., 0., 0.]])).get_jk(np.zeros((2, 6, 6)), omega=0.3, exxdiv='ewald')
     with pytest.raises(NotImplementedError):
         df.get_jk(np.eye(6), exxdiv='vcut_sph')
     with pytest.raises(NotImplementedError):
