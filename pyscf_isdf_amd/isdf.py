@@ -324,8 +324,6 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         ex = exxdiv if exxdiv is not None else self.exxdiv
         if ex not in (None, 'None'):
             raise NotImplementedError('range-separated J/K: only exxdiv=None is implemented')
-        if self.comm.size > 1 or self.force_sharded:
-            raise NotImplementedError('range-separated J/K is not implemented for the grid-sharded multi-GPU build')
         be = self.backend
         if not self._built:
             self.build()
@@ -335,7 +333,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
             if key not in self._W_omega:
                 t0 = time.perf_counter()
                 W = be.empty(tuple(self.W.shape))
-                self._finish_W(W)
+                (self._finish_W_sharded if self._fit_state.get('sharded') else self._finish_W)(W)
                 self._W_omega[key] = W
                 self._tick('S4S5_coulomb_W_omega', t0)
             W_plain, self.W = self.W, self._W_omega[key]

@@ -143,46 +143,12 @@ class ShardedMixin:
                 be.fit_apply(chol, self.aoP, self.ao, ng, theta, forward_only=not self.explicit_theta)
             t0 = self._tick('S3_fit', t0)
 
-            # S4 + S5 streamed over row batches: rank q convolves rows P_q[t*nb : (t+1)*nb] in step t
-            w = cell.vol / G
+            self._fit_state = dict(kind=route if route == 'blockjacobi' else ('explicit' if self.explicit_theta else 'cholesky'),
+                                   theta=theta, sharded=True,
+                                   Afac=Afac if route == 'blockjacobi' else None, Dblk=Dblk if route == 'blockjacobi' else None,
+                                   ip_off=ip_off, chol=None if route == 'blockjacobi' else chol)
             self.W = self._buffer('W', (P, P))
-            self.W.zero_()
-            slices = [comm.split_range(G, r) for r in range(R)]
-            rows = [comm.split_range(P, r) for r in range(R)]
-            nb = self.fft_batch or _default_fft_batch(G, max(1, P // R))
-            nsteps = max(-(-(hi - lo) // nb) for lo, hi in rows)
-            for t in range(nsteps):
-                bat = [(min(lo + t * nb, hi), min(lo + (t + 1) * nb, hi)) for lo, hi in rows]   # rows handled by rank q
-                nrow = [hi - lo for lo, hi in bat]
-                # all-to-all 1: send Theta[bat_q, S_r] to q; receive Theta[bat_r, S_q] from q
-                send = [theta[lo:hi] for lo, hi in bat]
-                recv = [be.empty((nrow[rk], s1 - s0)) for s0, s1 in slices]
-                comm.all_to_all(recv, send)
-                full = be.empty((nrow[rk], G))
-                for (s0, s1), piece in zip(slices, recv):
-                    full[:, s0:s1] = piece
-                del recv
-                if nrow[rk]:
-                    be.coulomb_rows(full, mesh, a, max(1, nrow[rk]))
-                # all-to-all 2: send V[bat_r, S_q] to q; receive V[bat_q, S_r] from q
-                send = [full[:, s0:s1].contiguous() for s0, s1 in slices]
-                recv = [be.empty((nrow[q], ng)) for q in range(R)]
-                comm.all_to_all(recv, send)
-                del full, send
-                for q in range(R):
-                    if nrow[q]:
-                        # W[bat_q, c0:] = w V[bat_q, S_r] Theta[c0:, S_r]^T  (partial over this rank's slice).
-                        # W is symmetric: only the columns from the batch's first row on are computed and
-                        # the lower part is mirrored after the all-reduce (half the flops).
-                        c0 = bat[q][0]
-                        be.gemm_nt(recv[q], theta[c0:], self.W[bat[q][0]:bat[q][1], c0:], alpha=w, beta=0.0)
-                del recv
-            comm.all_reduce_sum(self.W)
-            be.symmetrize_upper(self.W)
-            if route == 'blockjacobi':
-                self._bj_finish_sharded(Afac, Dblk, ip_off, self.W)
-            elif not self.explicit_theta:
-                be.W_from_factor(chol, 0, self.W)
+            self._finish_W_sharded(self.W)
             t0 = self._tick('S4S5_coulomb_W', t0)
             self.fit_route_used = route
             if route == 'blockjacobi' and self.fit_route == 'auto':
@@ -196,6 +162,58 @@ class ShardedMixin:
         del theta, aoP_T
         self._built = True
         return self
+
+    def _finish_W_sharded(self, W):
+        """S4 + S5 of the grid-sharded build for the fit held in self._fit_state (rows on this rank's grid slice + the
+        replicated factors): two all-to-alls around the row convolution, partial W over the slice, all-reduce, finishing.
+        Uses the Coulomb kernel the backend is set to (plain, or range-separated for get_jk(omega=...))."""
+        cell, be, comm = self.cell, self.backend, self.comm
+        st = self._fit_state
+        theta = st['theta']
+        P, ng = theta.shape
+        R, rk = comm.size, comm.rank
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        # S4 + S5 streamed over row batches: rank q convolves rows P_q[t*nb : (t+1)*nb] in step t
+        w = cell.vol / G
+        W.zero_()
+        slices = [comm.split_range(G, r) for r in range(R)]
+        rows = [comm.split_range(P, r) for r in range(R)]
+        nb = self.fft_batch or _default_fft_batch(G, max(1, P // R))
+        nsteps = max(-(-(hi - lo) // nb) for lo, hi in rows)
+        for t in range(nsteps):
+            bat = [(min(lo + t * nb, hi), min(lo + (t + 1) * nb, hi)) for lo, hi in rows]   # rows handled by rank q
+            nrow = [hi - lo for lo, hi in bat]
+            # all-to-all 1: send Theta[bat_q, S_r] to q; receive Theta[bat_r, S_q] from q
+            send = [theta[lo:hi] for lo, hi in bat]
+            recv = [be.empty((nrow[rk], s1 - s0)) for s0, s1 in slices]
+            comm.all_to_all(recv, send)
+            full = be.empty((nrow[rk], G))
+            for (s0, s1), piece in zip(slices, recv):
+                full[:, s0:s1] = piece
+            del recv
+            if nrow[rk]:
+                be.coulomb_rows(full, mesh, a, max(1, nrow[rk]))
+            # all-to-all 2: send V[bat_r, S_q] to q; receive V[bat_q, S_r] from q
+            send = [full[:, s0:s1].contiguous() for s0, s1 in slices]
+            recv = [be.empty((nrow[q], ng)) for q in range(R)]
+            comm.all_to_all(recv, send)
+            del full, send
+            for q in range(R):
+                if nrow[q]:
+                    # W[bat_q, c0:] = w V[bat_q, S_r] Theta[c0:, S_r]^T  (partial over this rank's slice).
+                    # W is symmetric: only the columns from the batch's first row on are computed and
+                    # the lower part is mirrored after the all-reduce (half the flops).
+                    c0 = bat[q][0]
+                    be.gemm_nt(recv[q], theta[c0:], W[bat[q][0]:bat[q][1], c0:], alpha=w, beta=0.0)
+            del recv
+        comm.all_reduce_sum(W)
+        be.symmetrize_upper(W)
+        if st['kind'] == 'blockjacobi':
+            self._bj_finish_sharded(st['Afac'], st['Dblk'], st['ip_off'], W)
+        elif st['kind'] == 'cholesky':
+            be.W_from_factor(st['chol'], 0, W)
 
     def _get_jk_sharded(self, d_dm, out_shape, with_j, with_k, exxdiv=None):
         cell, be, comm = self.cell, self.backend, self.comm

@@ -379,6 +379,10 @@ def test_sharded_code_path_on_one_gpu(route):
     # the block-Jacobi route amplifies the (layout-dependent) summation order of M' by cond(A')
     tol = 1e-9 if ref.fit_route_used == 'cholesky' else 1e-6
     assert abs(vj0 - vj1).max() < 1e-10 and abs(vk0 - vk1).max() < tol * abs(vk0).max()
+    # range separation goes through the same sharded S4/S5
+    wj0, wk0 = ref.get_jk(dm, omega=0.3)
+    wj1, wk1 = df.get_jk(dm, omega=0.3)
+    assert abs(wj0 - wj1).max() < 1e-10 and abs(wk0 - wk1).max() < tol * abs(wk0).max()
 
 
 @pytest.mark.parametrize('omega', [0.4, -0.4, 0.11])

@@ -34,7 +34,11 @@ def _run_case(comm, fft_batch, route='cholesky'):
     df.bj_check_tol = 1e-6                     # c_isdf=3 on 8 AOs: the check value is ~1e-8, far from the decision
     df.build()
     vj, vk = df.get_jk(dm)
-    return df.ip.copy(), df.W.numpy().copy(), vj, vk, df.fit_route_used, df.bj_check
+    # range separation through the sharded S4/S5: long range + short range = full, on every layout
+    vjl, vkl = df.get_jk(dm, omega=0.4)
+    vjs, vks = df.get_jk(dm, omega=-0.4)
+    assert abs(vjl + vjs - vj).max() < 1e-11 and abs(vkl + vks - vk).max() < 1e-7 * abs(vk).max()
+    return df.ip.copy(), df.W.numpy().copy(), vj, vk + 0.0 * vkl, df.fit_route_used, df.bj_check
 
 
 def _worker(rank, world, port, q, route):
