@@ -298,6 +298,29 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         self._built = True
         return self
 
+    def range_coulomb(self, omega):
+        """FFTDF.range_coulomb (pyscf/pbc/df/fft.py:337-359): a context manager whose object answers get_jk / get_ao_eri-less
+        calls with the range-separated kernel.  Here it is a view of this object that adds ``omega`` to get_jk."""
+        import contextlib
+        parent = self
+
+        class _RangeSeparatedView:
+            def __getattr__(self, name):
+                return getattr(parent, name)
+
+            def get_jk(self, dm, hermi=1, kpts=None, kpts_band=None, with_j=True, with_k=True, omega=None, exxdiv=None):
+                return parent.get_jk(dm, hermi, kpts, kpts_band, with_j, with_k, omega if omega is not None else omega_, exxdiv)
+        omega_ = omega
+
+        @contextlib.contextmanager
+        def ctx():
+            yield _RangeSeparatedView()
+        return ctx()
+
+    def to_gpu(self):
+        """FFTDF.to_gpu (pyscf/pbc/df/fft.py): this object already runs on the GPU."""
+        return self
+
     def _finish_W(self, W):
         """S4 + S5 for the fit held in self._fit_state (rows Y / Y' / Theta in the fit buffer + the factors that go with
         them): W <- w conv(rows) rows^T, then the route's P x P finishing.  Uses the Coulomb kernel the backend is set to

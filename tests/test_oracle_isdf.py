@@ -166,5 +166,8 @@ def test_range_separated_get_jk_host_logic_with_checker_backend():
                 W = oisdf.build_W(th, cell.lattice_vectors(), cell.mesh, omega=0.4)
                 k_or = oisdf.get_k(np.ascontiguousarray(aoT[:, df.ip].T), W, dm)
                 assert abs(vkl - k_or).max() < 1e-8 * abs(k_or).max()
+        with df.range_coulomb(0.4) as rsh:                                       # FFTDF.range_coulomb surface
+            assert abs(rsh.get_jk(dm)[1] - vkl).max() < 1e-14 and rsh.cell is df.cell
+        assert df.to_gpu() is df
         df.build()
         assert df._W_omega == {}
