@@ -8,8 +8,11 @@ with_k, omega, exxdiv)``, ``get_naoaux()``, ``get_ao_eri()/get_eri()``, ``update
 (pyscf/pbc/scf/hf.py:649-698) only ever use these.  Array conventions of get_jk follow
 pyscf/pbc/df/df_jk.py:1411-1444: the result has the shape of ``dm``; Γ point + real dm -> float64.
 
-What runs where: this file is host orchestration only (which stage, which buffers, which rank);
+What runs where: this file and its mixins are host orchestration only (which stage, which buffers, which rank);
 every stage executes in libmi355_isdf.so via ``backend.HipBackend``.  There is no CPU path.
+Modules: ``isdf`` (the object, Gamma-point single-GPU build and get_jk, ERIs, range separation), ``fit_route`` (fit routes and
+the probe check), ``sharded`` (grid-sharded multi-GPU build), ``kpoints`` (k-points, band k-points, k-point ERIs),
+``hcore`` (get_nuc / get_pp).
 """
 import os
 import sys
