@@ -47,9 +47,15 @@ int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out
   int64_t Gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
   ARG_CHECK(h, G < (int64_t)2147483647);
   FFT_TRY(h, hipfftPlanMany(&p.fwd, 3, dims, nullptr, 1, (int)G, nullptr, 1, (int)Gc, HIPFFT_D2Z, batch));
-  FFT_TRY(h, hipfftPlanMany(&p.bwd, 3, dims, nullptr, 1, (int)Gc, nullptr, 1, (int)G, HIPFFT_Z2D, batch));
-  FFT_TRY(h, hipfftSetStream(p.fwd, h->stream));
-  FFT_TRY(h, hipfftSetStream(p.bwd, h->stream));
+  hipfftResult r2 = hipfftPlanMany(&p.bwd, 3, dims, nullptr, 1, (int)Gc, nullptr, 1, (int)G, HIPFFT_Z2D, batch);
+  if (r2 == HIPFFT_SUCCESS) r2 = hipfftSetStream(p.fwd, h->stream);
+  if (r2 == HIPFFT_SUCCESS) r2 = hipfftSetStream(p.bwd, h->stream);
+  if (r2 != HIPFFT_SUCCESS) {                       // do not leak the half-built pair
+    (void)hipfftDestroy(p.fwd);
+    if (p.bwd) (void)hipfftDestroy(p.bwd);
+    return isdf_fail(h, ISDF_ERR_LIB, "hipFFT plan (%d x %d x %d, batch %d) failed: result %d", mesh[0], mesh[1], mesh[2], batch,
+                     (int)r2);
+  }
   auto res = h->plans.emplace(key, p);
   *out = &res.first->second;
   return ISDF_OK;
