@@ -324,6 +324,135 @@ __global__ __launch_bounds__(TPB2, 2) void gemm_nt_mfma_kernel_b(GemmArgs g) {
   }
 }
 
+// ---- variant D: A straight from global memory into MFMA operand registers, only B through LDS ----------------------
+// 128 x 128 tile, four waves stacked along M (each 32 rows x all 128 columns: 2 x 8 accumulators), two workgroups per
+// CU.  The rows of A are private to a wave, so staging them through LDS buys nothing: lane (r = lane & 15, kq = lane >> 4)
+// loads A[row r][16 c + 4 kq .. + 3] (32 contiguous bytes; the four kq lanes of a row cover one 128-byte line) and uses
+// element j in the j-th MFMA of the chunk.  That permutes the order of the k index inside a 16-deep chunk
+// (k = 4 kq + j instead of 4 j + kq) - the B fragments are read from LDS with the same map, the sum is the same set of
+// products.  Only B (128 rows x 16) is written to LDS: a third of variant B's LDS writes per flop, 35 KB of LDS per
+// workgroup, and the two resident workgroups hide each other's barrier.
+constexpr int TPBD = 256;
+
+template <bool SCALED>
+__global__ __launch_bounds__(TPBD, 2) void gemm_nt_mfma_kernel_d(GemmArgs g) {
+  __shared__ double sB[2][BN * LDT];
+  const int64_t bid = blockIdx.x;
+  const int64_t per_xcd = g.nunits_pad / 8;
+  const int64_t unit = (bid % 8) * per_xcd + bid / 8;
+  if (unit >= g.nunits) return;
+  const int tm = (int)(unit % g.ntm);
+  const int tn = (int)((unit / g.ntm) % g.ntn);
+  const int slab = (int)(unit / ((int64_t)g.ntm * g.ntn));
+  const int64_t k0 = (int64_t)slab * g.kslab;
+  const int64_t k1 = (k0 + g.kslab < g.K) ? k0 + g.kslab : g.K;
+  const int nchunks = (int)((k1 - k0) / BK);            // even (kslab is a multiple of 2 BK, K % 32 == 0)
+  const int last = nchunks - 1;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fkq = lane >> 4;
+  const int mlast = g.M - 1, nlast = g.N - 1;
+  // A: two 16-row groups of this wave's 32 rows; four consecutive k per lane
+  const double* pA0 = g.A + (int64_t)min(tm * BM + wave * 32 + frow, mlast) * g.lda + k0 + 4 * fkq;
+  const double* pA1 = g.A + (int64_t)min(tm * BM + wave * 32 + 16 + frow, mlast) * g.lda + k0 + 4 * fkq;
+  // B staging: 128 rows x 16 doubles per chunk = 8 doubles per thread: rows srow and srow + 64, k offset 4 sseg .. + 3
+  const int srow = tid >> 2, sseg = tid & 3;
+  const double* pB0 = g.B + (int64_t)min(tn * BN + srow, nlast) * g.ldb + k0 + 4 * sseg;
+  const double* pB1 = g.B + (int64_t)min(tn * BN + srow + 64, nlast) * g.ldb + k0 + 4 * sseg;
+  const double* pS = SCALED ? g.kscale + k0 + 4 * sseg : nullptr;
+
+  // register sets: X / Y alternate between chunks (A operands + B staging)
+  double2 xa00, xa01, xa10, xa11, xb00, xb01, xb10, xb11;
+  double2 ya00, ya01, ya10, ya11, yb00, yb01, yb10, yb11;
+#define ISDF_LOADD(C, A00, A01, A10, A11, B00, B01, B10, B11)                                 \
+  {                                                                                           \
+    const int off = (C) * BK;                                                                 \
+    A00 = *reinterpret_cast<const double2*>(pA0 + off);                                       \
+    A01 = *reinterpret_cast<const double2*>(pA0 + off + 2);                                   \
+    A10 = *reinterpret_cast<const double2*>(pA1 + off);                                       \
+    A11 = *reinterpret_cast<const double2*>(pA1 + off + 2);                                   \
+    B00 = *reinterpret_cast<const double2*>(pB0 + off);                                       \
+    B01 = *reinterpret_cast<const double2*>(pB0 + off + 2);                                   \
+    B10 = *reinterpret_cast<const double2*>(pB1 + off);                                       \
+    B11 = *reinterpret_cast<const double2*>(pB1 + off + 2);                                   \
+    if (SCALED) {                                                                             \
+      const double2 s0 = *reinterpret_cast<const double2*>(pS + off);                         \
+      const double2 s1 = *reinterpret_cast<const double2*>(pS + off + 2);                     \
+      B00.x *= s0.x; B00.y *= s0.y; B01.x *= s1.x; B01.y *= s1.y;                             \
+      B10.x *= s0.x; B10.y *= s0.y; B11.x *= s1.x; B11.y *= s1.y;                             \
+    }                                                                                         \
+  }
+#define ISDF_STORED(BUF, B00, B01, B10, B11)                                                  \
+  {                                                                                           \
+    double* q0 = &sB[BUF][srow * LDT + 4 * sseg];                                             \
+    double* q1 = &sB[BUF][(srow + 64) * LDT + 4 * sseg];                                      \
+    q0[0] = B00.x; q0[1] = B00.y; q0[2] = B01.x; q0[3] = B01.y;                               \
+    q1[0] = B10.x; q1[1] = B10.y; q1[2] = B11.x; q1[3] = B11.y;                               \
+  }
+
+  d4 acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  // one k-step: B fragments of the eight column groups at k = 4 kq + J, then 2 x 8 MFMAs
+#define ISDF_STEPD(BUF, J, AV0, AV1)                                                          \
+  {                                                                                           \
+    const double* pb = &sB[BUF][frow * LDT + 4 * fkq + (J)];                                  \
+    double bf[8];                                                                             \
+    _Pragma("unroll") for (int jn = 0; jn < 8; ++jn) bf[jn] = pb[jn * 16 * LDT];              \
+    _Pragma("unroll") for (int jn = 0; jn < 8; ++jn) {                                        \
+      acc[0][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(AV0, bf[jn], acc[0][jn], 0, 0, 0);    \
+      acc[1][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(AV1, bf[jn], acc[1][jn], 0, 0, 0);    \
+    }                                                                                         \
+  }
+#define ISDF_COMPUTED(BUF, A00, A01, A10, A11)                                                \
+  {                                                                                           \
+    ISDF_STEPD(BUF, 0, A00.x, A10.x)                                                          \
+    ISDF_STEPD(BUF, 1, A00.y, A10.y)                                                          \
+    ISDF_STEPD(BUF, 2, A01.x, A11.x)                                                          \
+    ISDF_STEPD(BUF, 3, A01.y, A11.y)                                                          \
+  }
+
+  // prologue: chunk 0 in set X (its B part published in buffer 0), chunk 1 in flight in set Y
+  ISDF_LOADD(0, xa00, xa01, xa10, xa11, xb00, xb01, xb10, xb11)
+  ISDF_LOADD(min(1, last), ya00, ya01, ya10, ya11, yb00, yb01, yb10, yb11)
+  ISDF_STORED(0, xb00, xb01, xb10, xb11)
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    // chunk c: A operands in X, B in buffer 0; chunk c+1 sits in Y; X is refilled with chunk c+2 after its use
+    ISDF_COMPUTED(0, xa00, xa01, xa10, xa11)
+    ISDF_STORED(1, yb00, yb01, yb10, yb11)
+    ISDF_LOADD(min(c + 2, last), xa00, xa01, xa10, xa11, xb00, xb01, xb10, xb11)
+    __syncthreads();
+    ISDF_COMPUTED(1, ya00, ya01, ya10, ya11)
+    ISDF_STORED(0, xb00, xb01, xb10, xb11)
+    ISDF_LOADD(min(c + 3, last), ya00, ya01, ya10, ya11, yb00, yb01, yb10, yb11)
+    __syncthreads();
+  }
+
+  double* out = g.P + (int64_t)slab * g.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tm * BM + wave * 32 + i * 16 + (lane >> 4) + 4 * r;
+      if (row >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int col = tn * BN + j * 16 + (lane & 15);
+        if (col >= g.N) continue;
+        double* q = out + (int64_t)row * g.ldp + col;
+        const double v = acc[i][j][r];
+        if (g.direct) *q = (g.beta == 0.0) ? g.alpha * v : g.alpha * v + g.beta * (*q);
+        else *q = v;
+      }
+    }
+  }
+}
+
 __global__ void reduce_slabs_kernel(const double* __restrict__ P, int nslab, int64_t slab_stride,
                                     int M, int N, double alpha, double beta, double* __restrict__ C,
                                     int64_t ldc) {
@@ -345,13 +474,17 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
   GemmArgs g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.kscale = kscale;
   g.M = M; g.N = N; g.K = K;
-  // variant: -1 auto (default), 0 force the 128x128 kernel, 1 force the 256x128 kernel where legal
+  // variant: -1 auto (default), 0 force the 128x128 kernel, 1 force the 256x128 kernel where legal, 3 the 128x128 kernel with
+  // A direct to registers (variant D) where legal
   static const int variant = getenv("ISDF_GEMM_VARIANT") ? atoi(getenv("ISDF_GEMM_VARIANT")) : -1;
   const bool alignedB = (lda % 2 == 0) && (ldb % 2 == 0) && (K % 32 == 0) && (((uintptr_t)A) % 16 == 0) &&
                         (((uintptr_t)B) % 16 == 0) && (!kscale || ((uintptr_t)kscale) % 16 == 0);
-  // the 256-row tile wins (+8%, profiles/r01_gemm_variants.log) unless its row padding wastes > 10%
-  const bool fitsB = (double)(cdiv(M, BM2) * BM2) <= 1.10 * (double)M;
-  const bool useB = alignedB && M > BM && (variant == 1 || (variant == -1 && fitsB));
+  // auto: the 256x128 kernel (B) for the wide W products (N >= 4096: 64.2 vs 63.5 TF/s in the bench), variant D (A direct
+  // to registers, 128x128, two workgroups per CU) for everything else that is aligned (vj at 1664^2: 65 vs 54 TF/s; the
+  // configs[1] W shape: 63 vs 60), variant A only for unaligned operands (profiles/r01_gemm_variants.log)
+  const bool fitsB = (double)(cdiv(M, BM2) * BM2) <= 1.10 * (double)M;   // row padding of the 256-row tile wastes < 10 %
+  const bool useB = alignedB && M > BM && (variant == 1 || (variant == -1 && fitsB && N >= 4096));
+  const bool useD = alignedB && !useB && (variant == 3 || variant == -1);
   g.ntm = (int)cdiv(M, useB ? BM2 : BM); g.ntn = (int)cdiv(N, BN);
   const int64_t ntiles = (int64_t)g.ntm * g.ntn;
   // enough units to fill 2 workgroups per CU about 8 times over, slabs at least 2048 deep,
@@ -379,11 +512,14 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
                     (!kscale || ((uintptr_t)kscale) % 16 == 0);
   ARG_CHECK(h, g.nunits_pad < 2147483647LL);
   // one profiling label per kernel instantiation, named as rocprofv3 names them
-  const char* label = useB ? (kscale ? "gemm_nt_mfma_kernel_b<true>[flop]" : "gemm_nt_mfma_kernel_b<false>[flop]")
+  const char* label = useD ? (kscale ? "gemm_nt_mfma_kernel_d<true>[flop]" : "gemm_nt_mfma_kernel_d<false>[flop]") : useB ? (kscale ? "gemm_nt_mfma_kernel_b<true>[flop]" : "gemm_nt_mfma_kernel_b<false>[flop]")
                            : (fast ? "gemm_nt_mfma_kernel<true>[flop]" : "gemm_nt_mfma_kernel<false>[flop]");
   {
     ProfScope ps(h, label, 2.0 * M * N * (double)K);
-    if (useB) {
+    if (useD) {
+      if (kscale) hipLaunchKernelGGL(gemm_nt_mfma_kernel_d<true>, dim3((unsigned)g.nunits_pad), dim3(TPBD), 0, h->stream, g);
+      else hipLaunchKernelGGL(gemm_nt_mfma_kernel_d<false>, dim3((unsigned)g.nunits_pad), dim3(TPBD), 0, h->stream, g);
+    } else if (useB) {
       const size_t lds = sizeof(double) * 2 * (BM2 + BN) * LDT;
       static bool attr_set = false;
       if (!attr_set) {
