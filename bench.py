@@ -208,13 +208,19 @@ def main():
         try:
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_bench_cfg3_fetch_write.json')) as f:
                 pmc = json.load(f)
+            # algorithmic bytes of the launches that kernel handles: W batch r reads V (nb x G) and the rows r.. of Y' ((P - r) x G)
+            # once and writes nb x (P - r); the 256x128 kernel takes the batches with P - r >= 4096 (gemm_f64.hip)
+            Gn, Pn = int(np.prod(cell.mesh)), len(df.ip)
+            nbat = int(getattr(df, '_last_fft_batch', 0) or 512)
+            algs = [8.0 * ((min(nbat, Pn - r) + (Pn - r)) * Gn + min(nbat, Pn - r) * (Pn - r))
+                    for r in range(0, Pn, nbat) if Pn - r >= 4096]
             for k, v in pmc.items():
                 fetch = v.get('FETCH_SIZE_per_launch', v.get('FETCH_SIZE_KB_per_launch'))     # counter unit: KB
                 write = v.get('WRITE_SIZE_per_launch', v.get('WRITE_SIZE_KB_per_launch'))
-                if k.startswith('gemm_nt_mfma_kernel') and fetch is not None and write is not None and v['launches'] > 4 \
-                        and args.workload == 'diamond-444-dzvp-120' and world == 1:
+                if k.startswith('gemm_nt_mfma_kernel_b') and fetch is not None and write is not None and v['launches'] > 4 \
+                        and args.workload == 'diamond-444-dzvp-120' and world == 1 and algs:
                     traffic = dict(bytes_per_launch=round((2 * fetch + write) * 1024),
-                                   algorithmic_bytes_per_launch=round(8.0 * (512 + 8320 + 256) * 1728000),
+                                   algorithmic_bytes_per_launch=round(sum(algs) / len(algs)),
                                    source='profiles/r01_pmc_bench_cfg3_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in '
                                           'separate passes of this command with ISDF_TRSM=subst, tools/pmc_summarise.py; FETCH x2 per '
                                           'MI355X_MICROARCH.md; counts fabric requests incl. Infinity-Cache hits)')

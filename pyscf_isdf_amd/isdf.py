@@ -334,6 +334,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         mesh = np.asarray(self.mesh, dtype=np.int32)
         a = np.asarray(self.cell.lattice_vectors(), dtype=float)
         batch = self.fft_batch or _default_fft_batch(G, P, be.free_bytes())
+        self._last_fft_batch = batch
         be.coulomb_W(theta, mesh, a, 0, P, batch, W, upper_only=True)
         be.symmetrize_upper(W)
         if st['kind'] == 'blockjacobi':
