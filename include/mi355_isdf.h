@@ -317,6 +317,15 @@ int isdf_pp_projector_overlaps(isdf_handle h, const int32_t* atm, int natm, cons
                                const int32_t* proj_tab, const double* proj_rl, int nproj,
                                const int32_t mesh[3], const double a[9], double* d_out);
 
+/* Robust-fitting K (Dunlap's correction on top of the ISDF exchange).  With V_P = conv(Theta_P) kept
+ * on the device, per batch of points:  F (nb, G) = (phi_P D)(nb, N) . phi (N, G)  [isdf_gemm_nn],  F .*= V rows
+ * [isdf_hadamard_rows],  (F phi^T)(nb, N) [isdf_gemm_nt]  ->  K1 = w phi_P^T (F phi^T);  K = K1 + K1^T - K_isdf.
+ *   isdf_gemm_nn:       C (M, ldc) = alpha A (M, K; lda) B (K, N; ldb) + beta C, row-major, N contiguous (rocBLAS dgemm)
+ *   isdf_hadamard_rows: X (rows, ldx) .*= Y (rows, ldy) on `cols` columns */
+int isdf_gemm_nn(isdf_handle h, int M, int64_t N, int K, double alpha, const double* d_A, int64_t lda, const double* d_B,
+                 int64_t ldb, double beta, double* d_C, int64_t ldc);
+int isdf_hadamard_rows(isdf_handle h, double* d_X, int64_t ldx, const double* d_Y, int64_t ldy, int rows, int64_t cols);
+
 /* Dense helper behind S5/S6 (exposed for tests and micro-benchmarks):
  *   C (M, ldc) = alpha * A (M, lda) * (B (N, ldb) .* kscale[None, :])^T + beta * C,
  * K contiguous in both operands (the W = V Theta^T / vj = ao (v.ao)^T shape); d_kscale may be NULL.

@@ -261,3 +261,21 @@ def isdf_eri_s4(aoP, W):
     i, j = np.tril_indices(nao)
     X = aoP[:, i] * aoP[:, j]            # (P, npair)
     return X.T.dot(W).dot(X)
+
+
+def get_k_robust(aoT, ip, theta, dm, a, mesh):
+    """K with Dunlap's robust correction: for rho_mn ~ sum_P Theta_P rho_mn(r_P),
+    (mu lam|sig nu) ~ (fit|exact) + (exact|fit) - (fit|fit):  K = K1 + K2 - K_isdf,
+    K1_mn = sum_P phi_m(P) sum_g w V_P(g) [phi_P D phi(g)] phi_n(g), V_P = conv(Theta_P), K2 = K1(D^T)^T."""
+    dm = np.asarray(dm, dtype=float)
+    G = aoT.shape[1]
+    w = abs(np.linalg.det(a)) / G
+    aoP = np.ascontiguousarray(aoT[:, ip].T)
+    V = coulomb_V(theta, a, mesh)
+    W = w * V.dot(theta.T)
+
+    def k1(D):
+        F = aoP.dot(D).dot(aoT) * V                       # (P, G)
+        return aoP.T.dot(w * F.dot(aoT.T))
+    return k1(dm) + k1(dm.T).T - get_k(aoP, W, dm)
+

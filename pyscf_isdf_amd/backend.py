@@ -281,6 +281,17 @@ class HipBackend:
         self.handle.call('isdf_get_k_exact', self._p(ao), ao.shape[0], int(ngrids), ao.stride(0), self._p(C), C.shape[1],
                          _np_ptr(mesh), _np_ptr(a), int(i0), int(ni), int(max_rows), self._p(vk))
 
+    def gemm_nn(self, A, B, C, alpha=1.0, beta=0.0):
+        """C (M, N) = alpha A (M, K) B (K, N) + beta C, row-major."""
+        self._stream()
+        self.handle.call('isdf_gemm_nn', A.shape[0], B.shape[1], A.shape[1], float(alpha), self._p(A), A.stride(0), self._p(B),
+                         B.stride(0), float(beta), self._p(C), C.stride(0))
+
+    def hadamard_rows(self, X, Y):
+        """X .*= Y (same shape, rows may be strided)."""
+        self._stream()
+        self.handle.call('isdf_hadamard_rows', self._p(X), X.stride(0), self._p(Y), Y.stride(0), X.shape[0], X.shape[1])
+
     def gemm_nt(self, A, B, C, alpha=1.0, beta=0.0, kscale=None):
         """C = alpha * A (B .* kscale)^T + beta * C; A (M,K), B (N,K) row-major, K contiguous."""
         self._stream()

@@ -173,3 +173,32 @@ extern "C" int isdf_get_k_exact(isdf_handle h, const double* d_ao, int nao, int6
   }
   return ISDF_OK;
 }
+
+// ---- robust K: building blocks ----------------------------------------------------------------------
+namespace {
+__global__ void hadamard_rows_kernel(double* __restrict__ X, int64_t ldx, const double* __restrict__ Y, int64_t ldy,
+                                     int64_t cols) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (c < cols) X[r * ldx + c] *= Y[r * ldy + c];
+}
+}  // namespace
+
+extern "C" int isdf_hadamard_rows(isdf_handle h, double* d_X, int64_t ldx, const double* d_Y, int64_t ldy, int rows,
+                                  int64_t cols) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_X && d_Y && rows > 0 && rows <= 65535 && cols > 0 && ldx >= cols && ldy >= cols);
+  ProfScope ps(h, "hadamard_rows_kernel[byte]", 24.0 * (double)rows * (double)cols);
+  hipLaunchKernelGGL(hadamard_rows_kernel, dim3((unsigned)cdiv(cols, 256), (unsigned)rows), dim3(256), 0, h->stream, d_X, ldx,
+                     d_Y, ldy, cols);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_gemm_nn(isdf_handle h, int M, int64_t N, int K, double alpha, const double* d_A, int64_t lda,
+                            const double* d_B, int64_t ldb, double beta, double* d_C, int64_t ldc) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_A && d_B && d_C && M > 0 && N > 0 && K > 0 && lda >= K && ldb >= N && ldc >= N);
+  return gemm_rm(h, 'N', 'N', M, N, K, alpha, d_A, lda, d_B, ldb, beta, d_C, ldc);
+}
+

@@ -66,6 +66,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         self.block_shift = 0.0           # relative diagonal shift of the per-atom blocks in the S3c route (raised per
                                          # block when a block is not positive definite: D is only a preconditioner)
         self.block_shift_used = 0.0
+        self.robust_k = False            # True: K with Dunlap's robust correction (error quadratic in the fit error): needs
+                                         # Theta itself and keeps V = conv(Theta) on the device; K costs 4 N G P flop
         self.explicit_theta = False      # True: form Theta itself (second O(P^2 G) solve); same W in exact arithmetic
         self.fft_batch = None             # rows per FFT batch (None: sized from free memory)
         self._backend = backend
@@ -74,6 +76,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         self._built = False
         self._W_omega = {}               # range-separated W per omega (get_jk(omega=...)), valid until the next build
         self._fit_state = None
+        self._V = None                   # robust_k: V = conv(Theta) (P, G), in the fit buffer
         self._bufs = {}
         self._ovlp = None
         self.timings = {}
@@ -178,6 +181,11 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
     def build(self):
         self.check_sanity()
         self._W_omega = {}
+        self._V = None
+        if self.robust_k:
+            if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band) or self.comm.size > 1 or self.force_sharded:
+                raise NotImplementedError('robust_k is implemented for the Gamma-point single-GPU build')
+            self.explicit_theta = True       # the correction needs V = conv(Theta), i.e. Theta itself
         if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
             return self._build_kpts()
         if self.comm.size > 1 or self.force_sharded:
@@ -284,6 +292,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
                         break
                     warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e); '
                                   'rebuilding W with the Cholesky route' % (self.bj_check, self.bj_check_tol))
+            self._keep_V_for_robust_k(t0)
             del theta
             self._built = True
             return self
@@ -298,8 +307,22 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         self.fit_route_used = 'selection-cholesky'
         del theta
         t0 = self._tick('S4S5_coulomb_W', t0)
+        self._keep_V_for_robust_k(t0)
         self._built = True
         return self
+
+    def _keep_V_for_robust_k(self, t0):
+        """robust_k: the fit buffer (Theta) becomes V = conv(Theta), in place (one more pass of batched FFTs)."""
+        if not self.robust_k:
+            return
+        be = self.backend
+        theta = self._fit_state['theta']
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        a = np.asarray(self.cell.lattice_vectors(), dtype=float)
+        be.coulomb_rows(theta, mesh, a, self._last_fft_batch)
+        self._V = theta
+        self._fit_state = None                   # Theta is gone: no range-separated rebuild from this fit
+        self._tick('S5_conv_for_robust_k', t0)
 
     def range_coulomb(self, omega):
         """FFTDF.range_coulomb (pyscf/pbc/df/fft.py:337-359): a context manager whose object answers get_jk / get_ao_eri-less
@@ -323,6 +346,40 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
     def to_gpu(self):
         """FFTDF.to_gpu (pyscf/pbc/df/fft.py): this object already runs on the GPU."""
         return self
+
+    def _robust_k_correction(self, d_dm, d_vk):
+        """K <- K1 + K2 - K_isdf (Dunlap's robust form of the fitted exchange: error quadratic in the fit error),
+        K1_mn = sum_P phi_m(P) sum_g w V_P(g) [phi_P D phi(g)] phi_n(g),  V_P = conv(Theta_P) (kept in the fit buffer by
+        build() when robust_k is set),  K2 = K1(D^T)^T.  Two N x G x P products per density matrix, batched over P."""
+        be = self.backend
+        V = self._V
+        if V is None:
+            raise RuntimeError('robust_k needs a build with robust_k=True (Theta explicit, V = conv(Theta) kept)')
+        P, G = V.shape
+        nao = self.cell.nao_nr()
+        w = self.cell.vol / G
+        nb = max(1, min(P, int((6 << 30) // (8 * G))))
+        aoPT = self.aoP.T.contiguous()                                      # (N, P)
+        for s in range(d_dm.shape[0]):
+            D = d_dm[s]
+            passes = [D] if bool(torch.allclose(D, D.T, rtol=0, atol=1e-13 * float(D.abs().max()) + 1e-300)) else [D, D.T.contiguous()]
+            ks = []
+            for Dp in passes:
+                X = be.empty((P, nao))
+                be.gemm_nn(self.aoP, Dp, X)                                 # phi_P D
+                K1 = be.zeros((nao, nao))
+                for r0 in range(0, P, nb):
+                    r1 = min(P, r0 + nb)
+                    F = be.empty((r1 - r0, G))
+                    be.gemm_nn(X[r0:r1], self.ao, F)                        # [phi_P D phi](P, g)
+                    be.hadamard_rows(F, V[r0:r1])
+                    Kt = be.empty((r1 - r0, nao))
+                    be.gemm_nt(F, self.ao, Kt, alpha=w)                     # sum_g w (.) phi_n(g)
+                    be.gemm_nn(aoPT[:, r0:r1], Kt, K1, beta=1.0)            # sum_P phi_m(P) (.)
+                    del F, Kt
+                ks.append(K1)
+            k2 = ks[0].T if len(ks) == 1 else ks[1].T
+            d_vk[s] = ks[0] + k2 - d_vk[s]
 
     def _finish_W(self, W):
         """S4 + S5 for the fit held in self._fit_state (rows Y / Y' / Theta in the fit buffer + the factors that go with
@@ -352,6 +409,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         if ex not in (None, 'None'):
             raise NotImplementedError('range-separated J/K: only exxdiv=None is implemented')
         be = self.backend
+        if self.robust_k:
+            raise NotImplementedError('range-separated J/K with robust_k is not implemented')
         if not self._built:
             self.build()
         key = round(float(omega), 10)
@@ -424,6 +483,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
             d_vk = be.empty((nset, nao, nao))
             P = self.W.shape[0]
             be.get_k(self.aoP, self.W, 0, P, d_dm, d_vk)
+            if self.robust_k:
+                self._robust_k_correction(d_dm, d_vk)
             if exxdiv == 'ewald':
                 self._add_ewald_exxdiv(d_dm, d_vk)
             t0 = self._tick('S7_get_k', t0)

@@ -68,6 +68,8 @@ SIGNATURES = {
     'isdf_vj_k': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'isdf_pp_local_potential': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'isdf_pp_projector_overlaps': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    'isdf_gemm_nn': (c_int, [c_vp, c_int, c_i64, c_int, c_dbl, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp, c_i64]),
+    'isdf_hadamard_rows': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_i64]),
     'isdf_gemm_nt': (c_int, [c_vp, c_int, c_int, c_i64, c_dbl, c_vp, c_i64, c_vp, c_i64, c_vp, c_dbl, c_vp, c_i64]),
     'isdf_get_k_exact': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'isdf_get_k': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]),

@@ -202,6 +202,12 @@ class OracleBackend:
     def symmetrize_mean(self, W, antisymmetric=False):
         W.copy_((W - W.T) / 2 if antisymmetric else (W + W.T) / 2)
 
+    def gemm_nn(self, A, B, C, alpha=1.0, beta=0.0):
+        C.copy_(torch.from_numpy(alpha * A.numpy().dot(B.numpy()) + beta * C.numpy()))
+
+    def hadamard_rows(self, X, Y):
+        X.mul_(Y)
+
     def gemm_nt(self, A, B, C, alpha=1.0, beta=0.0, kscale=None):
         b = B.numpy() if kscale is None else B.numpy() * kscale.numpy()
         C.copy_(torch.from_numpy(alpha * A.numpy().dot(b.T) + beta * C.numpy()))
