@@ -171,3 +171,39 @@ def test_range_separated_get_jk_host_logic_with_checker_backend():
         assert df.to_gpu() is df
         df.build()
         assert df._W_omega == {}
+
+
+def test_robust_k_host_logic_with_checker_backend():
+    """robust_k through the host driver (no GPU): forces Theta itself, keeps V = conv(Theta) in the fit buffer, assembles
+    K1 + K2 - K_isdf in row batches; equals the oracle's restatement and beats the plain ISDF K against the exact one."""
+    import cells
+    from oracle_backend import OracleBackend
+    from oracle import fftdf
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_diamond_prim('gth-szv', (12, 12, 12))
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(1)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao); occ[:4] = 2
+    dm = (c * occ).dot(c.T)
+    rcut = gto.estimate_rcut_per_shell(cell)
+    ao = oao.eval_ao(cell._atm, cell._bas, cell._env, cell.get_uniform_grids(), gto.get_lattice_Ls(cell, rcut=rcut.max()), rcut, rule='point')
+    aoT = np.ascontiguousarray(ao.T)
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    k_exact = fftdf.get_k(ao, dm, a, mesh)
+    plain = ISDF(cell, c_isdf=3, select='local', backend=OracleBackend())
+    k_plain = plain.get_jk(dm, with_j=False)[1]
+    df = ISDF(cell, c_isdf=3, select='local', backend=OracleBackend())
+    df.robust_k = True
+    k_rob = df.get_jk(dm, with_j=False)[1]
+    assert df.explicit_theta and df._V is not None and df._fit_state is None
+    th = oisdf.fit_theta_global_chol(aoT, df.ip, reg_rel=df.reg_used)
+    assert abs(k_rob - oisdf.get_k_robust(aoT, df.ip, th, dm, a, mesh)).max() < 1e-12
+    assert abs(k_rob - k_exact).max() < 0.5 * abs(k_plain - k_exact).max()
+    with pytest.raises(NotImplementedError):
+        df.get_jk(dm, omega=0.2)
+    sh = ISDF(cell, c_isdf=3, select='local', backend=OracleBackend())
+    sh.robust_k = True
+    sh.force_sharded = True
+    with pytest.raises(NotImplementedError):
+        sh.build()

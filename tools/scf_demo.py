@@ -12,7 +12,7 @@ from pyscf_isdf_amd.isdf import ISDF
 
 name = sys.argv[1] if len(sys.argv) > 1 else 'diamond-222-dzvp-80'
 cs = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [10]
-robust = '--robust' in sys.argv
+modes = [False, True] if '--both' in sys.argv else [('--robust' in sys.argv)]
 cell = workloads.make_cell(name)
 nao, nocc = cell.nao_nr(), cell.nelectron // 2
 mesh = np.asarray(cell.mesh)
@@ -65,21 +65,24 @@ def rhf(hcore, S, get_jk, tag, max_cycle=40, conv=1e-9):
 
 ref = None
 for c_isdf in cs:
-    df = ISDF(cell, c_isdf=c_isdf)
-    df.robust_k = robust
-    t0 = time.perf_counter()
-    df.build()
-    print('c_isdf %d: build %.2f s, P = %d, route %s' % (c_isdf, time.perf_counter() - t0, len(df.ip), df.fit_route_used), flush=True)
-    T, S = kinetic_and_overlap(df)
-    hcore = T + df.get_pp()
-    if ref is None:
-        def jk_exact(dm, cocc):
-            vj = df.get_jk(dm, with_k=False)[0]
-            occ = np.full(cocc.shape[1], 2.0)
-            return vj, df.get_k_exact(mo_coeff=cocc, mo_occ=occ)
-        ref = rhf(hcore, S, jk_exact, 'exact K')
-        print('exact-K RHF: E_el = %.10f Eh, gap %.4f Eh' % (ref[0], ref[2][nocc] - ref[2][nocc - 1]), flush=True)
-    e_isdf, dm, eps = rhf(hcore, S, lambda dm, cocc: df.get_jk(dm), 'ISDF c=%d%s' % (c_isdf, ' robust' if robust else ''))
-    print(('robust ' if robust else '') + 'ISDF c=%d RHF: E_el = %.10f Eh   E(ISDF) - E(exact K) = %.3e Eh = %.3e Eh/atom   gap %.4f (exact %.4f)' %
-          (c_isdf, e_isdf, e_isdf - ref[0], (e_isdf - ref[0]) / cell.natm, eps[nocc] - eps[nocc - 1], ref[2][nocc] - ref[2][nocc - 1]), flush=True)
-    df.reset()
+    for robust in modes:
+        df = ISDF(cell, c_isdf=c_isdf)
+        df.robust_k = robust
+        t0 = time.perf_counter()
+        df.build()
+        print('c_isdf %d%s: build %.2f s, P = %d, route %s' % (c_isdf, ' robust' if robust else '', time.perf_counter() - t0, len(df.ip),
+                                                             df.fit_route_used), flush=True)
+        if ref is None:
+            T, S = kinetic_and_overlap(df)
+            hcore = T + df.get_pp()
+
+            def jk_exact(dm, cocc, df=df):
+                vj = df.get_jk(dm, with_k=False)[0]
+                return vj, df.get_k_exact(mo_coeff=cocc, mo_occ=np.full(cocc.shape[1], 2.0))
+            ref = rhf(hcore, S, jk_exact, 'exact K')
+            print('exact-K RHF: E_el = %.10f Eh, gap %.4f Eh' % (ref[0], ref[2][nocc] - ref[2][nocc - 1]), flush=True)
+        tag = 'ISDF c=%d%s' % (c_isdf, ' robust' if robust else '')
+        e_isdf, dm, eps = rhf(hcore, S, lambda dm, cocc: df.get_jk(dm), tag)
+        print('%s RHF: E_el = %.10f Eh   E(ISDF) - E(exact K) = %.3e Eh = %.3e Eh/atom   gap %.4f (exact %.4f)' %
+              (tag, e_isdf, e_isdf - ref[0], (e_isdf - ref[0]) / cell.natm, eps[nocc] - eps[nocc - 1], ref[2][nocc] - ref[2][nocc - 1]), flush=True)
+        df.reset()
