@@ -183,8 +183,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         self._W_omega = {}
         self._V = None
         if self.robust_k:
-            if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band) or self.comm.size > 1 or self.force_sharded:
-                raise NotImplementedError('robust_k is implemented for the Gamma-point single-GPU build')
+            if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
+                raise NotImplementedError('robust_k is implemented at the Gamma point')
             self.explicit_theta = True       # the correction needs V = conv(Theta), i.e. Theta itself
         if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
             return self._build_kpts()
@@ -351,14 +351,15 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         """K <- K1 + K2 - K_isdf (Dunlap's robust form of the fitted exchange: error quadratic in the fit error),
         K1_mn = sum_P phi_m(P) sum_g w V_P(g) [phi_P D phi(g)] phi_n(g),  V_P = conv(Theta_P) (kept in the fit buffer by
         build() when robust_k is set),  K2 = K1(D^T)^T.  Two N x G x P products per density matrix, batched over P."""
-        be = self.backend
+        be, comm = self.backend, self.comm
         V = self._V
         if V is None:
             raise RuntimeError('robust_k needs a build with robust_k=True (Theta explicit, V = conv(Theta) kept)')
-        P, G = V.shape
+        P, ng = V.shape                                                     # ng = this rank's grid columns (all of them on one GPU)
         nao = self.cell.nao_nr()
-        w = self.cell.vol / G
-        nb = max(1, min(P, int((6 << 30) // (8 * G))))
+        w = self.cell.vol / int(np.prod(self.mesh))
+        sharded = comm.size > 1 or self.force_sharded
+        nb = max(1, min(P, int((6 << 30) // (8 * ng))))
         aoPT = self.aoP.T.contiguous()                                      # (N, P)
         for s in range(d_dm.shape[0]):
             D = d_dm[s]
@@ -370,13 +371,15 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
                 K1 = be.zeros((nao, nao))
                 for r0 in range(0, P, nb):
                     r1 = min(P, r0 + nb)
-                    F = be.empty((r1 - r0, G))
-                    be.gemm_nn(X[r0:r1], self.ao, F)                        # [phi_P D phi](P, g)
+                    F = be.empty((r1 - r0, ng))
+                    be.gemm_nn(X[r0:r1], self.ao, F)                        # [phi_P D phi](P, g) on the local columns
                     be.hadamard_rows(F, V[r0:r1])
                     Kt = be.empty((r1 - r0, nao))
                     be.gemm_nt(F, self.ao, Kt, alpha=w)                     # sum_g w (.) phi_n(g)
                     be.gemm_nn(aoPT[:, r0:r1], Kt, K1, beta=1.0)            # sum_P phi_m(P) (.)
                     del F, Kt
+                if sharded:
+                    comm.all_reduce_sum(K1)                                 # the grid sum was over this rank's slice
                 ks.append(K1)
             k2 = ks[0].T if len(ks) == 1 else ks[1].T
             d_vk[s] = ks[0] + k2 - d_vk[s]

@@ -159,6 +159,7 @@ class ShardedMixin:
                     break
                 warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e); '
                               'rebuilding W with the Cholesky route' % (self.bj_check, self.bj_check_tol))
+        self._keep_V_for_robust_k_sharded(t0)
         del theta, aoP_T
         self._built = True
         return self
@@ -215,6 +216,46 @@ class ShardedMixin:
         elif st['kind'] == 'cholesky':
             be.W_from_factor(st['chol'], 0, W)
 
+    def _keep_V_for_robust_k_sharded(self, t0):
+        """robust_k on the grid-sharded build: the fit rows on this rank's slice become V = conv(Theta)[:, S_r], in place -
+        the same two all-to-alls around the row convolution as S4, without the W product."""
+        if not self.robust_k:
+            return
+        cell, be, comm = self.cell, self.backend, self.comm
+        theta = self._fit_state['theta']
+        P, ng = theta.shape
+        R, rk = comm.size, comm.rank
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        slices = [comm.split_range(G, r) for r in range(R)]
+        rows = [comm.split_range(P, r) for r in range(R)]
+        nb = self.fft_batch or _default_fft_batch(G, max(1, P // R))
+        nsteps = max(-(-(hi - lo) // nb) for lo, hi in rows)
+        for t in range(nsteps):
+            bat = [(min(lo + t * nb, hi), min(lo + (t + 1) * nb, hi)) for lo, hi in rows]
+            nrow = [hi - lo for lo, hi in bat]
+            send = [theta[lo:hi] for lo, hi in bat]
+            recv = [be.empty((nrow[rk], s1 - s0)) for s0, s1 in slices]
+            comm.all_to_all(recv, send)
+            full = be.empty((nrow[rk], G))
+            for (s0, s1), piece in zip(slices, recv):
+                full[:, s0:s1] = piece
+            del recv
+            if nrow[rk]:
+                be.coulomb_rows(full, mesh, a, max(1, nrow[rk]))
+            send = [full[:, s0:s1].contiguous() for s0, s1 in slices]
+            recv = [be.empty((nrow[q], ng)) for q in range(R)]
+            comm.all_to_all(recv, send)
+            del full, send
+            for q in range(R):
+                if nrow[q]:
+                    theta[bat[q][0]:bat[q][1]] = recv[q]          # rows bat_q were sent in this step's first all-to-all
+            del recv
+        self._V = theta
+        self._fit_state = None
+        self._tick('S5_conv_for_robust_k', t0)
+
     def _get_jk_sharded(self, d_dm, out_shape, with_j, with_k, exxdiv=None):
         cell, be, comm = self.cell, self.backend, self.comm
         nao = cell.nao_nr()
@@ -245,6 +286,8 @@ class ShardedMixin:
             d_vk = be.empty((nset, nao, nao))
             be.get_k(self.aoP, self.W, r0, r1 - r0, d_dm, d_vk)
             comm.all_reduce_sum(d_vk)
+            if self.robust_k:
+                self._robust_k_correction(d_dm, d_vk)       # K1 over this rank's grid slice, all-reduced inside
             if exxdiv == 'ewald':
                 self._add_ewald_exxdiv(d_dm, d_vk)
             t0 = self._tick('S7_get_k', t0)

@@ -451,6 +451,11 @@ def test_robust_k_matches_oracle_and_reduces_the_error(be):
     assert abs(k_n - oisdf.get_k_robust(aoT, df.ip, th, dn, a, mesh)).max() < 1e-8 * abs(k_n).max()
     with pytest.raises(NotImplementedError):
         df.get_jk(dm, omega=0.3)
+    sh = ISDF(cell, c_isdf=4, select='local')                              # the grid-sharded layout on one rank
+    sh.robust_k = True
+    sh.force_sharded = True
+    sh.fft_batch = 37
+    assert abs(sh.get_jk(dm, with_j=False)[1] - k_rob).max() < 1e-9 * abs(k_rob).max()
 
 
 def test_exxdiv_ewald_adds_madelung_SDS():

@@ -202,8 +202,8 @@ def test_robust_k_host_logic_with_checker_backend():
     assert abs(k_rob - k_exact).max() < 0.5 * abs(k_plain - k_exact).max()
     with pytest.raises(NotImplementedError):
         df.get_jk(dm, omega=0.2)
-    sh = ISDF(cell, c_isdf=3, select='local', backend=OracleBackend())
+    sh = ISDF(cell, c_isdf=3, select='local', backend=OracleBackend())          # the grid-sharded layout, one rank
     sh.robust_k = True
     sh.force_sharded = True
-    with pytest.raises(NotImplementedError):
-        sh.build()
+    sh.fft_batch = 5
+    assert abs(sh.get_jk(dm, with_j=False)[1] - k_rob).max() < 1e-12
