@@ -84,7 +84,7 @@ class FitRouteMixin:
     def _fit_routes(self):
         if self.fit_route not in ('auto', 'blockjacobi', 'cholesky'):
             raise ValueError("fit_route must be 'auto', 'blockjacobi' or 'cholesky'")
-        if self.explicit_theta or self.fit_route == 'cholesky':
+        if self._want_theta or self.fit_route == 'cholesky':
             return ['cholesky']
         if self.fit_route == 'blockjacobi':
             return ['blockjacobi']

@@ -88,6 +88,11 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
 
     # ---- FFTDF-compatible plumbing ---------------------------------------------------------------
     @property
+    def _want_theta(self):
+        """Theta itself is formed when asked for, and always for robust_k (its correction needs V = conv(Theta))."""
+        return bool(self.explicit_theta or self.robust_k)
+
+    @property
     def mesh(self):
         return self.grids.mesh
 
@@ -185,7 +190,6 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         if self.robust_k:
             if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
                 raise NotImplementedError('robust_k is implemented at the Gamma point')
-            self.explicit_theta = True       # the correction needs V = conv(Theta), i.e. Theta itself
         if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
             return self._build_kpts()
         if self.comm.size > 1 or self.force_sharded:
@@ -220,7 +224,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
             t0 = self._tick('S2_select_ip', t0)
             theta = theta[:P]
             piv = piv[0, :P].contiguous()
-            if self.explicit_theta:
+            if self._want_theta:
                 be.fit_from_chol(theta, P, G, piv)
                 factor = None
             else:
@@ -273,12 +277,12 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
                     chol = self._buffer('factor', (P, P))
                     self.reg_used = be.fit_prepare(self.ao, d_ip, self.reg_rel, self.aoP, chol)
                     # forward solve only (Y = Lr^-1 B); the backward solve is applied to the (P, P) matrix below
-                    be.fit_apply(chol, self.aoP, self.ao, G, theta, forward_only=not self.explicit_theta)
+                    be.fit_apply(chol, self.aoP, self.ao, G, theta, forward_only=not self._want_theta)
                 t0 = self._tick('S3_fit', t0)
                 if route == 'blockjacobi':
                     self._fit_state = dict(kind='blockjacobi', theta=theta, Afac=Afac, Dblk=Dblk, ip_off=ip_off)
                 else:
-                    self._fit_state = dict(kind='explicit' if self.explicit_theta else 'cholesky', theta=theta, chol=chol)
+                    self._fit_state = dict(kind='explicit' if self._want_theta else 'cholesky', theta=theta, chol=chol)
                 self._finish_W(self.W)
                 t0 = self._tick('S4S5_coulomb_W', t0)
                 self.fit_route_used = route

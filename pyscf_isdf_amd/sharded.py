@@ -140,10 +140,10 @@ class ShardedMixin:
                     be.gather_aoP(aoP_T, ar, self.aoP)
                 comm.broadcast(chol)
                 self.reg_used = comm.agree_max(reg or 0.0)
-                be.fit_apply(chol, self.aoP, self.ao, ng, theta, forward_only=not self.explicit_theta)
+                be.fit_apply(chol, self.aoP, self.ao, ng, theta, forward_only=not self._want_theta)
             t0 = self._tick('S3_fit', t0)
 
-            self._fit_state = dict(kind=route if route == 'blockjacobi' else ('explicit' if self.explicit_theta else 'cholesky'),
+            self._fit_state = dict(kind=route if route == 'blockjacobi' else ('explicit' if self._want_theta else 'cholesky'),
                                    theta=theta, sharded=True,
                                    Afac=Afac if route == 'blockjacobi' else None, Dblk=Dblk if route == 'blockjacobi' else None,
                                    ip_off=ip_off, chol=None if route == 'blockjacobi' else chol)

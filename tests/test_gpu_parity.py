@@ -437,7 +437,7 @@ def test_robust_k_matches_oracle_and_reduces_the_error(be):
     df = ISDF(cell, c_isdf=4, select='local')
     df.robust_k = True
     k_rob = df.get_jk(dm, with_j=False)[1]
-    assert np.array_equal(plain.ip, df.ip) and df.explicit_theta and df._V is not None
+    assert np.array_equal(plain.ip, df.ip) and df._want_theta and df._V is not None
     aoT = df.backend.to_host(df.ao)
     a, mesh = cell.lattice_vectors(), cell.mesh
     th = oisdf.fit_theta_global_chol(aoT, df.ip, reg_rel=df.reg_used)

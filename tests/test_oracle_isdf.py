@@ -196,7 +196,7 @@ def test_robust_k_host_logic_with_checker_backend():
     df = ISDF(cell, c_isdf=3, select='local', backend=OracleBackend())
     df.robust_k = True
     k_rob = df.get_jk(dm, with_j=False)[1]
-    assert df.explicit_theta and df._V is not None and df._fit_state is None
+    assert df._want_theta and not df.explicit_theta and df._V is not None and df._fit_state is None
     th = oisdf.fit_theta_global_chol(aoT, df.ip, reg_rel=df.reg_used)
     assert abs(k_rob - oisdf.get_k_robust(aoT, df.ip, th, dm, a, mesh)).max() < 1e-12
     assert abs(k_rob - k_exact).max() < 0.5 * abs(k_plain - k_exact).max()

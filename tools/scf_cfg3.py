@@ -77,7 +77,6 @@ t1 = time.perf_counter()
 vk_ex = df.get_k_exact(mo_coeff=cocc, mo_occ=np.full(nocc, 2.0))
 print('exact K at the converged orbitals: %.1f s' % (time.perf_counter() - t1), flush=True)
 df.robust_k = False
-df.explicit_theta = False
 df.build()
 vk_plain = df.get_jk(dm, with_j=False)[1]
 ek = lambda k: np.einsum('ij,ji', k, dm) / 4
