@@ -370,18 +370,33 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
             passes = [D] if bool(torch.allclose(D, D.T, rtol=0, atol=1e-13 * float(D.abs().max()) + 1e-300)) else [D, D.T.contiguous()]
             ks = []
             for Dp in passes:
-                X = be.empty((P, nao))
-                be.gemm_nn(self.aoP, Dp, X)                                 # phi_P D
+                # [phi_P D phi(g)] = sum_i s_i psi_i(P) psi_i(g) through the eigenvectors of a symmetric D when its rank is low
+                # (an SCF density: nocc << N) - the first of the two big products then costs 2 P r G instead of 2 P N G flop
+                left, right = None, self.ao
+                if len(passes) == 1:
+                    ev, U = torch.linalg.eigh(Dp)
+                    keep = ev.abs() > 1e-12 * float(ev.abs().max())
+                    r = int(keep.sum())
+                    if 0 < r <= nao // 2:
+                        Ur = U[:, keep].contiguous()                         # (N, r)
+                        left = be.empty((P, r))
+                        be.gemm_nn(self.aoP, (Ur * ev[keep]).contiguous(), left)     # phi_P U s
+                        right = be.empty((r, ng))
+                        be.gemm_nn(Ur.T.contiguous(), self.ao, right)        # psi = U^T phi on the local columns
+                if left is None:
+                    left = be.empty((P, nao))
+                    be.gemm_nn(self.aoP, Dp, left)                          # phi_P D
                 K1 = be.zeros((nao, nao))
                 for r0 in range(0, P, nb):
                     r1 = min(P, r0 + nb)
                     F = be.empty((r1 - r0, ng))
-                    be.gemm_nn(X[r0:r1], self.ao, F)                        # [phi_P D phi](P, g) on the local columns
+                    be.gemm_nn(left[r0:r1], right, F)                       # [phi_P D phi](P, g) on the local columns
                     be.hadamard_rows(F, V[r0:r1])
                     Kt = be.empty((r1 - r0, nao))
                     be.gemm_nt(F, self.ao, Kt, alpha=w)                     # sum_g w (.) phi_n(g)
                     be.gemm_nn(aoPT[:, r0:r1], Kt, K1, beta=1.0)            # sum_P phi_m(P) (.)
                     del F, Kt
+                del left, right
                 if sharded:
                     comm.all_reduce_sum(K1)                                 # the grid sum was over this rank's slice
                 ks.append(K1)
