@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument('--select', default='local', choices=['local', 'global'])
     ap.add_argument('--c-isdf', type=int, default=10)
     ap.add_argument('--fit-route', default=None, choices=['auto', 'cholesky', 'blockjacobi'])
+    ap.add_argument('--robust-k', action='store_true', help='time the build + get_jk with the robust exchange (not the headline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--stage-report', default=None, help='write the per-kernel table to this file')
     return ap.parse_args()
@@ -158,6 +159,8 @@ def main():
         df = ISDF(cell, kpts=kpts, c_isdf=args.c_isdf, select=args.select, comm=comm)
     if args.fit_route:
         df.fit_route = args.fit_route
+    if args.robust_k:
+        df.robust_k = True
     be = df.backend
 
     def barrier():
@@ -245,7 +248,7 @@ def main():
             'config': {'workload': workloads.WORKLOADS[args.workload][1], 'natm': cell.natm, 'nao': nao, 'ngrids': G,
                        'nip': P, 'c_isdf': args.c_isdf, 'select': args.select, 'parallelism': ('grid-shard x%d' if kpts is None else 'q-shard x%d') % world,
                        'nkpts': (1 if kpts is None else len(kpts)),
-                       'fit_route': df.fit_route, 'fit_route_used': df.fit_route_used,
+                       'fit_route': df.fit_route, 'fit_route_used': df.fit_route_used, 'robust_k': bool(getattr(df, 'robust_k', False)),
                        'route_probe_mismatch': df.bj_check, 'route_probe_tol': df.bj_check_tol},
             'whole_path_algorithmic_GBps': round(alg_bytes / sec_per_step / 1e9, 1),
             'stage_seconds_last_step': {k: round(v, 4) for k, v in df.timings.items()},
