@@ -265,9 +265,20 @@ __global__ __launch_bounds__(TPB2, 2) void gemm_nt_mfma_kernel_b(GemmArgs g) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(AF[i], BF[j], acc[i][j], 0, 0, 0);
+  // issue order inside a k-step region: one LDS fragment read (of the NEXT k-step) after every second MFMA, so that the
+  // reads trickle in under the MFMAs instead of in one burst (+1%); the LDS writes of the next chunk are spread the same
+  // way over the last k-step, which leaves only the barrier at the end of the chunk
+#define ISDF_INTERLEAVE() _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#define ISDF_INTERLEAVE_W() _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+  // first k-step: the six global loads of the chunk after next ride along (one per MFMA pair, after the fragment read)
+#define ISDF_INTERLEAVE_L() _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                \
+    if (q_ < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
   // exactly two fragment sets live (the scheduler would otherwise hoist all four k-steps' reads and
   // spill): reads of k-step kk+1 are issued before the MFMAs of kk, fenced by sched_barrier
-#define ISDF_COMPUTEB(BUF)                                                                    \
+#define ISDF_COMPUTEB(BUF, LOAD_AHEAD, STORE_NEXT)                                            \
   {                                                                                           \
     const double* pa = sA + (BUF) * BM2 * LDT + (wm * 64 + frow) * LDT + fk;                  \
     const double* pb = sB + (BUF) * BN * LDT + (wn * 64 + frow) * LDT + fk;                   \
@@ -275,15 +286,22 @@ __global__ __launch_bounds__(TPB2, 2) void gemm_nt_mfma_kernel_b(GemmArgs g) {
     ISDF_FRAGB(0, a0, b0)                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     ISDF_FRAGB(1, a1, b1)                                                                     \
+    LOAD_AHEAD                                                                                \
     ISDF_MFMAB(a0, b0)                                                                        \
+    ISDF_INTERLEAVE_L()                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     ISDF_FRAGB(2, a0, b0)                                                                     \
     ISDF_MFMAB(a1, b1)                                                                        \
+    ISDF_INTERLEAVE()                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     ISDF_FRAGB(3, a1, b1)                                                                     \
     ISDF_MFMAB(a0, b0)                                                                        \
+    ISDF_INTERLEAVE()                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                        \
+    STORE_NEXT                                                                                \
     ISDF_MFMAB(a1, b1)                                                                        \
+    ISDF_INTERLEAVE_W()                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
   }
 
   // prologue: chunk 0 -> LDS buffer 0; chunk 1 in flight in set Y
@@ -294,13 +312,9 @@ __global__ __launch_bounds__(TPB2, 2) void gemm_nt_mfma_kernel_b(GemmArgs g) {
   // steady state, two chunks per iteration: while chunk c computes, chunk c+1 sits in registers and
   // chunk c+2 is being loaded, so every load has two chunks of MFMAs to land
   for (int c = 0; c < nchunks; c += 2) {
-    ISDF_LOADB(min(c + 2, last), xa0, xa1, xa2, xa3, xb0, xb1)
-    ISDF_COMPUTEB(0)
-    ISDF_STOREB(1, ya0, ya1, ya2, ya3, yb0, yb1)
+    ISDF_COMPUTEB(0, ISDF_LOADB(min(c + 2, last), xa0, xa1, xa2, xa3, xb0, xb1), ISDF_STOREB(1, ya0, ya1, ya2, ya3, yb0, yb1))
     __syncthreads();
-    ISDF_LOADB(min(c + 3, last), ya0, ya1, ya2, ya3, yb0, yb1)
-    ISDF_COMPUTEB(1)
-    ISDF_STOREB(0, xa0, xa1, xa2, xa3, xb0, xb1)
+    ISDF_COMPUTEB(1, ISDF_LOADB(min(c + 3, last), ya0, ya1, ya2, ya3, yb0, yb1), ISDF_STOREB(0, xa0, xa1, xa2, xa3, xb0, xb1))
     __syncthreads();
   }
 
