@@ -278,44 +278,61 @@ __global__ __launch_bounds__(TPB2, 2) void gemm_nt_mfma_kernel_b(GemmArgs g) {
     if (q_ < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
   // exactly two fragment sets live (the scheduler would otherwise hoist all four k-steps' reads and
   // spill): reads of k-step kk+1 are issued before the MFMAs of kk, fenced by sched_barrier
-#define ISDF_COMPUTEB(BUF, LOAD_AHEAD, STORE_NEXT)                                            \
+  // One chunk = four k-steps.  Fragment sets alternate (k0: set 0, k1: set 1, k2: set 0, k3: set 1); each region issues
+  // the LDS reads of the NEXT k-step under its own MFMAs.  The chunk's single barrier sits after k-step 2: by then every
+  // wave has issued and completed (s_waitcnt in __syncthreads) all its reads of the current buffer and has written its
+  // part of the next one, so k-step 3 can already prefetch the first fragments of the next chunk from the other buffer
+  // and the MFMA stream runs across the chunk boundary without the post-barrier bubble.  A wave can only reach the next
+  // chunk's writes of this buffer after passing this barrier, i.e. after all waves finished reading it.
+  const int aoff = (wm * 64 + frow) * LDT + fk, boff = (wn * 64 + frow) * LDT + fk;
+  double a0[4], b0[4], a1[4], b1[4];
+#define ISDF_FRAGQ(BUF, KK, AF, BF)                                                           \
   {                                                                                           \
-    const double* pa = sA + (BUF) * BM2 * LDT + (wm * 64 + frow) * LDT + fk;                  \
-    const double* pb = sB + (BUF) * BN * LDT + (wn * 64 + frow) * LDT + fk;                   \
-    double a0[4], b0[4], a1[4], b1[4];                                                        \
-    ISDF_FRAGB(0, a0, b0)                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                        \
-    ISDF_FRAGB(1, a1, b1)                                                                     \
+    const double* pa = sA + (BUF) * BM2 * LDT + aoff;                                         \
+    const double* pb = sB + (BUF) * BN * LDT + boff;                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+      AF[i] = pa[i * 16 * LDT + (KK) * 4];                                                    \
+      BF[i] = pb[i * 16 * LDT + (KK) * 4];                                                    \
+    }                                                                                         \
+  }
+#define ISDF_INTERLEAVE_RW() _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                \
+    if (q_ < 6) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#define ISDF_CHUNKB(BUF, LOAD_AHEAD, STORE_NEXT)                                              \
+  {                                                                                           \
+    ISDF_FRAGQ(BUF, 1, a1, b1)                                                                \
     LOAD_AHEAD                                                                                \
     ISDF_MFMAB(a0, b0)                                                                        \
     ISDF_INTERLEAVE_L()                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                        \
-    ISDF_FRAGB(2, a0, b0)                                                                     \
+    ISDF_FRAGQ(BUF, 2, a0, b0)                                                                \
     ISDF_MFMAB(a1, b1)                                                                        \
     ISDF_INTERLEAVE()                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                        \
-    ISDF_FRAGB(3, a1, b1)                                                                     \
-    ISDF_MFMAB(a0, b0)                                                                        \
-    ISDF_INTERLEAVE()                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                        \
+    ISDF_FRAGQ(BUF, 3, a1, b1)                                                                \
     STORE_NEXT                                                                                \
+    ISDF_MFMAB(a0, b0)                                                                        \
+    ISDF_INTERLEAVE_RW()                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    __syncthreads();                                                                          \
+    ISDF_FRAGQ(1 - (BUF), 0, a0, b0)                                                          \
     ISDF_MFMAB(a1, b1)                                                                        \
-    ISDF_INTERLEAVE_W()                                                                       \
+    ISDF_INTERLEAVE()                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                        \
   }
 
-  // prologue: chunk 0 -> LDS buffer 0; chunk 1 in flight in set Y
+  // prologue: chunk 0 -> LDS buffer 0; chunk 1 in flight in set Y; first fragments of chunk 0
   ISDF_LOADB(0, xa0, xa1, xa2, xa3, xb0, xb1)
   ISDF_LOADB(1, ya0, ya1, ya2, ya3, yb0, yb1)
   ISDF_STOREB(0, xa0, xa1, xa2, xa3, xb0, xb1)
   __syncthreads();
+  ISDF_FRAGQ(0, 0, a0, b0)
+  __builtin_amdgcn_sched_barrier(0);
   // steady state, two chunks per iteration: while chunk c computes, chunk c+1 sits in registers and
   // chunk c+2 is being loaded, so every load has two chunks of MFMAs to land
   for (int c = 0; c < nchunks; c += 2) {
-    ISDF_COMPUTEB(0, ISDF_LOADB(min(c + 2, last), xa0, xa1, xa2, xa3, xb0, xb1), ISDF_STOREB(1, ya0, ya1, ya2, ya3, yb0, yb1))
-    __syncthreads();
-    ISDF_COMPUTEB(1, ISDF_LOADB(min(c + 3, last), ya0, ya1, ya2, ya3, yb0, yb1), ISDF_STOREB(0, xa0, xa1, xa2, xa3, xb0, xb1))
-    __syncthreads();
+    ISDF_CHUNKB(0, ISDF_LOADB(min(c + 2, last), xa0, xa1, xa2, xa3, xb0, xb1), ISDF_STOREB(1, ya0, ya1, ya2, ya3, yb0, yb1))
+    ISDF_CHUNKB(1, ISDF_LOADB(min(c + 3, last), ya0, ya1, ya2, ya3, yb0, yb1), ISDF_STOREB(0, xa0, xa1, xa2, xa3, xb0, xb1))
   }
 
   double* out = g.P + (int64_t)slab * g.slab_stride;
