@@ -428,40 +428,65 @@ __global__ __launch_bounds__(TPBD, 2) void gemm_nt_mfma_kernel_d(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  // one k-step: B fragments of the eight column groups at k = 4 kq + J, then 2 x 8 MFMAs
-#define ISDF_STEPD(BUF, J, AV0, AV1)                                                          \
+  // Same issue order as variant B: the B fragments of the NEXT k-step are read from LDS under the MFMAs of the current one
+  // (two fragment sets), the chunk's single barrier sits after k-step 2, and k-step 3 already prefetches the first
+  // fragments of the next chunk from the other buffer.
+  double bf0[8], bf1[8];
+#define ISDF_FRAGD(BUF, J, BF)                                                                \
   {                                                                                           \
     const double* pb = &sB[BUF][frow * LDT + 4 * fkq + (J)];                                  \
-    double bf[8];                                                                             \
-    _Pragma("unroll") for (int jn = 0; jn < 8; ++jn) bf[jn] = pb[jn * 16 * LDT];              \
-    _Pragma("unroll") for (int jn = 0; jn < 8; ++jn) {                                        \
-      acc[0][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(AV0, bf[jn], acc[0][jn], 0, 0, 0);    \
-      acc[1][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(AV1, bf[jn], acc[1][jn], 0, 0, 0);    \
-    }                                                                                         \
+    _Pragma("unroll") for (int jn = 0; jn < 8; ++jn) BF[jn] = pb[jn * 16 * LDT];              \
   }
-#define ISDF_COMPUTED(BUF, A00, A01, A10, A11)                                                \
+#define ISDF_MFMAD(AV0, AV1, BF)                                                              \
+    _Pragma("unroll") for (int jn = 0; jn < 8; ++jn) {                                        \
+      acc[0][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(AV0, BF[jn], acc[0][jn], 0, 0, 0);    \
+      acc[1][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(AV1, BF[jn], acc[1][jn], 0, 0, 0);    \
+    }
+#define ISDF_ILD_R() _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#define ISDF_ILD_RL() _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#define ISDF_ILD_RW() _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                \
+    if (q_ < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#define ISDF_CHUNKD(BUF, A00, A01, A10, A11, LOAD_AHEAD, STORE_NEXT)                          \
   {                                                                                           \
-    ISDF_STEPD(BUF, 0, A00.x, A10.x)                                                          \
-    ISDF_STEPD(BUF, 1, A00.y, A10.y)                                                          \
-    ISDF_STEPD(BUF, 2, A01.x, A11.x)                                                          \
-    ISDF_STEPD(BUF, 3, A01.y, A11.y)                                                          \
+    ISDF_FRAGD(BUF, 1, bf1)                                                                   \
+    ISDF_MFMAD(A00.x, A10.x, bf0)                                                             \
+    ISDF_ILD_R()                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    ISDF_FRAGD(BUF, 2, bf0)                                                                   \
+    ISDF_MFMAD(A00.y, A10.y, bf1)                                                             \
+    ISDF_ILD_R()                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    ISDF_FRAGD(BUF, 3, bf1)                                                                   \
+    STORE_NEXT                                                                                \
+    ISDF_MFMAD(A01.x, A11.x, bf0)                                                             \
+    ISDF_ILD_RW()                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    __syncthreads();                                                                          \
+    ISDF_FRAGD(1 - (BUF), 0, bf0)                                                             \
+    ISDF_MFMAD(A01.y, A11.y, bf1)                                                             \
+    LOAD_AHEAD                                                                                \
+    ISDF_ILD_RL()                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
   }
 
-  // prologue: chunk 0 in set X (its B part published in buffer 0), chunk 1 in flight in set Y
+  // prologue: chunk 0 in set X (its B part published in buffer 0), chunk 1 in flight in set Y, first fragments of chunk 0
   ISDF_LOADD(0, xa00, xa01, xa10, xa11, xb00, xb01, xb10, xb11)
   ISDF_LOADD(min(1, last), ya00, ya01, ya10, ya11, yb00, yb01, yb10, yb11)
   ISDF_STORED(0, xb00, xb01, xb10, xb11)
   __syncthreads();
+  ISDF_FRAGD(0, 0, bf0)
+  __builtin_amdgcn_sched_barrier(0);
   for (int c = 0; c < nchunks; c += 2) {
-    // chunk c: A operands in X, B in buffer 0; chunk c+1 sits in Y; X is refilled with chunk c+2 after its use
-    ISDF_COMPUTED(0, xa00, xa01, xa10, xa11)
-    ISDF_STORED(1, yb00, yb01, yb10, yb11)
-    ISDF_LOADD(min(c + 2, last), xa00, xa01, xa10, xa11, xb00, xb01, xb10, xb11)
-    __syncthreads();
-    ISDF_COMPUTED(1, ya00, ya01, ya10, ya11)
-    ISDF_STORED(0, xb00, xb01, xb10, xb11)
-    ISDF_LOADD(min(c + 3, last), ya00, ya01, ya10, ya11, yb00, yb01, yb10, yb11)
-    __syncthreads();
+    // chunk c: A operands in X, B in buffer 0, chunk c+1 sits in Y (its B part goes to buffer 1 during k-step 2);
+    // X is refilled with chunk c+2 once its last use (k-step 3) has been issued
+    ISDF_CHUNKD(0, xa00, xa01, xa10, xa11, ISDF_LOADD(min(c + 2, last), xa00, xa01, xa10, xa11, xb00, xb01, xb10, xb11),
+                ISDF_STORED(1, yb00, yb01, yb10, yb11))
+    ISDF_CHUNKD(1, ya00, ya01, ya10, ya11, ISDF_LOADD(min(c + 3, last), ya00, ya01, ya10, ya11, yb00, yb01, yb10, yb11),
+                ISDF_STORED(0, xb00, xb01, xb10, xb11))
   }
 
   double* out = g.P + (int64_t)slab * g.slab_stride;
