@@ -212,11 +212,11 @@ def main():
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_bench_cfg3_fetch_write.json')) as f:
                 pmc = json.load(f)
             # algorithmic bytes of the launches that kernel handles: W batch r reads V (nb x G) and the rows r.. of Y' ((P - r) x G)
-            # once and writes nb x (P - r); the 256x128 kernel takes the batches with P - r >= 4096 (gemm_f64.hip)
+            # once and writes nb x (P - r); the 256x128 kernel takes every batch of more than 128 rows (gemm_f64.hip)
             Gn, Pn = int(np.prod(cell.mesh)), len(df.ip)
             nbat = int(getattr(df, '_last_fft_batch', 0) or 512)
             algs = [8.0 * ((min(nbat, Pn - r) + (Pn - r)) * Gn + min(nbat, Pn - r) * (Pn - r))
-                    for r in range(0, Pn, nbat) if Pn - r >= 4096]
+                    for r in range(0, Pn, nbat) if min(nbat, Pn - r) > 128]
             for k, v in pmc.items():
                 fetch = v.get('FETCH_SIZE_per_launch', v.get('FETCH_SIZE_KB_per_launch'))     # counter unit: KB
                 write = v.get('WRITE_SIZE_per_launch', v.get('WRITE_SIZE_KB_per_launch'))
