@@ -3,17 +3,25 @@
 //    70-74 TF/s of the 78.6 TF/s FP64 MFMA peak on them: profiles/r01_probe_rocblas_hipfft_mfma64.log).
 //  * gemm_nt_f64: C = alpha * A * (B .* kscale)^T + beta * C with K contiguous in BOTH operands and
 //    K >> M, N — the shape of W = V Theta^T (K = ngrids) and of vj = ao (v .* ao)^T.  rocBLAS runs
-//    this shape at 1-13 TF/s (same log), so it gets a hand-written v_mfma_f64_16x16x4_f64 kernel:
-//      - 128x128 output tile per 256-thread workgroup, each wave a 64x64 sub-tile = 4x4 MFMA
-//        accumulators (128 VGPRs);
+//    this shape at 13-34 TF/s (profiles/r01_gemm_variants.log), so it gets hand-written v_mfma_f64_16x16x4_f64
+//    kernels - three variants share the work-unit scheme below (the launcher picks: B when M fills 256-row tiles,
+//    D for other aligned operands, A for unaligned ones; 69 TF/s = 0.88 of peak on the W product):
+//      - A: 128x128 output tile per 256-thread workgroup, each wave a 64x64 sub-tile = 4x4 MFMA
+//        accumulators (128 VGPRs), both operands through LDS;  B: 256x128, 8 waves, one workgroup per CU;
+//        D: 128x128, A operand straight from global memory into MFMA registers, only B through LDS;
 //      - K is cut into slabs; one work unit = (slab, tile).  Units are ordered slab-major with the
 //        row tile fastest so that workgroups that share an operand panel run at the same time, and
 //        the block id is remapped so that such neighbours land on the same XCD (its L2);
 //      - operands are staged global -> registers -> LDS in 16-deep K chunks (one full 128-B line per
-//        row per chunk), double buffered, rows padded to 144 B so that the ds_read_b64 fragment
+//        row per chunk), double buffered, rows padded to 136 B so that the ds_read_b64 fragment
 //        reads are bank-conflict free;
 //      - partial tiles of the slabs go to a workspace and are summed in a fixed order (deterministic,
-//        no float atomics).
+//        no float atomics);
+//      - B and D: the instruction ORDER inside a chunk is pinned with sched_group_barrier - one LDS read (of the next
+//        k-step), LDS write (of the next chunk) or global load (of the chunk after next) after every second MFMA, the
+//        chunk's single barrier after k-step 2, the next chunk's first fragments prefetched under k-step 3.  Worth
+//        64 -> 69 TF/s, and it keeps co-scheduled workgroups in step so that shared operand panels hit in L2 (fabric
+//        traffic 3.9x -> 1.3x the algorithmic bytes).
 //    Algorithmic work: 2*M*N*K flop; bound: FP64 MFMA (78.6 TF/s).
 #include "common.h"
 #include <cstdlib>
