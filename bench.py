@@ -34,7 +34,7 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default=os.environ.get('ISDF_BENCH_WORKLOAD', 'diamond-444-dzvp-120'))
-    ap.add_argument('--select', default='local', choices=['local', 'global'])
+    ap.add_argument('--select', default='local', choices=['local', 'refined', 'global'])
     ap.add_argument('--c-isdf', type=int, default=10)
     ap.add_argument('--fit-route', default=None, choices=['auto', 'cholesky', 'blockjacobi'])
     ap.add_argument('--robust-k', action='store_true', help='time the build + get_jk with the robust exchange (not the headline)')

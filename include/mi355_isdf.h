@@ -116,6 +116,17 @@ int isdf_select_ip(isdf_handle h, const double* d_ao, int nao, int64_t ld,
                    double tol, double tie_rtol,
                    double* d_L, int64_t ldL, int64_t* d_piv, int32_t* rank);
 
+/* S2, refined stage: pivoted Cholesky of an EXPLICIT symmetric positive semidefinite matrix d_A (m x m, row-major,
+ * leading dimension ldA, DESTROYED: it ends as the residual matrix) — the arithmetic of the reference's
+ * pivoted_cholesky_python (pyscf/lib/scipy_helper.py:71-110) applied to the matrix itself, organised in panels of
+ * ``panel`` pivots (<= 256; <= 0: 256) with a trailing update A <- A - Lp^T Lp after each panel (LAPACK dpstrf's scheme).
+ * Used on the pair-density Gram matrix restricted to a candidate set of grid points (isdf_gram_sq of the candidates'
+ * AO values): the candidates come from the per-atom selections, this call picks the final nip points among them.
+ * Same stopping rule (tol < 0: m * eps * max diag) and tie rule as isdf_select_ip.  d_piv (nip) int64 receives the
+ * pivots (indices into the candidate list), *rank (host) their number.  Synchronises the stream before returning. */
+int isdf_select_ip_gram(isdf_handle h, double* d_A, int m, int64_t ldA, int nip, double tol, double tie_rtol,
+                        int panel, int64_t* d_piv, int32_t* rank);
+
 /* Complex (k-point) mode of S2: d_ao holds the lattice-periodic parts u^k_m of all Bloch AOs as
  * 2*nh real rows, rows [0,nh) = Re u, rows [nh,2nh) = Im u (nao = 2*nh, nh = nk*nao_cell).  The
  * Gram matrix is A(r,r') = |sum_m conj(u_m(r)) u_m(r')|^2 (real).  nh = 0 is isdf_select_ip. */

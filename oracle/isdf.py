@@ -62,6 +62,48 @@ def select_ip(aoT, k, tol=-1.0, tie_rtol=TIE_RTOL):
     return piv[:rank], L[:rank]
 
 
+def pivoted_cholesky_gram(A, k, tol=-1.0, tie_rtol=TIE_RTOL):
+    """Pivoted Cholesky of an EXPLICIT symmetric positive semidefinite matrix — the reference's
+    pivoted_cholesky_python (pyscf/lib/scipy_helper.py:71-110: argmax of the residual diagonal, L[k,k] = sqrt(D[k]),
+    D -= L[:,k]^2, tol = n*eps*max(diag) when tol < 0) plus the tie rule above (tie_rtol = 0: the reference rule).
+    Restates include/mi355_isdf.h isdf_select_ip_gram.  Returns (piv[rank], L[rank, m])."""
+    A = np.array(A, dtype=float)
+    m = A.shape[0]
+    k = min(k, m)
+    d = A.diagonal().copy()
+    if tol < 0:
+        tol = m * np.finfo(float).eps * d.max()
+    L = np.zeros((k, m))
+    piv = np.zeros(k, dtype=np.int64)
+    alive = np.ones(m, dtype=bool)
+    rank = 0
+    for j in range(k):
+        dmax = d.max()
+        if not dmax > tol:
+            break
+        p = int(np.argmax((d >= dmax * (1.0 - tie_rtol)) & (d > 0)))
+        piv[j] = p
+        col = A[p] - (L[:j].T.dot(L[:j, p]) if j else 0.0)
+        dp = np.sqrt(d[p])
+        row = col / dp
+        row[~alive] = 0.0
+        row[p] = dp
+        L[j] = row
+        d = np.maximum(d - row * row, 0.0)
+        alive[p] = False
+        d[~alive] = -1.0
+        rank += 1
+    return piv[:rank], L[:rank]
+
+
+def refine_selection(aoT, cand, k, tol=-1.0, tie_rtol=TIE_RTOL):
+    """select='refined', second stage: the final k points among the candidate grid indices ``cand`` by pivoted Cholesky of
+    the pair-density Gram matrix restricted to the candidates.  Returns the chosen grid indices in pivot order."""
+    aoC = aoT[:, cand]
+    piv, _ = pivoted_cholesky_gram(aoC.T.dot(aoC) ** 2, k, tol=tol, tie_rtol=tie_rtol)
+    return np.asarray(cand)[piv]
+
+
 def fit_theta(L, piv):
     """Theta (k, m) = T^-1 L with T = L[:, piv] upper triangular."""
     T = np.triu(L[:, piv])

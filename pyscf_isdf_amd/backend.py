@@ -126,6 +126,15 @@ class HipBackend:
                          _np_ptr(nip), float(tol), float(tie_rtol), self._p(L), L.stride(0), self._p(piv), _np_ptr(rank))
         return rank
 
+    def select_ip_gram(self, A, nip, tol, tie_rtol, piv, panel=0):
+        """Pivoted Cholesky of the explicit matrix A (m, m) (destroyed); fills piv (nip,) int64; returns the rank."""
+        self._stream()
+        assert piv.dtype == torch.int64 and piv.is_contiguous() and A.stride(1) == 1 and A.shape[0] == A.shape[1]
+        rank = ctypes.c_int32(0)
+        self.handle.call('isdf_select_ip_gram', self._p(A), A.shape[0], A.stride(0), int(nip), float(tol), float(tie_rtol),
+                         int(panel), self._p(piv), ctypes.byref(rank))
+        return int(rank.value)
+
     def fit_from_chol(self, L, k, m, piv):
         self._stream()
         self.handle.call('isdf_fit_from_chol', self._p(L), int(k), int(m), L.stride(0), self._p(piv))

@@ -1,0 +1,239 @@
+// S2 (refined stage): pivoted Cholesky of an EXPLICIT symmetric positive semidefinite matrix A (m x m, HBM) —
+// the pair-density Gram matrix restricted to a candidate set, A = (phi_c^T phi_c)^2.  Same pivot rule as
+// select_ip.hip (pyscf/lib/scipy_helper.py:71-110 + the tie rule of mi355_isdf.h); the arithmetic is that of the
+// reference's pivoted_cholesky_python applied to A itself, organised like LAPACK's dpstrf:
+//
+//   * right-looking in panels of nb pivots: after a panel, the trailing matrix is updated in place,
+//     A <- A - Lp^T Lp (one m x m x nb GEMM), so a pivot column is one contiguous row of A (A stays symmetric) minus the
+//     contributions of the CURRENT panel only — 8*m*(1 + j_in_panel) bytes per pivot instead of 8*m*j for the
+//     left-looking form (33 TB -> 0.6 TB at m = 33280, P = 16640);
+//   * ONE launch per pivot.  Every workgroup owns 256 columns.  It first finds the pivot redundantly from the
+//     per-workgroup maxima of the previous step (nwg doubles) and the 256 residual diagonals of the first workgroup
+//     within the tie tolerance, then stages the panel entries of the pivot (pl[t] = Lp[t, p]) in LDS and updates its own
+//     columns: row = (A[p, i] - sum_t Lp[t, i] pl[t]) / sqrt(d_p), d[i] -= row^2.  The residual diagonal and the
+//     workgroup maxima are double-buffered (read step j-1, write step j) so that no workgroup reads what another one
+//     is writing in the same launch.
+#include "common.h"
+#include <cfloat>
+#include <climits>
+
+namespace {
+
+constexpr int TPB = 256;
+
+struct GramState {
+  double tol;
+  int rank;
+  int done;
+};
+
+__device__ inline double wmax(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline int wmin(int v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    int u = __shfl_xor(v, o);
+    v = u < v ? u : v;
+  }
+  return v;
+}
+
+// d0[i] = A[i,i]; per-workgroup maxima
+__global__ __launch_bounds__(TPB) void gram_diag_kernel(const double* __restrict__ A, int64_t ldA, int m,
+                                                       double* __restrict__ d, double* __restrict__ wgmax) {
+  __shared__ double red[TPB / 64];
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  double v = 0.0;
+  if (i < m) {
+    v = A[(int64_t)i * ldA + i];
+    d[i] = v;
+  }
+  double mx = wmax(i < m ? fmax(v, 0.0) : 0.0);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < TPB / 64; ++w) mx = fmax(mx, red[w]);
+    wgmax[blockIdx.x] = mx;
+  }
+}
+
+// One pivot: j = global pivot index, jl = index inside the current panel (rows of Lp).
+__global__ __launch_bounds__(TPB) void gram_pivot_step_kernel(
+    const double* __restrict__ A, int64_t ldA, int m, double* __restrict__ Lp, int64_t ldL,
+    const double* __restrict__ d_old, double* __restrict__ d_new, const double* __restrict__ wg_old,
+    double* __restrict__ wg_new, int nwg, int j, int jl, int nip, double tol_in, double tie_rtol,
+    GramState* __restrict__ st, int64_t* __restrict__ piv) {
+  __shared__ double s_red[TPB / 64];
+  __shared__ int s_redi[TPB / 64];
+  __shared__ double s_pl[TPB];
+  __shared__ double s_bc[2];
+  __shared__ int s_bci[2];
+  const int tid = threadIdx.x;
+  const int wg = blockIdx.x;
+  const int i = wg * TPB + tid;
+  const bool valid = i < m;
+
+  // (1) global maximum of the residual diagonal from the per-workgroup maxima of the previous step
+  double gm = 0.0;
+  for (int w = tid; w < nwg; w += TPB) gm = fmax(gm, wg_old[w]);
+  gm = wmax(gm);
+  if ((tid & 63) == 0) s_red[tid >> 6] = gm;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < TPB / 64; ++w) gm = fmax(gm, s_red[w]);
+    s_bc[0] = gm;
+  }
+  __syncthreads();
+  gm = s_bc[0];
+  const double tol = (j == 0) ? (tol_in < 0 ? (double)m * DBL_EPSILON * gm : tol_in) : st->tol;
+  const bool stop = st->done || j >= nip || !(gm > tol);
+  if (stop) {
+    if (valid) {
+      Lp[(int64_t)jl * ldL + i] = 0.0;
+      d_new[i] = d_old[i];
+    }
+    if (tid == 0) {
+      wg_new[wg] = wg_old[wg];
+      if (wg == 0) { st->done = 1; if (j == 0) { st->tol = tol; st->rank = 0; } }
+    }
+    return;
+  }
+  // (2) first workgroup whose maximum is within the tie tolerance, then the first such column inside it
+  const double thr = gm * (1.0 - tie_rtol);
+  int wfirst = INT_MAX;
+  for (int w = tid; w < nwg; w += TPB)
+    if (wg_old[w] >= thr && wg_old[w] > 0.0) { wfirst = w; break; }
+  wfirst = wmin(wfirst);
+  if ((tid & 63) == 0) s_redi[tid >> 6] = wfirst;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < TPB / 64; ++w) wfirst = s_redi[w] < wfirst ? s_redi[w] : wfirst;
+    s_bci[0] = wfirst;
+  }
+  __syncthreads();
+  wfirst = s_bci[0];
+  int cand = INT_MAX;
+  {
+    const int c = wfirst * TPB + tid;
+    if (c < m) {
+      const double dv = d_old[c];
+      if (dv >= thr && dv > 0.0) cand = c;
+    }
+  }
+  cand = wmin(cand);
+  if ((tid & 63) == 0) s_redi[tid >> 6] = cand;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < TPB / 64; ++w) cand = s_redi[w] < cand ? s_redi[w] : cand;
+    s_bci[1] = cand;
+    s_bc[1] = cand == INT_MAX ? 0.0 : sqrt(d_old[cand]);
+  }
+  __syncthreads();
+  const int p = s_bci[1];
+  const double dp = s_bc[1];
+  if (p == INT_MAX) {   // cannot happen while the maxima are consistent with d; never index with it
+    if (valid) {
+      Lp[(int64_t)jl * ldL + i] = 0.0;
+      d_new[i] = d_old[i];
+    }
+    if (tid == 0) {
+      wg_new[wg] = wg_old[wg];
+      if (wg == 0) st->done = 1;
+    }
+    return;
+  }
+  // (3) the pivot's entries of the current panel
+  if (tid < jl) s_pl[tid] = Lp[(int64_t)tid * ldL + p];
+  __syncthreads();
+  // (4) this workgroup's columns
+  double dnew = 0.0;
+  if (valid) {
+    const double dold = d_old[i];
+    double row;
+    if (i == p) {
+      row = dp;
+      dnew = -1.0;
+    } else if (dold < 0.0) {       // an earlier pivot: its residual row is exactly zero
+      row = 0.0;
+      dnew = -1.0;
+    } else {
+      double col = A[(int64_t)p * ldA + i];
+      const double* __restrict__ pL = Lp + i;
+#pragma unroll 8
+      for (int t = 0; t < jl; ++t) col = fma(-pL[(int64_t)t * ldL], s_pl[t], col);
+      row = col / dp;
+      dnew = fma(-row, row, dold);
+      if (dnew < 0.0) dnew = 0.0;
+    }
+    Lp[(int64_t)jl * ldL + i] = row;
+    d_new[i] = dnew;
+  }
+  double mx = wmax(valid ? fmax(dnew, 0.0) : 0.0);
+  if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < TPB / 64; ++w) mx = fmax(mx, s_red[w]);
+    wg_new[wg] = mx;
+    if (wg == 0) {
+      piv[j] = p;
+      st->rank = j + 1;
+      if (j == 0) st->tol = tol;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int isdf_select_ip_gram(isdf_handle h, double* d_A, int m, int64_t ldA, int nip, double tol,
+                                   double tie_rtol, int panel, int64_t* d_piv, int32_t* rank) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_A && d_piv && rank);
+  ARG_CHECK(h, m > 0 && ldA >= m && nip > 0 && tie_rtol >= 0.0 && tie_rtol < 1.0);
+  if (panel <= 0) panel = 256;
+  ARG_CHECK(h, panel <= TPB);
+  if (nip > m) nip = m;
+  const int nwg = (int)cdiv(m, TPB);
+  const int64_t ldL = ((int64_t)m + 31) / 32 * 32;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t b_d = al(sizeof(double) * m), b_w = al(sizeof(double) * nwg), b_st = al(sizeof(GramState));
+  const size_t b_L = al(sizeof(double) * (size_t)panel * ldL);
+  char* ws = (char*)isdf_ws(h, "select_gram", 2 * b_d + 2 * b_w + b_st + b_L);
+  if (!ws) return ISDF_ERR_HIP;
+  double* d_d[2];
+  double* d_w[2];
+  d_d[0] = (double*)ws; ws += b_d;
+  d_d[1] = (double*)ws; ws += b_d;
+  d_w[0] = (double*)ws; ws += b_w;
+  d_w[1] = (double*)ws; ws += b_w;
+  GramState* d_st = (GramState*)ws; ws += b_st;
+  double* d_Lp = (double*)ws;
+  HIP_TRY(h, hipMemsetAsync(d_st, 0, sizeof(GramState), h->stream));
+  HIP_TRY(h, hipMemsetAsync(d_piv, 0xff, sizeof(int64_t) * (size_t)nip, h->stream));
+  hipLaunchKernelGGL(gram_diag_kernel, dim3(nwg), dim3(TPB), 0, h->stream, d_A, ldA, m, d_d[0], d_w[0]);
+  KERNEL_CHECK(h);
+  int cur = 0;
+  for (int k0 = 0; k0 < nip; k0 += panel) {
+    const int nb = nip - k0 < panel ? nip - k0 : panel;
+    {
+      ProfScope ps(h, "gram_pivot_step_kernel[byte]", 8.0 * (double)m * (0.5 * nb * (nb - 1) + 4.0 * nb), nb);
+      for (int jl = 0; jl < nb; ++jl) {
+        hipLaunchKernelGGL(gram_pivot_step_kernel, dim3(nwg), dim3(TPB), 0, h->stream, d_A, ldA, m, d_Lp, ldL,
+                           d_d[cur], d_d[cur ^ 1], d_w[cur], d_w[cur ^ 1], nwg, k0 + jl, jl, nip, tol, tie_rtol,
+                           d_st, d_piv);
+        cur ^= 1;
+      }
+      KERNEL_CHECK(h);
+    }
+    if (k0 + nb < nip) {
+      // trailing update A <- A - Lp^T Lp (rows of finished pivots become zero rows of the residual)
+      int rc = gemm_rm(h, 'T', 'N', m, m, nb, -1.0, d_Lp, ldL, d_Lp, ldL, 1.0, d_A, ldA);
+      if (rc != ISDF_OK) return rc;
+    }
+  }
+  GramState hst;
+  HIP_TRY(h, hipMemcpyAsync(&hst, d_st, sizeof(GramState), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  *rank = hst.rank;
+  return ISDF_OK;
+}

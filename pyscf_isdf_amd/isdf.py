@@ -42,7 +42,10 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         self.blockdim = 240
         self.exxdiv = None
         self.c_isdf = c_isdf
-        self.select = select              # 'local': per-atom Voronoi blocks + global fit; 'global': one block
+        self.select = select              # 'local': per-atom Voronoi blocks + global fit; 'global': one block;
+                                          # 'refined': local candidates (refine_over x too many), then ONE pivoted Cholesky
+                                          # restricted to the candidate set picks the final points
+        self.refine_over = 2.0            # 'refined': candidates per atom = refine_over * c_isdf * nao_atom
         self.tie_rtol = 1e-10
         self.select_tol = -1.0           # stop when the largest residual diagonal <= tol; < 0: m*eps*max diag (scipy_helper.py:88-90)
         self.reg_rel = 1e-12             # relative diagonal shift of A_PP in the global fit
@@ -238,18 +241,21 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
             self.aoP.copy_(tmp.T)
             del tmp
             t0 = self._tick('S3_fit', t0)
-        elif self.select == 'local':
+        elif self.select in ('local', 'refined'):
             owner = partition_grid_by_atom(coords, cell.atom_coords(), a)
             perm = np.argsort(owner, kind='stable').astype(np.int64)
             counts = np.bincount(owner, minlength=cell.natm)
             blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)
-            nip = np.minimum(self.nip_per_atom(), counts).astype(np.int32)
+            nip_final = np.minimum(self.nip_per_atom(), counts).astype(np.int32)
+            nip = nip_final
+            if self.select == 'refined':
+                nip = np.minimum(np.ceil(self.nip_per_atom() * float(self.refine_over)).astype(np.int64), counts).astype(np.int32)
             kmax = int(nip.max())
             t0 = self._tick('host_partition', t0)
             d_perm = be.to_device(perm)
             # the block-major copy of phi and the Cholesky rows are scratch that dies before the fit:
             # they live inside the (P, G) fit buffer, which is not in use yet
-            Pmax = int(nip.sum())
+            Pmax = int(nip_final.sum())
             scratch = self._buffer('theta', (max(Pmax, nao + kmax), G))
             ao_sel = scratch[:nao]
             L = scratch[nao:nao + kmax]
@@ -259,7 +265,12 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
             del ao_sel, L, scratch
             piv_h = be.to_host(piv)
             clusters = self._bj_clusters()
-            ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for cl in clusters for b in cl])
+            if self.select == 'refined':
+                t0 = self._tick('S2_select_candidates', t0)
+                rank = self._refine_selection(perm, blk_off, piv_h, rank, int(nip_final.sum()), owner)
+                ip = np.concatenate([self._refined_by_atom[b] for cl in clusters for b in cl])
+            else:
+                ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for cl in clusters for b in cl])
             self.ip = ip.astype(np.int64)
             P = len(ip)
             t0 = self._tick('S2_select_ip', t0)
@@ -314,6 +325,29 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         self._keep_V_for_robust_k(t0)
         self._built = True
         return self
+
+    def _refine_selection(self, perm, blk_off, piv_h, rank, P_target, owner):
+        """select='refined': the per-atom selections (refine_over x too many points each) are only CANDIDATES; one
+        pivoted Cholesky of the pair-density Gram matrix restricted to the candidate set (a single block of the same
+        selection kernels, pivot rule pyscf/lib/scipy_helper.py:71-110) picks the final P_target points.  Leaves the chosen
+        grid indices per atom (in pivot order) in self._refined_by_atom and returns the points per atom."""
+        be = self.backend
+        natm = self.cell.natm
+        cand = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(natm)]).astype(np.int64)
+        m = len(cand)
+        P_target = min(P_target, m)
+        nao = self.ao.shape[0]
+        aoC = be.empty((m, nao))
+        be.gather_aoP(self.ao, be.to_device(cand), aoC)
+        A = be.empty((m, m))
+        be.gram_sq(aoC, A)
+        piv2 = be.empty((P_target,), dtype=torch.int64)
+        r2 = be.select_ip_gram(A, P_target, self.select_tol, self.tie_rtol, piv2)
+        chosen = cand[be.to_host(piv2)[:r2]]
+        del aoC, A, piv2
+        own = owner[chosen]
+        self._refined_by_atom = [chosen[own == b] for b in range(natm)]
+        return np.array([len(x) for x in self._refined_by_atom], dtype=np.int32)
 
     def _keep_V_for_robust_k(self, t0):
         """robust_k: the fit buffer (Theta) becomes V = conv(Theta), in place (one more pass of batched FFTs)."""

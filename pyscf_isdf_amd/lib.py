@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lib = None
 
@@ -33,6 +33,7 @@ SIGNATURES = {
     'isdf_eval_ao': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_i64]),
     'isdf_gather_cols': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_i64]),
     'isdf_select_ip': (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_i64, c_vp, c_vp]),
+    'isdf_select_ip_gram': (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_dbl, c_dbl, c_int, c_vp, ctypes.POINTER(ctypes.c_int32)]),
     'isdf_fit_from_chol': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp]),
     'isdf_fit_prepare': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_dbl, c_vp, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_fit_apply': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_i64, c_int, c_vp, c_i64]),

@@ -68,6 +68,11 @@ class OracleBackend:
             L[:len(p), blk_off[b]:blk_off[b + 1]] = torch.from_numpy(Lb)
         return rank
 
+    def select_ip_gram(self, A, nip, tol, tie_rtol, piv, panel=0):
+        p, _ = oisdf.pivoted_cholesky_gram(A.numpy(), int(nip), tol=tol, tie_rtol=tie_rtol)
+        piv[:len(p)] = torch.from_numpy(p)
+        return len(p)
+
     def fit_from_chol(self, L, k, m, piv):
         th = oisdf.fit_theta(L.numpy()[:k, :m], piv.numpy()[:k])
         L[:k, :m] = torch.from_numpy(th)

@@ -124,6 +124,72 @@ def test_select_ip_tie_rule_lowest_index(be):
     assert np.array_equal(piv[0, :12], piv_ref)
 
 
+def _select_gram_gpu(be, A, nip, tie_rtol=1e-10, tol=-1.0, panel=0):
+    import torch
+    piv = be.empty((nip,), dtype=torch.int64)
+    dA = be.to_device(np.ascontiguousarray(A))
+    r = be.select_ip_gram(dA, nip, tol, tie_rtol, piv, panel=panel)
+    return r, be.to_host(piv)[:r], be.to_host(dA)
+
+
+@pytest.mark.parametrize('panel', [0, 16, 7])
+def test_select_ip_gram_matches_reference_golden(be, panel):
+    """Refined stage on the explicit Gram matrix, through the C ABI, against the REFERENCE's own output
+    (tests/golden/pivoted_cholesky_golden.json, made by pyscf/lib/scipy_helper.py:71-110 on the same matrices,
+    tie_rtol = 0 = the reference rule): identical pivot lists and ranks — for one panel and for several panels with
+    trailing updates in between."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pivoted_cholesky_golden.json')) as f:
+        gold = json.load(f)
+    for case in gold['cases']:
+        rng = np.random.default_rng(case['seed'])
+        ao = rng.standard_normal((case['nao'], case['m'])) * np.exp(-3.0 * rng.random(case['m']))
+        r, piv, _ = _select_gram_gpu(be, ao.T.dot(ao) ** 2, case['m'], tie_rtol=0.0, panel=panel)
+        assert r == case['rank']
+        assert list(piv) == case['piv']
+
+
+def test_select_ip_gram_matches_oracle_ragged_and_ties(be):
+    """m not a multiple of the workgroup (1000), 300 pivots in panels of 64 (four trailing updates): identical pivots
+    to the oracle restatement and the same residual matrix where no pivot has been taken; a rank-deficient matrix
+    stops at its rank; exactly duplicated columns: the lowest index wins on every step."""
+    rng = np.random.default_rng(21)
+    ao = rng.standard_normal((40, 1000)) * np.exp(-2.0 * rng.random(1000))
+    A = ao.T.dot(ao) ** 2
+    pr, Lr = oisdf.pivoted_cholesky_gram(A, 300)
+    r, piv, _ = _select_gram_gpu(be, A, 300, panel=64)
+    assert r == 300 and np.array_equal(piv, pr)
+    ao6 = rng.standard_normal((6, 700))                       # 21 independent pair products
+    pr, _ = oisdf.pivoted_cholesky_gram(ao6.T.dot(ao6) ** 2, 50)
+    r, piv, _ = _select_gram_gpu(be, ao6.T.dot(ao6) ** 2, 50, panel=8)
+    assert len(pr) == 21 and r == 21 and np.array_equal(piv, pr)
+    base = rng.standard_normal((5, 300))
+    dup = np.concatenate([base, base, base], axis=1)
+    r, piv, _ = _select_gram_gpu(be, dup.T.dot(dup) ** 2, 12, panel=5)
+    assert r == 12 and (piv < 300).all()
+    assert np.array_equal(piv, oisdf.pivoted_cholesky_gram(dup.T.dot(dup) ** 2, 12)[0])
+
+
+def test_refined_selection_end_to_end_matches_oracle_pipeline():
+    """select='refined' on the GPU == the same host driver over the CPU oracle (identical points; K within 1e-9
+    relative), on a rattled cell (no symmetry ties) with candidates 2x over-complete."""
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(3)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    out = {}
+    for name, backend in (('gpu', None), ('cpu', OracleBackend())):
+        df = ISDF(cell, c_isdf=3, select='refined', backend=backend)
+        df.refine_over = 2.0
+        df.fit_route = 'cholesky'
+        out[name] = (df.get_jk(dm, with_j=False)[1], df.ip.copy())
+    assert np.array_equal(out['gpu'][1], out['cpu'][1])
+    assert abs(out['gpu'][0] - out['cpu'][0]).max() < 1e-9 * abs(out['cpu'][0]).max()
+
+
 def test_fit_from_chol(be):
     """S3a: Theta = T^-1 L equals the normal-equation fit and is the identity on the points."""
     cell = cells.cell_he_c()

@@ -32,6 +32,60 @@ def test_pivots_match_reference_golden(impl):
         assert np.allclose(L[np.arange(len(piv)), piv], case['diag'], rtol=1e-7, atol=0)
 
 
+def test_explicit_gram_pivoted_cholesky_matches_reference_golden():
+    """oracle.pivoted_cholesky_gram (the restatement of isdf_select_ip_gram) on the explicitly formed Gram matrix ==
+    the reference's pivoted_cholesky_python on the same matrix (golden pivots, rank and factor diagonal)."""
+    with open(GOLD) as f:
+        gold = json.load(f)
+    for case in gold['cases']:
+        ao = _make_ao(case['seed'], case['nao'], case['m'])
+        piv, L = oisdf.pivoted_cholesky_gram(ao.T.dot(ao) ** 2, case['m'], tol=-1.0, tie_rtol=0.0)
+        assert len(piv) == case['rank'] and list(piv) == case['piv']
+        assert np.allclose(L[np.arange(len(piv)), piv], case['diag'], rtol=1e-7, atol=0)
+        # and it is the implicit selection's answer too
+        assert list(oisdf.select_ip(ao, case['m'], tol=-1.0, tie_rtol=0.0)[0]) == list(piv)
+
+
+def test_refined_selection_host_logic_with_checker_backend():
+    """select='refined' through the host driver (no GPU): per-atom candidates (refine_over x too many), one pivoted
+    Cholesky restricted to them; the points equal the oracle's two-stage restatement, are grouped by atom for the
+    block-Jacobi route, and K is closer to the exact exchange than with the plain local selection at equal P."""
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    from pyscf_isdf_amd._common import partition_grid_by_atom
+    cell = cells.cell_diamond_prim('gth-szv', (12, 12, 12))
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(1)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao); occ[:4] = 2
+    dm = (c * occ).dot(c.T)
+    rcut = gto.estimate_rcut_per_shell(cell)
+    coords = cell.get_uniform_grids()
+    ao = oao.eval_ao(cell._atm, cell._bas, cell._env, coords, gto.get_lattice_Ls(cell, rcut=rcut.max()), rcut, rule='point')
+    aoT = np.ascontiguousarray(ao.T)
+    k_exact = fftdf.get_k(ao, dm, cell.lattice_vectors(), cell.mesh)
+    errs = {}
+    for sel in ('local', 'refined'):
+        df = ISDF(cell, c_isdf=4, select=sel, backend=OracleBackend())
+        df.refine_over = 2.0
+        errs[sel] = abs(df.get_jk(dm, with_j=False)[1] - k_exact).max()
+        assert len(df.ip) == 4 * nao and len(set(df.ip)) == len(df.ip)
+        if sel == 'refined':
+            owner = partition_grid_by_atom(coords, cell.atom_coords(), cell.lattice_vectors())
+            perm = np.argsort(owner, kind='stable')
+            off = np.append(0, np.cumsum(np.bincount(owner, minlength=cell.natm)))
+            cand = np.concatenate([perm[off[b]:off[b + 1]][oisdf.select_ip(aoT[:, perm[off[b]:off[b + 1]]], 2 * 4 * 4)[0]]
+                                   for b in range(cell.natm)])
+            chosen = oisdf.refine_selection(aoT, cand, 4 * nao)
+            assert sorted(chosen) == sorted(df.ip)
+            # stored atom by atom (the preconditioner blocks of the block-Jacobi route), pivot order inside an atom
+            own = owner[df.ip]
+            assert (np.diff(own) >= 0).all()
+            for b in range(cell.natm):
+                assert list(df.ip[own == b]) == [g for g in chosen if owner[g] == b]
+    assert errs['refined'] < errs['local']
+
+
 def test_c_oracle_equals_numpy_oracle():
     ao = _make_ao(42, 12, 3000)
     p1, L1 = oisdf.select_ip(ao, 60)

@@ -15,7 +15,16 @@ print(name, 'nao', cell.nao_nr(), 'nocc', nocc, 'ngrids', int(np.prod(cell.mesh)
 ref = None
 for sel in selects:
     for cc in cs:
-        df = ISDF(cell, c_isdf=cc, select=sel)
+        over = None
+        if ':' in sel:                      # 'refined:3' = refined selection with refine_over = 3
+            sel_, over = sel.split(':')[0], float(sel.split(':')[1])
+        else:
+            sel_ = sel
+        df = ISDF(cell, c_isdf=cc, select=sel_)
+        if over is not None:
+            df.refine_over = over
+        if os.environ.get('ISDF_FIT_ROUTE'):
+            df.fit_route = os.environ['ISDF_FIT_ROUTE']
         t0 = time.perf_counter()
         vk = df.get_jk(dm, with_j=False)[1]
         t1 = time.perf_counter()
@@ -24,7 +33,7 @@ for sel in selects:
             df.backend.synchronize()
             print('exact K (N*nocc = %d FFT pairs) on the GPU: %.1f s' % (cell.nao_nr() * nocc, time.perf_counter() - t1), flush=True)
         ek, ek0 = np.einsum('ij,ji', vk, dm) / 4, np.einsum('ij,ji', ref, dm) / 4
-        print('select=%-6s c=%2d P=%6d  build+K %.2f s   E_K(ISDF) %.8f  E_K(exact) %.8f  dE_K %.2e Eh (%.1e rel)  max|dK| %.2e'
-              % (sel, cc, len(df.ip), t1 - t0, ek, ek0, ek - ek0, abs(ek - ek0) / ek0, abs(vk - ref).max()), flush=True)
+        print('select=%-10s c=%2d P=%6d  build+K %.2f s   E_K(ISDF) %.8f  E_K(exact) %.8f  dE_K %.2e Eh (%.1e rel)  max|dK| %.2e  route %s  stages %s'
+              % (sel, cc, len(df.ip), t1 - t0, ek, ek0, ek - ek0, abs(ek - ek0) / ek0, abs(vk - ref).max(), df.fit_route_used, {k: round(v, 2) for k, v in df.timings.items()}), flush=True)
         df.reset()
         del df

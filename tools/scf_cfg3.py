@@ -1,5 +1,5 @@
-"""Developer check at the headline size (diamond 4x4x4, gth-dzvp, 120^3): converge an RHF driven by the ISDF object with the
-robust K, then evaluate the reference's exact exchange ONCE at the converged orbitals (54 s) and compare the plain and the robust
+"""Developer check at the headline size (diamond 4x4x4, gth-dzvp, 120^3): converge an RHF driven by the ISDF object (robust K
+unless argv[4] == 'plain'), then evaluate the reference's exact exchange ONCE at the converged orbitals (54 s) and compare the plain and the robust
 ISDF exchange with it - the fit error with physical orbitals at configs[2].  Kinetic energy / overlap by plane-wave
 quadrature of the AO values, on the device with torch.fft (tool-level plumbing), before the ISDF buffers are allocated."""
 import sys, os, time
@@ -16,8 +16,14 @@ nao, nocc = cell.nao_nr(), cell.nelectron // 2
 mesh = [int(x) for x in cell.mesh]
 G = int(np.prod(mesh))
 
-df = ISDF(cell, c_isdf=10)
-df.robust_k = True
+select = sys.argv[2] if len(sys.argv) > 2 else 'local'
+c_isdf = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+drive_plain = len(sys.argv) > 4 and sys.argv[4] == 'plain'
+df = ISDF(cell, c_isdf=c_isdf, select=select.split(':')[0])
+if ':' in select:
+    df.refine_over = float(select.split(':')[1])
+df.robust_k = not drive_plain
+print(name, 'select', select, 'c', c_isdf, 'SCF driven by the', 'plain' if drive_plain else 'robust', 'K', flush=True)
 be = df.backend
 # AO values once, for T and S
 coords = df.grids.coords
@@ -45,7 +51,8 @@ print('T, S, hcore done', flush=True)
 
 t0 = time.perf_counter()
 df.build()
-print('robust build %.1f s  %s' % (time.perf_counter() - t0, {k: round(v, 2) for k, v in df.timings.items()}), flush=True)
+print('build (robust_k=%s) %.1f s' % (df.robust_k, 0.0), end='  ')
+print('build %.1f s  %s' % (time.perf_counter() - t0, {k: round(v, 2) for k, v in df.timings.items()}), flush=True)
 e, c = scipy.linalg.eigh(hcore, S)
 dm = 2 * c[:, :nocc].dot(c[:, :nocc].T)
 errs, focks, e_last = [], [], 0.0
@@ -72,13 +79,18 @@ for it in range(30):
     e, c = scipy.linalg.eigh(f, S)
     dm = 2 * c[:, :nocc].dot(c[:, :nocc].T)
 cocc = c[:, :nocc]
-vk_rob = df.get_jk(dm, with_j=False)[1]
+vk_first = df.get_jk(dm, with_j=False)[1]
 t1 = time.perf_counter()
 vk_ex = df.get_k_exact(mo_coeff=cocc, mo_occ=np.full(nocc, 2.0))
 print('exact K at the converged orbitals: %.1f s' % (time.perf_counter() - t1), flush=True)
-df.robust_k = False
+df.robust_k = drive_plain
+t1 = time.perf_counter()
 df.build()
-vk_plain = df.get_jk(dm, with_j=False)[1]
+print('second build (robust_k=%s) %.1f s  %s' % (df.robust_k, time.perf_counter() - t1, {k: round(v, 2) for k, v in df.timings.items()}), flush=True)
+t1 = time.perf_counter()
+vk_second = df.get_jk(dm, with_j=False)[1]
+print('its K: %.2f s' % (time.perf_counter() - t1), flush=True)
+vk_plain, vk_rob = (vk_first, vk_second) if drive_plain else (vk_second, vk_first)
 ek = lambda k: np.einsum('ij,ji', k, dm) / 4
 print('E_K exact %.10f   plain ISDF dE_K %.3e (max|dK| %.2e)   robust dE_K %.3e (max|dK| %.2e)   [%d atoms]' %
       (ek(vk_ex), ek(vk_plain) - ek(vk_ex), abs(vk_plain - vk_ex).max(), ek(vk_rob) - ek(vk_ex), abs(vk_rob - vk_ex).max(), cell.natm), flush=True)
