@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet, MI355X FP64 matrix (the guide's table has no f64 row);
                                # best rocBLAS dgemm measured on the box: 73.8 (profiles/r01_probe_*.log)
+PMC_FILE = 'r02_pmc_bench_cfg3_fetch_write.json'
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -34,7 +35,10 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default=os.environ.get('ISDF_BENCH_WORKLOAD', 'diamond-444-dzvp-120'))
-    ap.add_argument('--select', default='local', choices=['local', 'refined', 'global'])
+    ap.add_argument('--select', default='refined', choices=['local', 'refined', 'global'])
+    ap.add_argument('--refine-over', type=float, default=2.0)
+    ap.add_argument('--no-accuracy', action='store_true',
+                    help="skip the exact-exchange comparison (config.dE_K_vs_exact; 48 s at configs[2], after the timed region)")
     ap.add_argument('--c-isdf', type=int, default=10)
     ap.add_argument('--fit-route', default=None, choices=['auto', 'cholesky', 'blockjacobi'])
     ap.add_argument('--robust-k', action='store_true', help='time the build + get_jk with the robust exchange (not the headline)')
@@ -81,7 +85,7 @@ def cpu_baseline(cell, c_isdf, gpu_stage_sizes):
     A[np.diag_indices(P)] += 1e-3 * A.diagonal().max()
     cf = scipy.linalg.cho_factor(A, overwrite_a=True)
     t_chol = time.perf_counter() - t
-    n3 = min(G, 1024)
+    n3 = min(G, 16384)
     t = time.perf_counter()
     B = aoP.dot(aoT_s[:, :n3]) ** 2
     scipy.linalg.cho_solve(cf, B)
@@ -91,14 +95,16 @@ def cpu_baseline(cell, c_isdf, gpu_stage_sizes):
     n4 = 4
     rows = rng.standard_normal((n4, G))
     t = time.perf_counter()
-    V = oisdf.coulomb_V(rows, a, mesh)
+    oisdf.coulomb_V(rows, a, mesh)
     est['S4_coulomb_fft'] = (time.perf_counter() - t) * P / n4
-    n5 = min(G, 65536)
+    del rows
+    r5, n5 = min(P, 512), min(G, 16384)                  # a 512-row batch of V against all P rows of Theta: BLAS at full rate
+    Vs = rng.standard_normal((r5, n5))
     th = rng.standard_normal((P, n5))
     t = time.perf_counter()
-    V[:, :n5].dot(th.T)
-    est['S5_W_gemm'] = (time.perf_counter() - t) * (P / n4) * (G / n5) * 0.5   # symmetric half, like the GPU path
-    del th
+    Vs.dot(th.T)
+    est['S5_W_gemm'] = (time.perf_counter() - t) * (P / r5) * (G / n5) * 0.5   # symmetric half, like the GPU path
+    del th, Vs
     # S6 J (two N x N x G contractions on a slice) and S7 K (exact size if affordable, else row slice)
     dm = rng.standard_normal((nao, nao))
     t = time.perf_counter()
@@ -115,15 +121,58 @@ def cpu_baseline(cell, c_isdf, gpu_stage_sizes):
     est['S7_get_k'] = (time.perf_counter() - t) * P / n7
     total = sum(est.values())
     sample = ('numpy/scipy oracle (Cholesky fit route), stage samples extrapolated linearly: S1 %d of %d grid points; S2 1 of %d atom blocks '
-              '(%d pts, %d pivots); S3 full %dx%d Cholesky + %d of %d grid columns; S4 %d of %d FFT rows; S5 %d rows x %d cols; '
+              '(%d pts, %d pivots); S3 full %dx%d Cholesky + %d of %d grid columns; S4 %d of %d FFT rows; S5 %d rows x %d grid columns against all P rows; '
               'S6 %d grid points; S7 %d of %d rows; measured %.1f s of CPU work; per-stage estimate (s): %s'
-              % (n1, G, natm, m_b, k_b, P, P, n3, G, n4, P, n4, n5, n1, n7, P, time.perf_counter() - t_all,
+              % (n1, G, natm, m_b, k_b, P, P, n3, G, n4, P, r5, n5, n1, n7, P, time.perf_counter() - t_all,
                  {k: round(v, 1) for k, v in est.items()}))
     return total, sample
 
 
+def cpu_baseline_exact_fftdf(cell, nocc):
+    """The reference's own algorithm for K (pyscf/pbc/df/fft_jk.py:276-287: one FFT pair per (occupied orbital, AO) pair
+    density + the contraction with the AOs), timed on a few pairs with the oracle's FFT and extrapolated to the N*nocc
+    pairs of the workload.  Returns (seconds for one exact get_k of the full workload, description)."""
+    from oracle import pbc_tools as tools
+    rng = np.random.default_rng(1)
+    mesh = np.asarray(cell.mesh)
+    G = int(np.prod(mesh))
+    nao = cell.nao_nr()
+    a = cell.lattice_vectors()
+    coulG = tools.get_coulG(a, mesh)
+    npair, nrow = 16, 256
+    ao_rows = rng.standard_normal((nrow, G))                 # stand-ins for AO values on the grid (timing only)
+    rho = rng.standard_normal((npair, G))
+    t = time.perf_counter()
+    v = tools.ifft(tools.fft(rho, mesh) * coulG, mesh).real   # fft_jk.py:281-284
+    t_fft = (time.perf_counter() - t) / npair
+    t = time.perf_counter()
+    (ao_rows * v[0]).dot(ao_rows.T)                           # fft_jk.py:286: vk += einsum over the grid, one occupied orbital
+    t_dot = (time.perf_counter() - t) * (nao / nrow) ** 2 / nao   # per pair: an (nao x G x nao) product serves nao pairs
+    pairs = nao * nocc
+    total = pairs * (t_fft + t_dot)
+    return total, ('exact FFTDF exchange (fft_jk.py:276-287) extrapolated from %d FFT pairs (%.3f s each) and a %d-row slice of the '
+                   'grid contraction (%.4f s per pair) to N*nocc = %d pairs' % (npair, t_fft, nrow, t_dot, pairs))
+
+
+def spawn_ranks(n):
+    """python bench.py --gpus N with no launcher around it: start the N ranks as a fresh child (torch.distributed.run, one
+    rank per GPU) BEFORE this process touches torch or the GPU, relay its output and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     import torch
     import torch.distributed as dist
     from pyscf_isdf_amd import workloads
@@ -157,6 +206,7 @@ def main():
             dm.append((c * occ).dot(c.conj().T))
         dm = np.array(dm)
         df = ISDF(cell, kpts=kpts, c_isdf=args.c_isdf, select=args.select, comm=comm)
+    df.refine_over = args.refine_over
     if args.fit_route:
         df.fit_route = args.fit_route
     if args.robust_k:
@@ -173,8 +223,14 @@ def main():
         df.build()
         return df.get_jk(dm) if kpts is None else df.get_jk(dm, kpts=kpts)
 
-    for _ in range(args.warmup):
+    cold_first_step = None
+    for i in range(args.warmup):
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        if i == 0:
+            cold_first_step = time.perf_counter() - tc     # allocations, FFT plans, rocBLAS kernel loading: what a one-shot caller pays
     be.prof_reset()
     be.prof_enable(True)
     barrier()
@@ -204,12 +260,14 @@ def main():
         # dominant HAND-WRITTEN kernel (library calls are listed in the stage report, not used for the roofline)
         own = [r for r in rows if not r['kernel'].startswith(('rocblas', 'rocsolver'))]
         dom = own[0] if own else rows[0]
-        # HBM-side bytes per launch of that kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 per the
-        # gfx950 correction + WRITE_SIZE), which cannot run inside this process: read the committed
-        # profile of the same command if it is there (profiles/r01_pmc_bench_cfg3_fetch_write.json).
+        # HBM-side bytes per launch of that kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
+        # correction + WRITE_SIZE, separate passes), which cannot run inside this process: the committed summary of the
+        # same command (PMC_FILE, written by tools/pmc_summarise.py) is used ONLY when it describes this run - same
+        # kernel, same launches per step, average launch duration within 5 % of the live HIP-event figure; else null.
         traffic = None
+        traffic_note = None
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_bench_cfg3_fetch_write.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', PMC_FILE)) as f:
                 pmc = json.load(f)
             # algorithmic bytes of the launches that kernel handles: W batch r reads V (nb x G) and the rows r.. of Y' ((P - r) x G)
             # once and writes nb x (P - r); the 256x128 kernel takes every batch of more than 128 rows (gemm_f64.hip)
@@ -217,22 +275,30 @@ def main():
             nbat = int(getattr(df, '_last_fft_batch', 0) or 512)
             algs = [8.0 * ((min(nbat, Pn - r) + (Pn - r)) * Gn + min(nbat, Pn - r) * (Pn - r))
                     for r in range(0, Pn, nbat) if min(nbat, Pn - r) > 128]
-            for k, v in pmc.items():
-                fetch = v.get('FETCH_SIZE_per_launch', v.get('FETCH_SIZE_KB_per_launch'))     # counter unit: KB
-                write = v.get('WRITE_SIZE_per_launch', v.get('WRITE_SIZE_KB_per_launch'))
-                if k.startswith('gemm_nt_mfma_kernel_b') and fetch is not None and write is not None and v['launches'] > 4 \
-                        and args.workload == 'diamond-444-dzvp-120' and world == 1 and algs:
+            base = dom['kernel'].split('[')[0]
+            v = pmc.get(base)
+            if v is None:
+                traffic_note = 'no entry for %s in profiles/%s' % (base, PMC_FILE)
+            else:
+                fetch, write = v.get('FETCH_SIZE_per_launch'), v.get('WRITE_SIZE_per_launch')     # counter unit: KB
+                per_step = dom['launches'] / max(args.steps, 1)
+                if fetch is None or write is None:
+                    traffic_note = 'profiles/%s lacks FETCH_SIZE or WRITE_SIZE for %s' % (PMC_FILE, base)
+                elif v['launches'] != per_step or abs(v['avg_ms'] - dom['avg_ms']) > 0.05 * dom['avg_ms'] or world != 1 or not algs:
+                    traffic_note = ('profiles/%s is for another run (%d launches of %.1f ms there, %.1f per step of %.1f ms here)'
+                                    % (PMC_FILE, v['launches'], v['avg_ms'], per_step, dom['avg_ms']))
+                else:
                     traffic = dict(bytes_per_launch=round((2 * fetch + write) * 1024),
                                    algorithmic_bytes_per_launch=round(sum(algs) / len(algs)),
-                                   source='profiles/r01_pmc_bench_cfg3_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in '
-                                          'separate passes of this command with ISDF_TRSM=subst, tools/pmc_summarise.py; FETCH x2 per '
-                                          'MI355X_MICROARCH.md; counts fabric requests incl. Infinity-Cache hits)')
-        except (OSError, KeyError, ValueError):
-            pass
+                                   source='profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, '
+                                          'tools/pmc_summarise.py; FETCH x2 per MI355X_MICROARCH.md; counts fabric requests incl. '
+                                          'Infinity-Cache hits)' % PMC_FILE)
+        except (OSError, KeyError, ValueError) as e:
+            traffic_note = 'profiles/%s unusable: %s' % (PMC_FILE, e)
         if dom['unit'] == 'TFLOP/s':
             roof = dict(bound='mfma', kernel=dom['kernel'], achieved=round(dom['achieved'], 2), peak=FP64_MFMA_PEAK_TFLOPS,
                         unit='TFLOP/s', frac=round(dom['achieved'] / FP64_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                        avg_launch_ms=round(dom['avg_ms'], 3), launches=dom['launches'])
+                        avg_launch_ms=round(dom['avg_ms'], 3), launches=dom['launches'], traffic_note=traffic_note)
         else:
             roof = dict(bound='hbm', kernel=dom['kernel'], achieved=round(dom['achieved'], 1), peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=round(dom['achieved'] / HBM_PEAK_GBS, 4), traffic=None, avg_launch_ms=round(dom['avg_ms'], 3),
@@ -257,6 +323,23 @@ def main():
                           'EK': float(np.einsum('kij,kji', vk, dm).real / 4 / len(kpts))}),
             'roofline': roof,
         }
+        out['cold_first_step_s'] = None if cold_first_step is None else round(cold_first_step, 3)
+        out['config']['refine_over'] = args.refine_over if args.select == 'refined' else None
+        # accuracy of the timed configuration against the reference's exact exchange (fft_jk.py:177-302 on the GPU,
+        # isdf_get_k_exact; outside the timed region).  J is the reference's own formula (fft_jk.py:33-109): no fit error.
+        out['config']['dE_K_vs_exact'] = None
+        if world == 1 and kpts is None and not args.no_accuracy and not args.robust_k:
+            ta = time.perf_counter()
+            _, c_mo, occ_mo = workloads.make_dm(cell)
+            vk_ex = df.get_k_exact(mo_coeff=c_mo, mo_occ=occ_mo)
+            ek_ex = float(np.einsum('ij,ji', vk_ex, dm) / 4)
+            out['config']['dE_K_vs_exact'] = float(out['energies']['EK'] - ek_ex)
+            out['accuracy'] = {'E_K_exact': ek_ex, 'dE_K_Eh': out['config']['dE_K_vs_exact'],
+                               'dE_K_Eh_per_atom': out['config']['dE_K_vs_exact'] / cell.natm,
+                               'max_abs_dK': float(abs(vk - vk_ex).max()), 'exact_K_seconds_on_this_gpu': round(time.perf_counter() - ta, 1),
+                               'dE_J_Eh': 0.0, 'note': 'exact = the reference algorithm (N*nocc FFT pairs) on the same GPU and grid; J uses '
+                               'the reference formula itself; north-star tolerance 1e-6 Eh: see DESIGN.md section 2 for the c / selection scan'}
+            del vk_ex
         if os.environ.get('ISDF_ONE_GPU'):
             out['data'] = 'synthetic; REHEARSAL: %d ranks on one GPU over gloo, not a benchmark' % world
         if world == 1 and not args.no_cpu_baseline and kpts is None:
@@ -270,6 +353,9 @@ def main():
             val, sample = cpu_baseline(cell, args.c_isdf, dict(P=P))
             out['cpu_baseline'] = {'value': round(val, 1), 'unit': 's', 'cores': ncores, 'kind': 'port',
                                    'sample': sample + '; host has %d logical CPUs' % (os.cpu_count() or 1)}
+            # second entry: the reference's EXACT algorithm on the same host (what ISDF replaces), extrapolated per FFT pair
+            xv, xs = cpu_baseline_exact_fftdf(cell, cell.nelectron // 2)
+            out['cpu_baseline']['exact_fftdf'] = {'value': round(xv, 1), 'unit': 's per get_k', 'cores': ncores, 'kind': 'port', 'sample': xs}
         else:
             out['cpu_baseline'] = None
         if args.stage_report:

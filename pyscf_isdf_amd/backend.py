@@ -63,6 +63,23 @@ class HipBackend:
     def synchronize(self):
         torch.cuda.synchronize(self.device)
 
+    # ---- streams (overlap of the exchange / FFT pipeline with the MFMA products in the grid-sharded build) ----
+    def new_stream(self):
+        return torch.cuda.Stream(device=self.device)
+
+    def on_stream(self, stream):
+        """Context: library calls, torch ops and torch.distributed collectives inside are ordered on ``stream``."""
+        return torch.cuda.stream(stream)
+
+    def record_event(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def wait_event(self, ev):
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
     def release_workspace(self):
         self.handle.call('isdf_release_workspace')
 

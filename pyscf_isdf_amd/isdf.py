@@ -96,6 +96,12 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         return bool(self.explicit_theta or self.robust_k)
 
     @property
+    def _sharded(self):
+        """The grid-sharded (multi-GPU) code path: more than one rank, or forced for tests (force_sharded; a Comm that
+        issues its collectives even with one rank)."""
+        return self.comm.size > 1 or self.force_sharded or getattr(self.comm, 'always', False)
+
+    @property
     def mesh(self):
         return self.grids.mesh
 
@@ -120,14 +126,28 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         if cell is not None:
             self.cell = cell
         self.grids = UniformGrids(self.cell, self.cell.mesh)
-        self.ao = self.aoP = self.W = self.ip = None
+        self._drop_build_state()
         self._bufs = {}
-        self._ovlp = None
         if self._backend is not None:
             self._backend.empty_cache()
         self._rsh_df = {}
-        self._built = False
         return self
+
+    def _drop_build_state(self):
+        """Forget everything a build produced (views of the persistent buffers included: the 214 GiB fit buffer must not
+        stay referenced from a stale fit state when reset() lets the buffers go).  Called by reset() and at the top of
+        every build path."""
+        self.ao = self.aoP = self.W = self.ip = None
+        self._fit_state = None
+        self._kfit_state = None
+        self._V = None
+        self._Wq = None
+        self._aoP_k = None
+        self._W_omega = {}
+        self._k_built = None
+        self._band_built = None
+        self._ovlp = None
+        self._built = False
 
     def dump_flags(self, verbose=None):
         out = self.stdout
@@ -188,14 +208,13 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
 
     def build(self):
         self.check_sanity()
-        self._W_omega = {}
-        self._V = None
+        self._drop_build_state()
         if self.robust_k:
             if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
                 raise NotImplementedError('robust_k is implemented at the Gamma point')
         if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
             return self._build_kpts()
-        if self.comm.size > 1 or self.force_sharded:
+        if self._sharded:
             return self._build_sharded()
         cell, be = self.cell, self.backend
         self.timings = {}
@@ -327,27 +346,34 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         return self
 
     def _refine_selection(self, perm, blk_off, piv_h, rank, P_target, owner):
-        """select='refined': the per-atom selections (refine_over x too many points each) are only CANDIDATES; one
-        pivoted Cholesky of the pair-density Gram matrix restricted to the candidate set (a single block of the same
-        selection kernels, pivot rule pyscf/lib/scipy_helper.py:71-110) picks the final P_target points.  Leaves the chosen
-        grid indices per atom (in pivot order) in self._refined_by_atom and returns the points per atom."""
+        """select='refined' on one GPU: the per-atom selections (refine_over x too many points each) are only CANDIDATES;
+        see _refine_pick.  Leaves the chosen grid indices per atom (in pivot order) in self._refined_by_atom and returns the
+        points per atom."""
         be = self.backend
         natm = self.cell.natm
         cand = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(natm)]).astype(np.int64)
-        m = len(cand)
-        P_target = min(P_target, m)
-        nao = self.ao.shape[0]
-        aoC = be.empty((m, nao))
+        aoC = be.empty((len(cand), self.ao.shape[0]))
         be.gather_aoP(self.ao, be.to_device(cand), aoC)
+        chosen = self._refine_pick(aoC, cand, P_target)
+        del aoC
+        own = owner[chosen]
+        self._refined_by_atom = [chosen[own == b] for b in range(natm)]
+        return np.array([len(x) for x in self._refined_by_atom], dtype=np.int32)
+
+    def _refine_pick(self, aoC, cand, P_target):
+        """One pivoted Cholesky of the pair-density Gram matrix restricted to the candidate set (aoC: AO values at the
+        candidates, (m, nao); isdf_gram_sq + isdf_select_ip_gram, pivot rule pyscf/lib/scipy_helper.py:71-110) picks the
+        final P_target points.  Returns their grid indices in pivot order."""
+        be = self.backend
+        m = len(cand)
+        P_target = min(int(P_target), m)
         A = be.empty((m, m))
         be.gram_sq(aoC, A)
         piv2 = be.empty((P_target,), dtype=torch.int64)
         r2 = be.select_ip_gram(A, P_target, self.select_tol, self.tie_rtol, piv2)
-        chosen = cand[be.to_host(piv2)[:r2]]
-        del aoC, A, piv2
-        own = owner[chosen]
-        self._refined_by_atom = [chosen[own == b] for b in range(natm)]
-        return np.array([len(x) for x in self._refined_by_atom], dtype=np.int32)
+        chosen = np.asarray(cand)[be.to_host(piv2)[:r2]]
+        del A, piv2
+        return chosen
 
     def _keep_V_for_robust_k(self, t0):
         """robust_k: the fit buffer (Theta) becomes V = conv(Theta), in place (one more pass of batched FFTs)."""
@@ -396,7 +422,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         P, ng = V.shape                                                     # ng = this rank's grid columns (all of them on one GPU)
         nao = self.cell.nao_nr()
         w = self.cell.vol / int(np.prod(self.mesh))
-        sharded = comm.size > 1 or self.force_sharded
+        sharded = self._sharded
         nb = max(1, min(P, int((6 << 30) // (8 * ng))))
         aoPT = self.aoP.T.contiguous()                                      # (N, P)
         for s in range(d_dm.shape[0]):
@@ -528,7 +554,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         d_dm = be.to_device(dms)
         vj = vk = None
         t0 = time.perf_counter()
-        if self.comm.size > 1 or self.force_sharded:
+        if self._sharded:
             return self._get_jk_sharded(d_dm, dm_in.shape, with_j, with_k, exxdiv)
         if with_j:
             d_vj = be.empty((nset, nao, nao))
@@ -576,7 +602,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         if max_rows is None:
             max_rows = max(nocc, int((4 << 30) // (8 * G)) // nocc * nocc)
         vk = be.empty((nao, nao))
-        if self.comm.size > 1 or self.force_sharded:
+        if self._sharded:
             raise NotImplementedError('get_k_exact is a single-GPU verification path')
         be.get_k_exact(self.ao, G, be.to_device(np.ascontiguousarray(c)), mesh, a, 0, nao, max_rows, vk)
         return be.to_host(vk)
@@ -591,7 +617,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
             G = int(np.prod(self.mesh))
             S = be.empty((nao, nao))
             be.gemm_nt(self.ao, self.ao, S, alpha=self.cell.vol / G)
-            if self.comm.size > 1 or self.force_sharded:
+            if self._sharded:
                 self.comm.all_reduce_sum(S)
             self._ovlp = S
         return self._ovlp

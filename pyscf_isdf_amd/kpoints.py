@@ -287,7 +287,7 @@ class KPointMixin:
                         else:                      # stored as its time-reversal partner: W^{-q} = conj(W^q)
                             Wq = torch.conj_physical(Wq_set[self._q_partner[iq]])
                         be.get_k_pair(self._aoP_k[k1], self._aoP_k[k2], d_dm[k2], Wq, 1.0 / nk, d_vk[s, i1])
-            if comm.size > 1:
+            if comm.size > 1 or getattr(comm, 'always', False):
                 flat = torch.view_as_real(d_vk)
                 comm.all_reduce_sum(flat)
             vk = be.to_host(d_vk)
@@ -338,7 +338,7 @@ class KPointMixin:
                 or getattr(self, '_band_built', None) is not None:
             self.kpts = uniq
             self.kpts_band = None
-            self._build_kpts()
+            self.build()                     # through build(): drops the state (range-separated W^q included) of the old k-point set
         iq = self._qindex[idx[0], idx[1]]
         Wq = self._Wq[iq] if iq in self._Wq else torch.conj_physical(self._Wq[self._q_partner[iq]])
         Wq = be.to_host(Wq)

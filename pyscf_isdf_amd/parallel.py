@@ -7,13 +7,21 @@ import torch.distributed as dist
 
 
 class Comm:
-    def __init__(self, rank=0, size=1, local_rank=0, group=None):
+    def __init__(self, rank=0, size=1, local_rank=0, group=None, always=False):
         self.rank, self.size, self.local_rank, self.group = rank, size, local_rank, group
+        # always: issue every collective even with one rank (a process group must be initialised).  Lets a ONE-GPU box
+        # execute the RCCL code paths (tests/nccl_one_rank.py); with more than one rank it changes nothing.
+        self.always = bool(always)
+
+    @property
+    def _live(self):
+        return self.size > 1 or self.always
 
     @classmethod
     def from_env(cls):
         if dist.is_available() and dist.is_initialized():
-            return cls(dist.get_rank(), dist.get_world_size(), int(os.environ.get('LOCAL_RANK', '0')))
+            return cls(dist.get_rank(), dist.get_world_size(), int(os.environ.get('LOCAL_RANK', '0')),
+                       always=bool(os.environ.get('ISDF_COMM_ALWAYS')))
         return cls()
 
     def split_range(self, n, r=None):
@@ -26,10 +34,10 @@ class Comm:
     def _staged(self, t):
         """gloo moves host memory: device tensors are staged through the host (rehearsals of the N > 1 path with
         several ranks on ONE GPU, tools/rehearse_ranks_one_gpu.sh; the production backend is nccl = RCCL)."""
-        return self.size > 1 and t.is_cuda and dist.get_backend(self.group) == 'gloo'
+        return self._live and t.is_cuda and dist.get_backend(self.group) == 'gloo'
 
     def all_reduce_sum(self, t):
-        if self.size > 1:
+        if self._live:
             if self._staged(t):
                 h = t.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -40,7 +48,7 @@ class Comm:
 
     def broadcast(self, t, src=0):
         """Every rank ends with rank src's tensor."""
-        if self.size > 1:
+        if self._live:
             if self._staged(t):
                 h = t.cpu()
                 dist.broadcast(h, src, group=self.group)
@@ -51,7 +59,7 @@ class Comm:
 
     def agree_max(self, x):
         """max over the ranks of a host float: decisions taken on replicated data must not diverge in the last bit."""
-        if self.size == 1:
+        if not self._live:
             return float(x)
         h = torch.tensor([float(x)], dtype=torch.float64)
         if dist.get_backend(self.group) != 'gloo':
@@ -76,7 +84,7 @@ class Comm:
 
     def all_gather_rows(self, t_local, counts):
         """Concatenate row blocks of unequal height (counts[r] rows from rank r)."""
-        if self.size == 1:
+        if not self._live:
             return t_local
         mx = max(counts)
         pad = torch.zeros((mx,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
@@ -92,7 +100,7 @@ class Comm:
         return torch.cat([bufs[r][:counts[r]] for r in range(self.size)], dim=0)
 
     def all_gather_object(self, obj):
-        if self.size == 1:
+        if not self._live:
             return [obj]
         out = [None] * self.size
         dist.all_gather_object(out, obj, group=self.group)
@@ -100,7 +108,7 @@ class Comm:
 
     def all_to_all(self, recv, send):
         """recv[q] <- what rank q put in its send[self.rank]; lists of contiguous tensors."""
-        if self.size == 1:
+        if not self._live:
             recv[0].copy_(send[0])
             return
         send = [s.contiguous() for s in send]
@@ -127,5 +135,5 @@ class Comm:
             dist.all_to_all(recv, send, group=self.group)
 
     def barrier(self):
-        if self.size > 1:
+        if self._live:
             dist.barrier(group=self.group)

@@ -47,8 +47,8 @@ class ShardedMixin:
         Streaming over row batches bounds memory at any rank count.
         """
         cell, be, comm = self.cell, self.backend, self.comm
-        if self.select != 'local':
-            raise NotImplementedError("multi-GPU build needs select='local'")
+        if self.select not in ('local', 'refined'):
+            raise NotImplementedError("multi-GPU build needs select='local' or 'refined'")
         R, rk = comm.size, comm.rank
         self.timings = {}
         t0 = time.perf_counter()
@@ -75,7 +75,10 @@ class ShardedMixin:
         perm = np.argsort(owner, kind='stable').astype(np.int64)
         counts = np.bincount(owner, minlength=cell.natm)
         blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)
-        nip = np.minimum(self.nip_per_atom(), counts).astype(np.int32)
+        nip_final = np.minimum(self.nip_per_atom(), counts).astype(np.int32)
+        nip = nip_final
+        if self.select == 'refined':                      # the per-atom selections are candidates (isdf.ISDF._refine_pick)
+            nip = np.minimum(np.ceil(self.nip_per_atom() * float(self.refine_over)).astype(np.int64), counts).astype(np.int32)
         mine = [b for b in range(cell.natm) if b % R == rk and nip[b] > 0]
         t0 = self._tick('host_partition', t0)
         my_ips = {}
@@ -96,8 +99,20 @@ class ShardedMixin:
         merged = {}
         for d in all_ips:
             merged.update(d)
+        none = np.zeros(0, dtype=np.int64)                 # an atom that owns no grid points / no AOs selects nothing
+        if self.select == 'refined':
+            t0 = self._tick('S2_select_candidates', t0)
+            # phi at the candidates from the slice collocations (zero-padded all_reduce, 8 m N bytes); the pivoted
+            # Cholesky of the candidate Gram matrix runs on rank 0 and its answer is shared: one decision for all ranks
+            cand = np.concatenate([merged.get(b, none) for b in range(cell.natm)]).astype(np.int64)
+            aoC = self._slice_columns(cand, g0, g1).T.contiguous()
+            chosen = comm.run_on_root(lambda: self._refine_pick(aoC, cand, int(nip_final.sum())))
+            chosen = comm.all_gather_object(chosen)[0]
+            del aoC
+            own = owner[chosen]
+            merged = {b: chosen[own == b] for b in range(cell.natm)}
         clusters = self._bj_clusters()
-        self.ip = np.concatenate([merged[b] for cl in clusters for b in cl]).astype(np.int64)
+        self.ip = np.concatenate([merged.get(b, none) for cl in clusters for b in cl]).astype(np.int64)
         P = len(self.ip)
         t0 = self._tick('S2_select_ip', t0)
 
@@ -105,18 +120,11 @@ class ShardedMixin:
         # all_reduce of 8 P N bytes).  Taking them from the SAME evaluation as the fit's right-hand sides keeps
         # B[:, ip] == A_PP to the last bit (a separate collocation differs by the image-screening tolerance, which
         # the fit amplifies by cond(A)).  P x P factorisations replicated, rows of the fit on the slice.
-        aoP_T = be.zeros((nao, P))
-        mine_p = np.nonzero((self.ip >= g0) & (self.ip < g1))[0]
-        if len(mine_p):
-            loc = be.empty((nao, len(mine_p)))
-            be.gather_cols(self.ao, be.to_device(self.ip[mine_p] - g0), loc)
-            aoP_T[:, be.to_device(mine_p)] = loc
-            del loc
-        comm.all_reduce_sum(aoP_T)
+        aoP_T = self._slice_columns(self.ip, g0, g1)
         self.aoP = self._buffer('aoP', (P, nao))
         theta = self._buffer('theta', (P, ng))
         ar = be.to_device(np.arange(P, dtype=np.int64))
-        ip_off = self._bj_blocks([len(merged[b]) for b in range(cell.natm)], clusters)
+        ip_off = self._bj_blocks([len(merged.get(b, none)) for b in range(cell.natm)], clusters)
         for route in self._fit_routes():
             # the P x P factorisations run on rank 0 and are broadcast (2 x 8 P^2 bytes): every rank then holds the
             # same bits, and the shift ladders' decisions cannot diverge between ranks
@@ -164,6 +172,21 @@ class ShardedMixin:
         self._built = True
         return self
 
+    def _slice_columns(self, idx, g0, g1):
+        """phi at the grid points idx, (nao, len(idx)), on every rank: each point lies in exactly one rank's slice
+        [g0, g1) of the collocation self.ao; zero-padded all_reduce of 8 nao len(idx) bytes."""
+        be, comm = self.backend, self.comm
+        idx = np.asarray(idx, dtype=np.int64)
+        out = be.zeros((self.ao.shape[0], len(idx)))
+        mine = np.nonzero((idx >= g0) & (idx < g1))[0]
+        if len(mine):
+            loc = be.empty((self.ao.shape[0], len(mine)))
+            be.gather_cols(self.ao, be.to_device(idx[mine] - g0), loc)
+            out[:, be.to_device(mine)] = loc
+            del loc
+        comm.all_reduce_sum(out)
+        return out
+
     def _finish_W_sharded(self, W):
         """S4 + S5 of the grid-sharded build for the fit held in self._fit_state (rows on this rank's grid slice + the
         replicated factors): two all-to-alls around the row convolution, partial W over the slice, all-reduce, finishing.
@@ -176,39 +199,79 @@ class ShardedMixin:
         mesh = np.asarray(self.mesh, dtype=np.int32)
         G = int(np.prod(mesh))
         a = np.asarray(cell.lattice_vectors(), dtype=float)
-        # S4 + S5 streamed over row batches: rank q convolves rows P_q[t*nb : (t+1)*nb] in step t
+        # S4 + S5 streamed over row batches: rank q convolves rows P_q[t*nb : (t+1)*nb] in step t.  Two streams: the
+        # exchange/FFT pipeline of step t+1 (all-to-all, row assembly, convolution, all-to-all) runs on a side stream
+        # while the MFMA products of step t run on the work stream; every buffer is allocated once (two slots).
         w = cell.vol / G
         W.zero_()
         slices = [comm.split_range(G, r) for r in range(R)]
         rows = [comm.split_range(P, r) for r in range(R)]
         nb = self.fft_batch or _default_fft_batch(G, max(1, P // R))
+        if not self.fft_batch:
+            # two slots of three batch-sized buffers + the FFT's half spectrum and work area, 2 GiB kept back
+            nb = min(nb, int(max(0, be.free_bytes() - (2 << 30)) // (72 * G)))
+        nb = max(1, min(nb, max(hi - lo for lo, hi in rows)))
         nsteps = max(-(-(hi - lo) // nb) for lo, hi in rows)
-        for t in range(nsteps):
+        nslot = min(2, nsteps)
+        pieces = [be.empty((nb * G,)) for _ in range(nslot)]         # per slot: the R exchanged pieces of this rank's batch
+        full = [be.empty((nb, G)) for _ in range(nslot)]             # the batch's rows over the whole grid
+        recvV = [be.empty((R * nb * ng,)) for _ in range(nslot)]     # V[bat_q, S_r] from every rank q
+
+        def batches(t):
             bat = [(min(lo + t * nb, hi), min(lo + (t + 1) * nb, hi)) for lo, hi in rows]   # rows handled by rank q
-            nrow = [hi - lo for lo, hi in bat]
+            return bat, [hi - lo for lo, hi in bat]
+
+        def views(flat, nrow_of, width_of):
+            out, off = [], 0
+            for q in range(R):
+                n = nrow_of(q) * width_of(q)
+                out.append(flat[off:off + n].view(nrow_of(q), width_of(q)))
+                off += n
+            return out
+
+        def exchange_and_convolve(t, slot):
+            bat, nrow = batches(t)
+            mine = nrow[rk]
             # all-to-all 1: send Theta[bat_q, S_r] to q; receive Theta[bat_r, S_q] from q
-            send = [theta[lo:hi] for lo, hi in bat]
-            recv = [be.empty((nrow[rk], s1 - s0)) for s0, s1 in slices]
-            comm.all_to_all(recv, send)
-            full = be.empty((nrow[rk], G))
+            recv = views(pieces[slot], lambda q: mine, lambda q: slices[q][1] - slices[q][0])
+            comm.all_to_all(recv, [theta[lo:hi] for lo, hi in bat])
+            rows_full = full[slot][:mine]
             for (s0, s1), piece in zip(slices, recv):
-                full[:, s0:s1] = piece
-            del recv
-            if nrow[rk]:
-                be.coulomb_rows(full, mesh, a, max(1, nrow[rk]))
+                rows_full[:, s0:s1] = piece
+            if mine:
+                be.coulomb_rows(rows_full, mesh, a, mine)
             # all-to-all 2: send V[bat_r, S_q] to q; receive V[bat_q, S_r] from q
-            send = [full[:, s0:s1].contiguous() for s0, s1 in slices]
-            recv = [be.empty((nrow[q], ng)) for q in range(R)]
-            comm.all_to_all(recv, send)
-            del full, send
+            for (s0, s1), piece in zip(slices, recv):
+                piece.copy_(rows_full[:, s0:s1])
+            got = views(recvV[slot], lambda q: nrow[q], lambda q: ng)
+            comm.all_to_all(got, recv)
+            return bat, nrow, got
+
+        def products(bat, nrow, got):
             for q in range(R):
                 if nrow[q]:
                     # W[bat_q, c0:] = w V[bat_q, S_r] Theta[c0:, S_r]^T  (partial over this rank's slice).
                     # W is symmetric: only the columns from the batch's first row on are computed and
                     # the lower part is mirrored after the all-reduce (half the flops).
                     c0 = bat[q][0]
-                    be.gemm_nt(recv[q], theta[c0:], W[bat[q][0]:bat[q][1], c0:], alpha=w, beta=0.0)
-            del recv
+                    be.gemm_nt(got[q], theta[c0:], W[bat[q][0]:bat[q][1], c0:], alpha=w, beta=0.0)
+
+        side = be.new_stream()
+        ready = be.record_event()                    # the fit rows (and W.zero_) are complete on the work stream
+        staged, consumed = {}, {}
+        for t in range(nsteps + 1):
+            if t < nsteps:
+                with be.on_stream(side):
+                    be.wait_event(ready if t == 0 else None)
+                    be.wait_event(consumed.get(t - nslot))          # the slot's buffers were read by the products of step t - nslot
+                    out = exchange_and_convolve(t, t % nslot)
+                    staged[t] = (out, be.record_event())
+            if t >= 1:
+                out, ev = staged.pop(t - 1)
+                be.wait_event(ev)
+                products(*out)
+                consumed[t - 1] = be.record_event()
+        del staged, consumed, pieces, full, recvV
         comm.all_reduce_sum(W)
         be.symmetrize_upper(W)
         if st['kind'] == 'blockjacobi':

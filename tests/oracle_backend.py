@@ -30,6 +30,19 @@ class OracleBackend:
     def to_host(self, t):
         return t.detach().numpy().copy()
 
+    def new_stream(self):
+        return None
+
+    def on_stream(self, stream):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def record_event(self):
+        return None
+
+    def wait_event(self, ev):
+        pass
+
     def synchronize(self):
         pass
 

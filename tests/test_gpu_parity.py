@@ -837,3 +837,22 @@ def test_block_jacobi_route_end_to_end():
     finally:
         df.backend.set_option('trsm_substitution', 0)
     assert abs(vk2 - vk1).max() < 1e-7 * abs(vk1).max()
+
+
+def test_rccl_code_paths_execute_on_one_gpu():
+    """Every collective of pyscf_isdf_amd/parallel.py on the real backend: a child process initialises
+    torch.distributed with backend "nccl" (RCCL), world_size 1, and runs the grid-sharded build (pipelined list
+    all_to_all around the convolution, all_reduce of W, broadcast of the factors, MAX all_reduce of the route decision,
+    all_gather_object of the point lists) and the q-sharded k-point build with Comm(always=True); results must equal the
+    single-GPU path (tests/nccl_one_rank.py).  world_size > 1 over RCCL is only reachable in the driver's scaling bench."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'nccl_one_rank.py')
+    r = subprocess.run([sys.executable, script, str(port)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'RCCL-ONE-RANK OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -87,3 +87,48 @@ def test_madelung_simple_cubic_textbook_value():
                    basis={'He': [[0, [1.0, 1.0]]]}, mesh=[5] * 3)
     sup = gto.super_cell(fcc, [2, 3, 5], mesh=[5] * 3)
     assert abs(gto.madelung(sup) - gto.madelung(fcc, nk=(2, 3, 5))) < 1e-9
+
+
+def test_reset_drops_every_view_of_the_build_and_rebuilds():
+    """reset() must not leave a stale fit state pointing at the old (214 GiB at headline size) fit buffer; a rebuild after
+    reset gives the same answer."""
+    import cells
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_diamond_prim('gth-szv', (10, 10, 10))
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(0)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    df = ISDF(cell, c_isdf=3, select='local', backend=OracleBackend())
+    df.robust_k = True
+    k0 = df.get_jk(dm, with_j=False)[1]
+    assert df._V is not None and df._bufs
+    df.reset()
+    for name in ('ao', 'aoP', 'W', 'ip', '_fit_state', '_kfit_state', '_V', '_Wq', '_aoP_k', '_k_built', '_band_built'):
+        assert getattr(df, name) is None, name
+    assert df._bufs == {} and df._W_omega == {} and not df._built
+    assert abs(df.get_jk(dm, with_j=False)[1] - k0).max() < 1e-12
+
+
+def test_switching_kpoint_sets_does_not_reuse_range_separated_Wq():
+    """get_ao_eri on a new k-point set rebuilds through build(): the range-separated W^q cached for the OLD set (keyed by
+    omega only) must be gone, so get_jk(omega) on the new set equals a fresh object's."""
+    import cells
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he2_triclinic()
+    cell.mesh = np.array([9, 9, 9])
+    nao = cell.nao_nr()
+    kA = cell.make_kpts([2, 1, 1])
+    kB = np.array([[0.11, 0.07, -0.05]])
+    rng = np.random.default_rng(4)
+    dA = rng.standard_normal((2, nao, nao)); dA = dA + dA.transpose(0, 2, 1)
+    dB = rng.standard_normal((1, nao, nao)); dB = dB + dB.transpose(0, 2, 1)
+    df = ISDF(cell, kpts=kA, c_isdf=6, select='global', backend=OracleBackend())
+    df.get_jk(dA, kpts=kA, omega=0.5)
+    assert list(df._W_omega) == [0.5]
+    df.get_ao_eri(kB)
+    assert df._W_omega == {} and df._k_built.shape == (1, 3)
+    vk = df.get_jk(dB, kpts=kB, omega=0.5, with_j=False)[1]
+    fresh = ISDF(cell, kpts=kB, c_isdf=6, select='global', backend=OracleBackend())
+    assert abs(vk - fresh.get_jk(dB, kpts=kB, omega=0.5, with_j=False)[1]).max() < 1e-12
