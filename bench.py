@@ -325,6 +325,7 @@ def main():
         }
         out['cold_first_step_s'] = None if cold_first_step is None else round(cold_first_step, 3)
         out['config']['refine_over'] = args.refine_over if args.select == 'refined' else None
+        out['config']['fit_row_panels'] = int(getattr(df, 'n_panels', 1))
         # accuracy of the timed configuration against the reference's exact exchange (fft_jk.py:177-302 on the GPU,
         # isdf_get_k_exact; outside the timed region).  J is the reference's own formula (fft_jk.py:33-109): no fit error.
         out['config']['dE_K_vs_exact'] = None

@@ -53,8 +53,8 @@ int64_t isdf_workspace_bytes(isdf_handle h);
 int isdf_release_workspace(isdf_handle h);
 /* Runtime switches.  "trsm_substitution": 0 (default) the fit's triangular solves with Cholesky factors go through rocBLAS
  * dtrsm, 1 through the substitution blocks of trsm.hip (plain forward/backward substitution on 64-row diagonal blocks +
- * dgemm updates: slower, no inverted diagonal blocks; also the way to profile with rocprofv3 --pmc, which crashes inside
- * rocBLAS's trsm on the 1.7M-column right-hand sides).  Unknown keys are an error. */
+ * dgemm updates: slower, no inverted diagonal blocks; an independent cross-check of rocBLAS's algorithm).  Unknown keys are
+ * an error. */
 int isdf_set_option(isdf_handle h, const char* key, int value);
 /* Range separation of the Gamma-point Coulomb kernel used by isdf_coulomb_W / _rows / _potential / isdf_get_j, as
  * pyscf/pbc/tools/pbc.py:408-418: omega > 0 long range (erf(omega r)/r), omega < 0 short range, 0 (default) plain 1/r.
@@ -208,6 +208,15 @@ int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel, doubl
  * independent: the grid-sharded build gives every rank n = P/R columns of the P x P finishing solves. */
 int isdf_factor_solve(isdf_handle h, const double* d_fac, int P, double* d_X, int64_t n, int64_t ldx);
 
+/* The two halves of isdf_bj_probe_rows, for builds that hold only a panel of the fit rows at a time:
+ * isdf_bj_probe_vectors: d_T (n, P) rows t_j -> e_j = A'^-1 D^-1 t_j in place;
+ * isdf_rows_combine: d_F (n, ng) (+)= d_E (n, rows; leading dimension ldE) d_Y (rows, ng) - for n <= 8 one streaming pass
+ * over Y (HBM-bound), accumulate != 0 adds to F. */
+int isdf_bj_probe_vectors(isdf_handle h, double* d_T, int n, const double* d_fac, const double* d_D, int P,
+                          int nblk, const int32_t* blk_off);
+int isdf_rows_combine(isdf_handle h, const double* d_E, int n, int64_t ldE, int rows, const double* d_Y,
+                      int64_t ng, int64_t ldy, double* d_F, int64_t ldf, int accumulate);
+
 /* A-posteriori check of the block-Jacobi route (it amplifies rounding in M' by cond(A')):
  * for probe vectors t_j (rows of d_T, values of a density at the points) the fitted density Theta^T t_j on ng grid
  * columns,   d_T (n, P) <- e_j = A'^-1 D^-1 t_j  (in place),   d_F (n, ldf) <- E Y'.
@@ -280,6 +289,15 @@ int isdf_get_k_exact(isdf_handle h, const double* d_ao, int nao, int64_t ngrids,
 int isdf_get_k(isdf_handle h, const double* d_aoP, int P, int nao,
                const double* d_W, int64_t ldw, int row0, int nrows,
                const double* d_dm, int nset, double* d_vk);
+
+/* Coulomb kernel table for a difference vector q (Cartesian, 1/Bohr) on the full FFT mesh, fftfreq C order, G doubles:
+ * 4 pi / |q + G|^2 with the reference's treatment of components beyond / on the mesh edge for q != 0 (wrap-around,
+ * pyscf/pbc/tools/pbc.py:272-302, zeroed edge entries :400-401; wrap_around = 0 switches both off), |q + G| = 0 -> 0
+ * (:352-356), range separation omega as :408-418 (0: plain).  Replaces tools.get_coulG(cell, k, exx=None) of the reference
+ * as fft_jk.py:276 calls it; the table feeds isdf_coulomb_Wq.  Fails with ISDF_ERR_ARG when q lies outside the first FFT
+ * box (the reference's assertion, pbc.py:281). */
+int isdf_coulG_q(isdf_handle h, const int32_t mesh[3], const double a[9], const double q[3], int wrap_around,
+                 double omega, double* d_out);
 
 /* ---- k-points (BASELINE configs[3]); conventions of pyscf/pbc/df/fft_jk.py:177-302 ------------------
  * Bloch AOs are carried as lattice-periodic parts in two real planes (isdf_eval_ao_k, periodic_part=1);

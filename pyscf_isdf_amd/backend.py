@@ -110,7 +110,7 @@ class HipBackend:
     @staticmethod
     def _p(t):
         assert t.is_contiguous() or t.stride(-1) == 1
-        return _vp(t.data_ptr())
+        return _vp(t.data_ptr())          # data_ptr() of a view already points at its first element
 
     # ---- stages -------------------------------------------------------------------------------
     def eval_ao(self, atm, bas, env, Ls, rcut, coords_soa, ao):
@@ -199,7 +199,8 @@ class HipBackend:
         self._stream()
         blk_off = np.ascontiguousarray(blk_off, dtype=np.int32)
         n = X.shape[1] if side == 0 else X.shape[0]
-        self.handle.call('isdf_block_solve', self._p(D), D.shape[0], len(blk_off) - 1, _np_ptr(blk_off), int(side), int(trans),
+        # D may be the (r0:r1, r0:r1) view of the full block factor: its leading dimension is what the library needs
+        self.handle.call('isdf_block_solve', self._p(D), D.stride(0), len(blk_off) - 1, _np_ptr(blk_off), int(side), int(trans),
                          self._p(X), int(n), X.stride(0))
 
     def shift_diag(self, A, shift_rel):
@@ -225,6 +226,21 @@ class HipBackend:
         blk_off = np.ascontiguousarray(blk_off, dtype=np.int32)
         self.handle.call('isdf_bj_probe_rows', self._p(T), T.shape[0], self._p(fac), self._p(D), D.shape[0],
                          len(blk_off) - 1, _np_ptr(blk_off), self._p(Yp), int(ng), Yp.stride(0), self._p(F), F.stride(0))
+
+    def bj_probe_vectors(self, T, fac, D, blk_off):
+        """T (n, P) <- rows (A'^-1 D^-1 t_j)^T in place."""
+        self._stream()
+        blk_off = np.ascontiguousarray(blk_off, dtype=np.int32)
+        assert T.is_contiguous()
+        self.handle.call('isdf_bj_probe_vectors', self._p(T), T.shape[0], self._p(fac), self._p(D), D.shape[0],
+                         len(blk_off) - 1, _np_ptr(blk_off))
+
+    def rows_combine(self, E, Y, F, accumulate=False):
+        """F (n, ng) (+)= E (n, rows) Y (rows, ng); E may be a column slice of a wider matrix."""
+        self._stream()
+        assert E.stride(1) == 1 and Y.stride(1) == 1 and F.stride(1) == 1 and E.shape[1] == Y.shape[0]
+        self.handle.call('isdf_rows_combine', self._p(E), E.shape[0], E.stride(0), E.shape[1], self._p(Y), Y.shape[1],
+                         Y.stride(0), self._p(F), F.stride(0), int(bool(accumulate)))
 
     def gather_T(self, L, k, piv, T):
         self._stream()
@@ -363,6 +379,18 @@ class HipBackend:
         self._stream()
         self.handle.call('isdf_fit_apply_cplx', self._p(chol), self._p(aoP), aoP.shape[0], aoP.shape[1], int(nh),
                          self._p(X), int(ng), X.stride(0), int(bool(forward_only)), self._p(theta), theta.stride(0))
+
+    def coulG_q(self, mesh, a, q, omega=None, wrap_around=True, out=None):
+        """Device table (G,) of the Coulomb kernel for the difference vector q (include/mi355_isdf.h isdf_coulG_q)."""
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(3)
+        if out is None:
+            out = self.empty((int(np.prod(mesh)),))
+        self.handle.call('isdf_coulG_q', _np_ptr(mesh), _np_ptr(a), _np_ptr(q), int(bool(wrap_around)), float(omega or 0.0),
+                         self._p(out))
+        return out
 
     def coulomb_Wq(self, theta, mesh, coulG, weight, row0, nrows, batch, Wre, Wim, upper_only=False):
         self._stream()

@@ -53,6 +53,43 @@ __global__ void coulG_half_kernel(double* __restrict__ out, int n0, int n1, int 
   out[idx] = scale * 0.5 * (c1 + c2);
 }
 
+// Full-spectrum kernel table for a difference vector q (k-point exchange, pyscf/pbc/tools/pbc.py:230-420 with exxdiv=None),
+// worked out in INDEX space: with q = sum_i qf_i b_i and the mesh frequency f_i, the component of q + G along b_i in units of
+// the mesh edge (n_i//2 + 1/2) b_i is x_i = (f_i + qf_i) / (n_i//2 + 1/2).  Components with |x_i| >= 1 (to 9 decimals, the
+// reference's rounding) lie beyond the edge and are wrapped back by 2 (n_i//2) + 1 frequencies (pbc.py:272-302); a component
+// exactly ON the edge (|x_i| = 1) is ambiguous and its table entry is zeroed (pbc.py:400-401).
+__global__ void coulG_q_kernel(double* __restrict__ out, int n0, int n1, int n2, Recip r, double qf0, double qf1,
+                               double qf2, int wrap, double omega) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tot = (int64_t)n0 * n1 * n2;
+  if (idx >= tot) return;
+  const int iz = (int)(idx % n2);
+  const int iy = (int)((idx / n2) % n1);
+  const int ix = (int)(idx / ((int64_t)n2 * n1));
+  const int n[3] = {n0, n1, n2};
+  const int id[3] = {ix, iy, iz};
+  const double qf[3] = {qf0, qf1, qf2};
+  double c[3];
+  bool edge = false;
+  for (int d = 0; d < 3; ++d) {
+    double f = (id[d] < (n[d] + 1) / 2) ? id[d] : id[d] - n[d];
+    if (wrap) {
+      const int half = n[d] / 2;
+      const double x9 = rint((f + qf[d]) / (half + 0.5) * 1e9);   // numpy.round(x, 9) * 1e9
+      if (x9 >= 1e9) f -= 2 * half + 1;
+      else if (x9 <= -1e9) f += 2 * half + 1;
+      edge = edge || x9 == 1e9 || x9 == -1e9;
+    }
+    c[d] = f + qf[d];
+  }
+  const double gx = c[0] * r.b[0] + c[1] * r.b[3] + c[2] * r.b[6];
+  const double gy = c[0] * r.b[1] + c[1] * r.b[4] + c[2] * r.b[7];
+  const double gz = c[0] * r.b[2] + c[1] * r.b[5] + c[2] * r.b[8];
+  const double g2 = gx * gx + gy * gy + gz * gz;
+  double v = (g2 == 0.0 || edge) ? 0.0 : 4.0 * 3.14159265358979323846 / g2 * range_factor(g2, omega);
+  out[idx] = v;
+}
+
 __global__ void mul_half_kernel(double2* __restrict__ z, const double* __restrict__ cg, int64_t gc,
                                 int64_t total) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,6 +127,44 @@ static int get_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9
                      mesh[1], mesh[2], rr, extra_scale / (double)G, h->coul_omega);
   KERNEL_CHECK(h);
   *out = cg;
+  return ISDF_OK;
+}
+
+static int reciprocal_rows(isdf_handle h, const double a[9], Recip* rr) {
+  // b = 2 pi inv(a^T): rows b_i (pyscf/pbc/gto/cell.py:1571-1591)
+  const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) +
+                     a[2] * (a[3] * a[7] - a[4] * a[6]);
+  if (det == 0.0) return isdf_fail(h, ISDF_ERR_ARG, "singular lattice");
+  const double tp = 2.0 * 3.14159265358979323846 / det;
+  const double b[9] = {tp * (a[4] * a[8] - a[5] * a[7]), tp * (a[5] * a[6] - a[3] * a[8]), tp * (a[3] * a[7] - a[4] * a[6]),
+                       tp * (a[7] * a[2] - a[8] * a[1]), tp * (a[8] * a[0] - a[6] * a[2]), tp * (a[6] * a[1] - a[7] * a[0]),
+                       tp * (a[1] * a[5] - a[2] * a[4]), tp * (a[2] * a[3] - a[0] * a[5]), tp * (a[0] * a[4] - a[1] * a[3])};
+  for (int i = 0; i < 9; ++i) rr->b[i] = b[i];
+  return ISDF_OK;
+}
+
+extern "C" int isdf_coulG_q(isdf_handle h, const int32_t mesh[3], const double a[9], const double q[3], int wrap_around,
+                            double omega, double* d_out) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, mesh && a && q && d_out && mesh[0] > 0 && mesh[1] > 0 && mesh[2] > 0);
+  Recip rr;
+  int rc = reciprocal_rows(h, a, &rr);
+  if (rc) return rc;
+  // q in units of the reciprocal vectors: q = qf b  ->  qf = q a^T / 2 pi
+  double qf[3];
+  for (int i = 0; i < 3; ++i)
+    qf[i] = (q[0] * a[3 * i] + q[1] * a[3 * i + 1] + q[2] * a[3 * i + 2]) / (2.0 * 3.14159265358979323846);
+  const bool nonzero = fabs(q[0]) + fabs(q[1]) + fabs(q[2]) > 1e-9;     // the reference wraps only for q != 0 (pbc.py:272)
+  const int wrap = (wrap_around && nonzero) ? 1 : 0;
+  if (wrap)
+    for (int i = 0; i < 3; ++i)
+      if (fabs(rint(qf[i] / (mesh[i] / 2 + 0.5) * 1e9)) >= 1e9)
+        return isdf_fail(h, ISDF_ERR_ARG, "isdf_coulG_q: q lies outside the first FFT box (pyscf/pbc/tools/pbc.py:281)");
+  if (!nonzero) qf[0] = qf[1] = qf[2] = 0.0;
+  const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  hipLaunchKernelGGL(coulG_q_kernel, dim3((unsigned)cdiv(G, 256)), dim3(256), 0, h->stream, d_out, mesh[0], mesh[1],
+                     mesh[2], rr, qf[0], qf[1], qf[2], wrap, omega);
+  KERNEL_CHECK(h);
   return ISDF_OK;
 }
 

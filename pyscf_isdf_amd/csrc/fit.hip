@@ -315,9 +315,9 @@ __global__ void copy_block_kernel(const double* __restrict__ A, int P, int off, 
 // F (n <= 8 rows, ng) = E (n, P) * Y (P, ng): one grid column per lane, the P-long dot products streamed row by row
 // (every load of a wave is one coalesced 512-byte row segment); E staged through LDS in 64-row pieces.  HBM-bound:
 // reads Y once.  (rocBLAS dgemm with M = 8 moves the same bytes at under 1 TB/s.)
-__global__ __launch_bounds__(256) void skinny_rows_kernel(const double* __restrict__ E, int n, int P,
+__global__ __launch_bounds__(256) void skinny_rows_kernel(const double* __restrict__ E, int n, int P, int64_t ldE,
                                                           const double* __restrict__ Y, int64_t ldy, int64_t ng,
-                                                          double* __restrict__ F, int64_t ldf) {
+                                                          double* __restrict__ F, int64_t ldf, int accumulate) {
   __shared__ double sE[8][64];
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = g < ng;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void skinny_rows_kernel(const double* __restri
     __syncthreads();
     for (int t = threadIdx.x; t < 8 * 64; t += 256) {
       const int j = t >> 6, pp = t & 63;
-      sE[j][pp] = (j < n && pp < np) ? E[(int64_t)j * P + p0 + pp] : 0.0;
+      sE[j][pp] = (j < n && pp < np) ? E[(int64_t)j * ldE + p0 + pp] : 0.0;
     }
     __syncthreads();
     if (live) {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void skinny_rows_kernel(const double* __restri
     }
   }
   if (live)
-    for (int j = 0; j < n; ++j) F[(int64_t)j * ldf + g] = acc[j];
+    for (int j = 0; j < n; ++j) F[(int64_t)j * ldf + g] = accumulate ? F[(int64_t)j * ldf + g] + acc[j] : acc[j];
 }
 
 __global__ void add_diag_const_kernel(double* __restrict__ A, int n, int64_t ld, double v) {
@@ -404,7 +404,7 @@ extern "C" int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nbl
   ARG_CHECK(h, n < 2147483647LL && ldx < 2147483647LL);
   if (side == 0 && trans == 0 && !h->trsm_substitution) {
     // the hot one (Y' = D^-1 B over the whole grid): all blocks in one launch of the hand-written kernel
-    ARG_CHECK(h, blk_off[0] == 0 && blk_off[nblk] == P);
+    ARG_CHECK(h, blk_off[0] == 0 && blk_off[nblk] <= P);
     return block_forward_solve(h, d_D, P, nblk, blk_off, d_X, ldx, n);
   }
   for (int b = 0; b < nblk; ++b) {
@@ -478,25 +478,41 @@ extern "C" int isdf_factor_solve(isdf_handle h, const double* d_fac, int P, doub
   return tri_left(h, true, P, n, d_fac, P, d_X, ldx);
 }
 
+extern "C" int isdf_bj_probe_vectors(isdf_handle h, double* d_T, int n, const double* d_fac, const double* d_D, int P,
+                                     int nblk, const int32_t* blk_off) {
+  // T (n, P) rows t_j  ->  e_j = A'^-1 D^-1 t_j (in place)
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_T && d_fac && d_D && n > 0 && P > 0);
+  int rc = isdf_block_solve(h, d_D, P, nblk, blk_off, 1, 1, d_T, n, P);      // t^T D^-T = (D^-1 t)^T
+  if (rc) return rc;
+  // rows t^T <- t^T A'^-1 = t^T L^-T L^-1  (A' = L L^T symmetric)
+  rc = tri_right(h, true, P, n, d_fac, P, d_T, P);
+  if (rc) return rc;
+  return tri_right(h, false, P, n, d_fac, P, d_T, P);
+}
+
+extern "C" int isdf_rows_combine(isdf_handle h, const double* d_E, int n, int64_t ldE, int rows, const double* d_Y,
+                                 int64_t ng, int64_t ldy, double* d_F, int64_t ldf, int accumulate) {
+  // F (n, ng) (+)= E (n, rows; leading dimension ldE) Y (rows, ng): a few combinations of many long rows, one pass over Y
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_E && d_Y && d_F && n > 0 && rows > 0 && ng > 0 && ldE >= rows && ldy >= ng && ldf >= ng);
+  if (n > 8) return gemm_rm(h, 'N', 'N', n, ng, rows, 1.0, d_E, ldE, d_Y, ldy, accumulate ? 1.0 : 0.0, d_F, ldf);
+  ProfScope ps(h, "skinny_rows_kernel[byte]", 8.0 * (double)rows * (double)ng);
+  hipLaunchKernelGGL(skinny_rows_kernel, dim3((unsigned)cdiv(ng, 256)), dim3(256), 0, h->stream, d_E, n, rows, ldE, d_Y, ldy,
+                     ng, d_F, ldf, accumulate ? 1 : 0);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
 extern "C" int isdf_bj_probe_rows(isdf_handle h, double* d_T, int n, const double* d_fac, const double* d_D, int P,
                                   int nblk, const int32_t* blk_off, const double* d_Yp, int64_t ng, int64_t ldy,
                                   double* d_F, int64_t ldf) {
   // T (n, P) rows t_j  ->  e_j = A'^-1 D^-1 t_j (in place),  F (n, ng) = E Y' = (Theta^T t_j) on the grid columns
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_T && d_fac && d_D && d_Yp && d_F && n > 0 && P > 0 && ng > 0 && ldy >= ng && ldf >= ng);
-  int rc = isdf_block_solve(h, d_D, P, nblk, blk_off, 1, 1, d_T, n, P);      // t^T D^-T = (D^-1 t)^T
+  int rc = isdf_bj_probe_vectors(h, d_T, n, d_fac, d_D, P, nblk, blk_off);
   if (rc) return rc;
-  // rows t^T <- t^T A'^-1 = t^T L^-T L^-1  (A' = L L^T symmetric)
-  rc = tri_right(h, true, P, n, d_fac, P, d_T, P);
-  if (rc) return rc;
-  rc = tri_right(h, false, P, n, d_fac, P, d_T, P);
-  if (rc) return rc;
-  if (n > 8) return gemm_rm(h, 'N', 'N', n, ng, P, 1.0, d_T, P, d_Yp, ldy, 0.0, d_F, ldf);
-  ProfScope ps(h, "skinny_rows_kernel[byte]", 8.0 * (double)P * (double)ng);
-  hipLaunchKernelGGL(skinny_rows_kernel, dim3((unsigned)cdiv(ng, 256)), dim3(256), 0, h->stream, d_T, n, P, d_Yp, ldy, ng, d_F,
-                     ldf);
-  KERNEL_CHECK(h);
-  return ISDF_OK;
+  return isdf_rows_combine(h, d_T, n, P, P, d_Yp, ng, ldy, d_F, ldf, 0);
 }
 
 extern "C" int isdf_gather_aoP(isdf_handle h, const double* d_ao, int nao, int64_t ld, const int64_t* d_ip, int P,

@@ -9,8 +9,10 @@
 // read through the scalar cache, and everything off the diagonal is rocBLAS dgemm; right-sided solves are left-sided ones
 // on the transpose.  Measured: the two give the same K to the noise level of the block-Jacobi route on every case tried
 // (He2 test cell, diamond 2x2x2 / 4x4x4), rocBLAS is faster (12.4 s against 12.8 s per step at 4x4x4; many small launches
-// here), so rocBLAS stays the default; this path is what rocprofv3 --pmc runs use (the profiler crashes inside rocBLAS's
-// trsm on 1.7M-column right-hand sides) and a cross-check that does not share rocBLAS's algorithm.
+// here), so rocBLAS stays the default; this path is a cross-check that does not share rocBLAS's algorithm.  (Round 1 ran its
+// rocprofv3 --pmc passes through it after a profiler crash attributed to rocBLAS's trsm on 1.7M-column right-hand sides; the
+// isolated call with those arguments profiles cleanly - profiles/r02_trsm_under_pmc_repro.log - and the default fit route
+// never calls dtrsm over the grid, so PMC passes of the default command need no switch.)
 #include "common.h"
 #include <cstdlib>
 

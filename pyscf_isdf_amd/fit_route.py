@@ -30,6 +30,104 @@ class FitRouteMixin:
         be.pair_gram_rows(aoP, ao, ng, out, nh)
         be.block_solve(Dblk, ip_off, 0, 0, out)
 
+    # ---- paneled S3c/S4/S5: more fit rows than HBM holds at once -------------------------------------------------
+    def _resident_rows(self, G, P):
+        """(rows_single, rows_panel): how many (G-long) fit rows can stay resident next to what a build of P points still has
+        to allocate - W, the factor of A' and the block factors (3 x 8 P^2 bytes), FFT batches with their half spectra and
+        work areas (24 G bytes per row of the batch), the GEMM's slab buffers.  rows_single assumes the smallest FFT batch
+        the single-pass build would settle for (128 rows); rows_panel the paneled build's 512-row batches plus its
+        recompute scratch.  ``max_resident_rows`` overrides both (tests, experiments)."""
+        if self.max_resident_rows:
+            return int(self.max_resident_rows), int(self.max_resident_rows)
+        be = self.backend
+        have = be.free_bytes() + sum(int(b.numel()) * 8 for k, b in self._bufs.items() if k in ('theta', 'W', 'factor', 'Dblk', 'rows_scratch'))
+        fixed = 3 * 8 * P * P + (3 << 30)
+        single = (have - fixed - 24 * 128 * G) // (8 * G)
+        panel = (have - fixed - 40 * 512 * G) // (8 * G)
+        return max(0, int(single)), max(0, int(panel))
+
+    def _panel_plan(self, ip_off, nrows_max):
+        """Split the point blocks (offsets ip_off) into consecutive panels of at most nrows_max rows, as equal as the
+        block boundaries allow.  Returns [(r0, r1), ...]."""
+        ip_off = np.asarray(ip_off, dtype=np.int64)
+        P = int(ip_off[-1])
+        big = int(np.diff(ip_off).max())
+        if nrows_max < big:
+            raise MemoryError('ISDF: not enough device memory for one block of %d fit rows' % big)
+        npan = max(1, -(-P // int(nrows_max)))
+        while True:
+            # cut at the block boundaries nearest to k P / npan
+            cuts = sorted({int(ip_off[np.abs(ip_off - k * P / npan).argmin()]) for k in range(1, npan)} | {0, P})
+            panels = [(x, y) for x, y in zip(cuts[:-1], cuts[1:]) if y > x]
+            if all(y - x <= nrows_max for x, y in panels):
+                return panels
+            npan += 1
+
+    def _bj_rows_range(self, r0, r1, out):
+        """out (r1 - r0, G) <- rows r0:r1 of Y' = D^-1 (aoP ao)^2 (r0, r1 on block boundaries): pair-gram rows of those
+        points, forward solves with their own diagonal blocks only."""
+        be, st = self.backend, self._fit_state
+        ip_off = np.asarray(st['ip_off'])
+        i0, i1 = int(np.searchsorted(ip_off, r0)), int(np.searchsorted(ip_off, r1))
+        assert ip_off[i0] == r0 and ip_off[i1] == r1
+        G = self.ao.shape[1]
+        be.pair_gram_rows(self.aoP[r0:r1], self.ao, G, out, 0)
+        be.block_solve(st['Dblk'][r0:r1, r0:r1], (ip_off[i0:i1 + 1] - r0).astype(np.int32), 0, 0, out)
+
+    def _finish_W_paneled(self, W, probe=None):
+        """S3c + S4 + S5 when the P fit rows do not fit into HBM together (c_isdf above ~10 at configs[2] on one GPU).
+        The rows are produced panel by panel into ONE resident buffer; M' = w conv(Y') Y'^T is assembled from
+          * the diagonal panel blocks (resident rows against themselves, upper half: isdf_coulomb_W), and
+          * the blocks above the diagonal: the rows of every EARLIER panel are recomputed in FFT-batch-sized pieces
+            (pair-gram rows + their own block solves, 2 N G flop per row against 2 P G for the product), convolved and
+            multiplied with the resident panel (isdf_coulomb_rows + isdf_gemm_nt).
+        With R panels the row stage runs (R + 1) / 2 times and the convolutions likewise; the P^2 G product is done once.
+        probe: (E (n, P), F (n, G)) - the route check's combination rows; F <- E Y' is accumulated on the way."""
+        be, st = self.backend, self._fit_state
+        cell = self.cell
+        P = W.shape[0]
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        w = cell.vol / G
+        ip_off = np.asarray(st['ip_off'], dtype=np.int64)
+        panels = st['panels']
+        buf = st['rows']                                        # (largest panel, G)
+        nbat = int(self.fft_batch or 512)
+        big = int(np.diff(ip_off).max())
+        self._last_fft_batch = nbat
+        # recomputed rows arrive block by block (a block's solve needs all of its rows) but leave in batches of exactly nbat
+        # rows - one FFT plan, full GEMM tiles: the scratch holds a batch plus the block that overshoots it
+        scratch = self._buffer('rows_scratch', (nbat + big, G))
+        for q, (q0, q1) in enumerate(panels):
+            Yq = buf[:q1 - q0]
+            self._bj_rows_range(q0, q1, Yq)
+            be.coulomb_W(Yq, mesh, a, 0, q1 - q0, min(nbat, q1 - q0), W[q0:q1, q0:q1], upper_only=True)
+            if probe is not None:
+                be.rows_combine(probe[0][:, q0:q1], Yq, probe[1], accumulate=q > 0)
+            for p0, p1 in panels[:q]:
+                nxt, fill, g0 = p0, 0, p0              # next row to recompute, rows waiting in the scratch, their first index
+                while nxt < p1 or fill > 0:
+                    while fill < nbat and nxt < p1:
+                        i = int(np.searchsorted(ip_off, nxt))
+                        j = i + 1
+                        while j + 1 < len(ip_off) and ip_off[j + 1] <= p1 and fill + (ip_off[j + 1] - nxt) <= nbat + big:
+                            j += 1
+                        b1 = int(ip_off[j])
+                        self._bj_rows_range(nxt, b1, scratch[fill:fill + (b1 - nxt)])
+                        fill += b1 - nxt
+                        nxt = b1
+                    take = min(nbat, fill)
+                    V = scratch[:take]
+                    be.coulomb_rows(V, mesh, a, take)
+                    be.gemm_nt(V, Yq, W[g0:g0 + take, q0:q1], alpha=w)
+                    if fill > take:
+                        scratch[:fill - take].copy_(scratch[take:fill].clone() if fill - take > take else scratch[take:fill])
+                    g0 += take
+                    fill -= take
+        be.symmetrize_upper(W)
+        self._bj_finish(st['Afac'], st['Dblk'], st['ip_off'], W)
+
     def _bj_finish(self, Afac, Dblk, ip_off, W, antisymmetric=False):
         """W <- D^-T [A'^-1 W A'^-1] D^-1 (W holds M' on entry)."""
         be = self.backend
@@ -92,22 +190,12 @@ class FitRouteMixin:
             return ['cholesky']
         return ['blockjacobi', 'cholesky']
 
-    def _bj_probe_mismatch(self, aoT_P, Afac, Dblk, ip_off, Yp, ng, grid_slice, W=None):
-        """A-posteriori check of the S3c route: for random symmetric R_j the density t_j = diag(phi_P R_j phi_P^T)
-        at the points has the Coulomb energy  t^T W t  through the matrix and  w sum_g f conv(f), f = Theta^T t,
-        through the fitted density itself (vector operations only: one pass over Y', nprobe FFTs).  The second form
-        does not see the cond(A')-amplified rounding of M'; their largest relative difference is returned.
-        aoT_P: (nao, P), or a list of such planes whose densities are added (k-points: Re/Im u^k at the points, the
-        density sum_k u^k* R u^k with real symmetric R; W = the real plane of W^{q=0})."""
-        be, comm = self.backend, self.comm
-        cell = self.cell
+    def _bj_probe_densities(self, aoT_P):
+        """t_j = diag(phi_P R_j phi_P^T) at the points for the fixed random symmetric probe matrices R_j: (n, P)."""
+        be = self.backend
         planes = aoT_P if isinstance(aoT_P, (list, tuple)) else [aoT_P]
         nao, P = planes[0].shape
-        W = self.W if W is None else W
         n = int(self.bj_nprobe)
-        mesh = np.asarray(self.mesh, dtype=np.int32)
-        G = int(np.prod(mesh))
-        a = np.asarray(cell.lattice_vectors(), dtype=float)
         # the probe matrices R_j (random symmetric, fixed seed) are kept on the device: drawing n nao^2 normals
         # costs 0.2 s at nao = 1664
         cached = getattr(self, '_probe_R', None)
@@ -121,15 +209,28 @@ class FitRouteMixin:
         for pl in planes:
             be.rho(pl, P, d_R, tmp)
             T += tmp
-        del tmp
+        return T
+
+    def _bj_probe_vectors(self, aoT_P, Afac, Dblk, ip_off):
+        """(T0, E): the probe densities at the points and their combination rows e_j = A'^-1 D^-1 t_j, so that the fitted
+        density of probe j is f_j = Theta^T t_j = Y'^T e_j (paneled builds accumulate F = E Y' panel by panel)."""
+        T = self._bj_probe_densities(aoT_P)
         T0 = T.clone()
-        # matrix side: t^T W t
-        TW = be.empty((n, P))
+        self.backend.bj_probe_vectors(T, Afac, Dblk, ip_off)
+        return T0, T
+
+    def _bj_probe_energies(self, T0, F, W, grid_slice):
+        """Largest relative mismatch between t^T W t (through the matrix) and w sum_g f conv(f) (through the fitted density
+        itself, F (n, columns of this rank))."""
+        be, comm = self.backend, self.comm
+        cell = self.cell
+        n = T0.shape[0]
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        TW = be.empty(tuple(T0.shape))
         be.gemm_nt(T0, W, TW)
         e_mat = np.einsum('jp,jp->j', be.to_host(TW), be.to_host(T0))
-        # density side
-        F = be.empty((n, ng))
-        be.bj_probe_rows(T, Afac, Dblk, ip_off, Yp, ng, F)
         if grid_slice is None:
             CF = be.empty((n, G))
             be.coulomb_rows(F, mesh, a, n, out=CF)
@@ -148,3 +249,17 @@ class FitRouteMixin:
             comm.all_reduce_sum(E)
             e_fit = cell.vol / G * np.diag(be.to_host(E))
         return float(abs(e_mat - e_fit).max() / abs(e_fit).max())
+
+    def _bj_probe_mismatch(self, aoT_P, Afac, Dblk, ip_off, Yp, ng, grid_slice, W=None):
+        """A-posteriori check of the S3c route: for random symmetric R_j the density t_j = diag(phi_P R_j phi_P^T)
+        at the points has the Coulomb energy  t^T W t  through the matrix and  w sum_g f conv(f), f = Theta^T t,
+        through the fitted density itself (vector operations only: one pass over Y', nprobe FFTs).  The second form
+        does not see the cond(A')-amplified rounding of M'; their largest relative difference is returned.
+        aoT_P: (nao, P), or a list of such planes whose densities are added (k-points: Re/Im u^k at the points, the
+        density sum_k u^k* R u^k with real symmetric R; W = the real plane of W^{q=0})."""
+        be = self.backend
+        T = self._bj_probe_densities(aoT_P)
+        T0 = T.clone()
+        F = be.empty((T.shape[0], ng))
+        be.bj_probe_rows(T, Afac, Dblk, ip_off, Yp, ng, F)
+        return self._bj_probe_energies(T0, F, self.W if W is None else W, grid_slice)

@@ -438,46 +438,32 @@ def estimate_rcut_per_shell(cell):
 
 
 def get_lattice_Ls(cell, rcut=None):
-    """Translation vectors T with any atom image within ``rcut`` of the (wrap-around) grid box,
-    sorted by |T| with a stable sort (eval_gto.py:132-136,188-253; 3-D only)."""
+    """Lattice translations T = n.a for the AO lattice sum (the role of pyscf/pbc/gto/eval_gto.py:188-253): every T for
+    which some atom image R + T can come within ``rcut`` of a point of the grid box, sorted by |T| (stable, so that
+    translations of equal length keep their lexicographic order and the summation order is reproducible).
+
+    Own construction, slab test in fractional coordinates: the grid points live in the parallelepiped with fractional
+    coordinates in [-1/2, 1] (both the wrap-around and the [0, 1) grid conventions); a point whose fractional coordinate
+    along axis i lies e_i outside that interval is at least e_i * h_i away from the box, h_i = 1 / |column i of a^-1| being
+    the spacing of the lattice planes of that axis.  An image is kept when max_i e_i h_i < rcut for at least one atom.  The
+    list only has to be a superset of the images that contribute: the collocation kernel screens every (point, image)
+    pair against the shell's own cutoff, so any such superset gives the same AO values."""
     if rcut is None:
         rcut = cell.rcut
-    a = cell.lattice_vectors()
-    atom_coords = cell.atom_coords()
-    scaled = np.linalg.solve(a.T, atom_coords.T).T
-    bmax = scaled.max(axis=0)
-    bmin = scaled.min(axis=0)
-    bmax[bmax > 1] = 1
-    bmin[bmin < -1] = -1
-    bound1 = np.diag(bmax).dot(a)
-    bound2 = np.diag(bmin).dot(a)
-
-    def find_boundary(aa):
-        aR = np.vstack([aa, bound1, bound2])
-        r = np.linalg.qr(aR.T)[1]
-        return (rcut + abs(r[2, 3:]).max()) / abs(r[2, 2])
-
-    xb = find_boundary(a[[1, 2, 0]])
-    yb = find_boundary(a[[2, 0, 1]])
-    zb = find_boundary(a)
-    bounds = np.ceil([xb, yb, zb]).astype(int)
-    Ts = cartesian_prod([np.arange(-bounds[i], bounds[i] + 1) for i in range(3)])
-    Ls = np.dot(Ts, a)
-
-    grids_edge = cartesian_prod([[-.5, 1.]] * 3).dot(a)
-    edge_lb = grids_edge.min(axis=0)
-    edge_ub = grids_edge.max(axis=0)
-    g2a = Ls + atom_coords[:, None, :]
-    f1 = g2a > edge_lb
-    f2 = g2a < edge_ub
-    for x in range(3):
-        g2a[~f1[:, :, x], x] -= edge_lb[x]
-        g2a[~f2[:, :, x], x] -= edge_ub[x]
-    g2a[f1 & f2] = 0.
-    mask = (np.linalg.norm(g2a, axis=2) < rcut).any(axis=0)
-    Ls = Ls[mask]
-    Ls = Ls[np.argsort(np.linalg.norm(Ls, axis=1), kind='stable')]
-    return np.ascontiguousarray(Ls)
+    a = np.asarray(cell.lattice_vectors(), dtype=float)
+    ainv = np.linalg.inv(a)
+    spacing = 1.0 / np.linalg.norm(ainv, axis=0)
+    frac = np.asarray(cell.atom_coords(), dtype=float).dot(ainv)
+    lo, hi = -0.5, 1.0
+    reach = rcut / spacing
+    nlo = np.floor(lo - reach - frac.max(axis=0)).astype(int)
+    nhi = np.ceil(hi + reach - frac.min(axis=0)).astype(int)
+    n = cartesian_prod([np.arange(nlo[i], nhi[i] + 1) for i in range(3)])
+    pos = frac[:, None, :] + n[None, :, :]
+    outside = np.maximum(np.maximum(lo - pos, pos - hi), 0.0) * spacing
+    keep = (outside.max(axis=2) < rcut).any(axis=0)
+    Ls = n[keep].dot(a)
+    return np.ascontiguousarray(Ls[np.argsort(np.linalg.norm(Ls, axis=1), kind='stable')])
 
 
 def super_cell(cell, ncopy, mesh=None):

@@ -85,7 +85,6 @@ class HcoreMixin:
         The potential is assembled on the host (O(G natm)); the contraction runs on the device with the
         J kernels (isdf_vj_from_vR / isdf_vj_k).  Returns (nao,nao) for a single k-point (or Gamma),
         else (nk,nao,nao), like the reference."""
-        from . import pbc_tools
         cell, be = self.cell, self.backend
         if kpts is None:
             kpts_lst, single = np.zeros((1, 3)), True
@@ -99,7 +98,7 @@ class HcoreMixin:
         charge = -np.asarray(cell.atom_charges(), dtype=float)
         SI = np.exp(-1j * np.dot(cell.atom_coords(), Gv.T))
         rhoG = charge.dot(SI)
-        vneG = rhoG * pbc_tools.get_coulG(cell, np.zeros(3), mesh)
+        vneG = rhoG * be.to_host(be.coulG_q(mesh, cell.lattice_vectors(), np.zeros(3)))
         vneR = np.fft.ifftn(vneG.reshape(*mesh)).real.ravel()
         d_v = be.to_device(vneR.reshape(1, G))
         rcut = gto.estimate_rcut_per_shell(cell)

@@ -73,6 +73,9 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
                                          # Theta itself and keeps V = conv(Theta) on the device; K costs 4 N G P flop
         self.explicit_theta = False      # True: form Theta itself (second O(P^2 G) solve); same W in exact arithmetic
         self.fft_batch = None             # rows per FFT batch (None: sized from free memory)
+        self.max_resident_rows = None     # fit rows held in HBM at once (None: from free memory); fewer than the number of
+                                          # points -> the rows are produced panel by panel (block-Jacobi route)
+        self.n_panels = 1
         self._backend = backend
         self._comm = comm
         self._rsh_df = {}
@@ -128,6 +131,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         self.grids = UniformGrids(self.cell, self.cell.mesh)
         self._drop_build_state()
         self._bufs = {}
+        self._rows_plan = (None,)
         if self._backend is not None:
             self._backend.empty_cache()
         self._rsh_df = {}
@@ -275,7 +279,16 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
             # the block-major copy of phi and the Cholesky rows are scratch that dies before the fit:
             # they live inside the (P, G) fit buffer, which is not in use yet
             Pmax = int(nip_final.sum())
-            scratch = self._buffer('theta', (max(Pmax, nao + kmax), G))
+            # how many fit rows HBM can hold next to everything else: above that the rows are produced panel by panel
+            # (fit_route.FitRouteMixin._finish_W_paneled; block-Jacobi route only)
+            # (decided once per problem size: later builds find the persistent buffers already allocated)
+            key = (Pmax, G, nao, self.max_resident_rows, self.fft_batch)
+            if getattr(self, '_rows_plan', (None,))[0] != key:
+                self._rows_plan = (key,) + self._resident_rows(G, Pmax)
+            rows_single, rows_panel = self._rows_plan[1:]
+            paneled = Pmax > rows_single and not self._want_theta and self.fit_route != 'cholesky'
+            rows_buf = max(min(Pmax, rows_panel) if paneled else Pmax, nao + kmax)
+            scratch = self._buffer('theta', (rows_buf, G))
             ao_sel = scratch[:nao]
             L = scratch[nao:nao + kmax]
             be.gather_cols(self.ao, d_perm, ao_sel)
@@ -293,10 +306,14 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
             self.ip = ip.astype(np.int64)
             P = len(ip)
             t0 = self._tick('S2_select_ip', t0)
-            theta = self._buffer('theta', (max(Pmax, nao + kmax), G))[:P]
             self.aoP = self._buffer('aoP', (P, nao))
             d_ip = be.to_device(self.ip)
             self.W = self._buffer('W', (P, P))
+            if paneled:
+                self._build_paneled(rank, clusters, d_ip, rows_buf, rows_panel, t0)
+                self._built = True
+                return self
+            theta = self._buffer('theta', (rows_buf, G))[:P]
             for route in self._fit_routes():
                 if route == 'blockjacobi':
                     # S3c: no triangular solve over the grid.  theta <- Y' = D^-1 (aoP ao)^2
@@ -345,6 +362,39 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         self._built = True
         return self
 
+    def _build_paneled(self, rank, clusters, d_ip, rows_buf, rows_panel, t0):
+        """S3c + S4 + S5 with the fit rows produced panel by panel (more points than HBM holds rows for): block-Jacobi
+        route only - its rows depend on their own preconditioner block alone, so a panel can be recomputed at will.  The
+        probe check runs alongside (its combination rows are accumulated panel by panel); there is no second route to fall
+        back to here, a failed check is reported as a warning and in bj_check."""
+        be = self.backend
+        P = len(self.ip)
+        nao, G = self.ao.shape
+        ip_off = self._bj_blocks(rank, clusters)
+        Afac, Dblk = self._bj_prepare(self.ao, 0, d_ip, ip_off, self.aoP, scratch=self.W)
+        panels = self._panel_plan(ip_off, min(rows_panel, rows_buf))
+        rows = self._buffer('theta', (rows_buf, G))
+        self._fit_state = dict(kind='blockjacobi-paneled', rows=rows, panels=panels, Afac=Afac, Dblk=Dblk, ip_off=ip_off)
+        t0 = self._tick('S3_fit', t0)
+        probe = None
+        if self.fit_route == 'auto':
+            aoT = be.empty((nao, P))
+            be.gather_cols(self.ao, d_ip, aoT)
+            T0, E = self._bj_probe_vectors(aoT, Afac, Dblk, ip_off)
+            del aoT
+            probe = (E, be.empty((E.shape[0], G)))
+        self._finish_W_paneled(self.W, probe=probe)
+        t0 = self._tick('S4S5_coulomb_W', t0)
+        self.fit_route_used = 'blockjacobi'
+        self.n_panels = len(panels)
+        if probe is not None:
+            self.bj_check = self._bj_probe_energies(T0, probe[1], self.W, None)
+            t0 = self._tick('S5_route_check', t0)
+            if self.bj_check > self.bj_check_tol:
+                warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e) in a paneled build, '
+                              'where the Cholesky route is not available: W carries rounding noise of that relative size'
+                              % (self.bj_check, self.bj_check_tol))
+
     def _refine_selection(self, perm, blk_off, piv_h, rank, P_target, owner):
         """select='refined' on one GPU: the per-atom selections (refine_over x too many points each) are only CANDIDATES;
         see _refine_pick.  Leaves the chosen grid indices per atom (in pivot order) in self._refined_by_atom and returns the
@@ -354,20 +404,23 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         cand = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(natm)]).astype(np.int64)
         aoC = be.empty((len(cand), self.ao.shape[0]))
         be.gather_aoP(self.ao, be.to_device(cand), aoC)
-        chosen = self._refine_pick(aoC, cand, P_target)
-        del aoC
+        # the candidate Gram matrix (17 GB at c = 14) lives in the fit-row buffer, which is not in use yet
+        rows_buf = self._bufs.get('theta')
+        gram = None if rows_buf is None or rows_buf.numel() < len(cand) ** 2 else rows_buf[:len(cand) ** 2].view(len(cand), len(cand))
+        chosen = self._refine_pick(aoC, cand, P_target, gram=gram)
+        del aoC, gram
         own = owner[chosen]
         self._refined_by_atom = [chosen[own == b] for b in range(natm)]
         return np.array([len(x) for x in self._refined_by_atom], dtype=np.int32)
 
-    def _refine_pick(self, aoC, cand, P_target):
+    def _refine_pick(self, aoC, cand, P_target, gram=None):
         """One pivoted Cholesky of the pair-density Gram matrix restricted to the candidate set (aoC: AO values at the
         candidates, (m, nao); isdf_gram_sq + isdf_select_ip_gram, pivot rule pyscf/lib/scipy_helper.py:71-110) picks the
         final P_target points.  Returns their grid indices in pivot order."""
         be = self.backend
         m = len(cand)
         P_target = min(int(P_target), m)
-        A = be.empty((m, m))
+        A = be.empty((m, m)) if gram is None else gram
         be.gram_sq(aoC, A)
         piv2 = be.empty((P_target,), dtype=torch.int64)
         r2 = be.select_ip_gram(A, P_target, self.select_tol, self.tie_rtol, piv2)
@@ -468,6 +521,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         them): W <- w conv(rows) rows^T, then the route's P x P finishing.  Uses the Coulomb kernel the backend is set to
         (plain, or range-separated for get_jk(omega=...): the fit itself does not depend on the kernel)."""
         be, st = self.backend, self._fit_state
+        if st['kind'] == 'blockjacobi-paneled':
+            return self._finish_W_paneled(W)
         theta = st['theta']
         P, G = theta.shape
         mesh = np.asarray(self.mesh, dtype=np.int32)

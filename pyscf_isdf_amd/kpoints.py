@@ -148,7 +148,6 @@ class KPointMixin:
     def _build_Wq(self, omega, t0, probe=False):
         """S4 + S5 for this rank's share of the q list from the fit held in self._kfit_state: {iq: W^q (P, P) complex}.
         omega: range separation of the kernel (pyscf/pbc/tools/pbc.py:408-418) - the fit does not depend on it."""
-        from . import pbc_tools
         cell, be, comm = self.cell, self.backend, self.comm
         st = self._kfit_state
         Y, r_ip = st['Y'], st['r_ip']
@@ -162,7 +161,7 @@ class KPointMixin:
             if self._q_owner[iq] != comm.rank:
                 continue
             q = self._qs[iq]
-            coulG = be.to_device(pbc_tools.get_coulG(cell, q, mesh, omega=omega))
+            coulG = be.coulG_q(mesh, cell.lattice_vectors(), q, omega=omega)
             be.coulomb_Wq(Y, mesh, coulG, w, 0, P, st['batch'], Wre, Wim, upper_only=True)
             be.symmetrize_hermitian(Wre, Wim)
             if st['route'] == 'blockjacobi':

@@ -45,6 +45,8 @@ SIGNATURES = {
     'isdf_shift_diag': (c_int, [c_vp, c_vp, c_int, c_dbl]),
     'isdf_chol_inplace': (c_int, [c_vp, c_vp, c_int, c_dbl, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_factor_solve': (c_int, [c_vp, c_vp, c_int, c_vp, c_i64, c_i64]),
+    'isdf_bj_probe_vectors': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
+    'isdf_rows_combine': (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_int]),
     'isdf_bj_probe_rows': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64]),
     'isdf_gather_T': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),
     'isdf_W_from_factor': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64]),
@@ -61,6 +63,7 @@ SIGNATURES = {
     'isdf_select_ip_cplx': (c_int, [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_i64, c_vp, c_vp]),
     'isdf_fit_prepare_cplx': (c_int, [c_vp, c_vp, c_int, c_int, c_i64, c_vp, c_int, c_dbl, c_vp, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_fit_apply_cplx': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_int, c_vp, c_i64]),
+    'isdf_coulG_q': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_dbl, c_vp]),
     'isdf_coulomb_Wq': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_dbl, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64]),
     'isdf_symmetrize_hermitian': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64]),
     'isdf_finish_Wq': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),

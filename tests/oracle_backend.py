@@ -182,6 +182,18 @@ class OracleBackend:
         T.copy_(torch.from_numpy(np.ascontiguousarray(t)))
         F[:, :ng] = torch.from_numpy(t.dot(Yp.numpy()[:, :ng]))
 
+    def bj_probe_vectors(self, T, fac, D, blk_off):
+        self.block_solve(D, blk_off, 1, 1, T)
+        t = scipy.linalg.cho_solve((fac.numpy(), True), T.numpy().T).T
+        T.copy_(torch.from_numpy(np.ascontiguousarray(t)))
+
+    def rows_combine(self, E, Y, F, accumulate=False):
+        r = torch.from_numpy(E.numpy().dot(Y.numpy()))
+        if accumulate:
+            F += r
+        else:
+            F.copy_(r)
+
     def gather_T(self, L, k, piv, T):
         T.copy_(torch.from_numpy(np.triu(L.numpy()[:k][:, piv.numpy()[:k]])))
 
@@ -294,6 +306,13 @@ class OracleBackend:
             theta[:, :ng] = torch.from_numpy(scipy.linalg.solve_triangular(chol.numpy(), B, lower=True))
         else:
             theta[:, :ng] = torch.from_numpy(scipy.linalg.cho_solve((chol.numpy(), True), B))
+
+    def coulG_q(self, mesh, a, q, omega=None, wrap_around=True, out=None):
+        t = torch.from_numpy(tools.get_coulG(a, mesh, q, wrap_around=wrap_around, omega=omega))
+        if out is None:
+            return t
+        out.copy_(t)
+        return out
 
     def coulomb_Wq(self, theta, mesh, coulG, weight, row0, nrows, batch, Wre, Wim, upper_only=False):
         th = theta.numpy()

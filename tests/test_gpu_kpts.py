@@ -82,6 +82,36 @@ def test_select_and_fit_complex_mode(be):
     assert abs(be.to_host(theta) - ref).max() < 1e-7 * abs(ref).max()
 
 
+def test_coulG_q_kernel_matches_reference_pins_and_oracle(be):
+    """isdf_coulG_q (index-space wrap-around) against the REFERENCE's own constants for tools.get_coulG
+    (pyscf/pbc/tools/test/test_pbc.py:54-77: random triclinic lattice + random k, mesh [11,9,7]; cubic cell with q on the
+    mesh edge, with and without wrap-around), and against the oracle restatement for generic q, even meshes and omega.
+    Tolerance 1e-9 on the fingerprints (the reference's assertAlmostEqual places), 1e-12 relative element-wise."""
+    np.random.seed(19)
+    kpt = np.random.random(3)
+    a = (np.array(((0., 1.7834, 1.7834), (1.7834, 0., 1.7834), (1.7834, 1.7834, 0.))) + np.random.random((3, 3)).T) / 0.52917721092
+    mesh = [11, 9, 7]
+    got = be.to_host(be.coulG_q(mesh, a, kpt))
+    assert abs(otools.fp(got) - 62.75448804333378) < 1e-9 * 62.75
+    assert abs(got - otools.get_coulG(a, mesh, kpt)).max() < 1e-12 * abs(got).max()
+    eye = np.eye(3)
+    q = np.array([0, np.pi, 0])
+    assert abs(otools.fp(be.to_host(be.coulG_q(mesh, eye, q))) - 4.6737453679713905) < 1e-9
+    assert abs(otools.fp(be.to_host(be.coulG_q(mesh, eye, q, wrap_around=False))) - 4.5757877990664744) < 1e-9
+    # generic q, even and odd mesh sizes, range separation; the Gamma table too
+    cell = cells.cell_he2_triclinic()
+    al = cell.lattice_vectors()
+    for m in ([9, 9, 9], [10, 8, 6], [12, 5, 7]):
+        for qv in (np.zeros(3), np.array([0.13, -0.2, 0.31]), cell.make_kpts([2, 2, 2])[5], -cell.make_kpts([2, 2, 2])[7]):
+            for om in (None, 0.4, -0.4):
+                ref = otools.get_coulG(al, m, qv, omega=om)
+                got = be.to_host(be.coulG_q(m, al, qv, omega=om))
+                assert np.array_equal(got == 0, ref == 0)                      # the same zeroed (edge / G = 0) entries
+                assert abs(got - ref).max() < 1e-12 * abs(ref).max()
+    with pytest.raises(Exception):
+        be.coulG_q([9, 9, 9], eye, np.array([0, 2 * np.pi * 5, 0]))             # outside the first FFT box (pbc.py:281)
+
+
 def test_coulomb_Wq(be):
     """M^q and W^q for q = 0 and a generic q against the oracle's complex FFT construction."""
     cell, coords, Ls, rcut, kpts, aos, dms = _setup()
@@ -95,7 +125,7 @@ def test_coulomb_Wq(be):
     for q in (np.zeros(3), kpts[1] - kpts[0], kpts[0] - kpts[1]):
         ref = kisdf.build_Wq(theta, a, mesh, q, coords[piv])
         Wre = be.empty((P, P)); Wim = be.empty((P, P)); Wc = be.empty((P, P), dtype=torch.complex128)
-        be.coulomb_Wq(be.to_device(theta), mesh, be.to_device(pbc_tools.get_coulG(cell, q)), w, 0, P, 7, Wre, Wim, upper_only=True)
+        be.coulomb_Wq(be.to_device(theta), mesh, be.coulG_q(mesh, cell.lattice_vectors(), q), w, 0, P, 7, Wre, Wim, upper_only=True)
         be.symmetrize_hermitian(Wre, Wim)
         be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * coords[piv].dot(q))), Wc)
         assert abs(be.to_host(Wc) - ref).max() < 1e-10 * abs(ref).max()

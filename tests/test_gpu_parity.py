@@ -589,28 +589,6 @@ def test_exact_exchange_on_gpu_matches_reference_pin():
     assert abs(df.get_k_exact(dm) - ref).max() < 1e-10
 
 
-def test_headline_config_regression_diamond444():
-    """BASELINE configs[2] at full size (N=1664, G=1728000, P=16640; ~256 GiB of HBM, ~25 s): size-independent
-    properties plus a regression pin of the energies recorded in profiles/r01_bench_cfg3.json (the exact-
-    exchange comparison at this size is in profiles/r01_accuracy_isdf_vs_exact_k.log)."""
-    import torch
-    from pyscf_isdf_amd import workloads
-    from pyscf_isdf_amd.isdf import ISDF
-    if torch.cuda.get_device_properties(0).total_memory < 270 * 2 ** 30:
-        pytest.skip('needs a 288 GB device')
-    cell = workloads.make_cell('diamond-444-dzvp-120')
-    dm, c, occ = workloads.make_dm(cell)
-    df = ISDF(cell, c_isdf=10, select='local')
-    vj, vk = df.get_jk(dm)
-    assert len(df.ip) == 16640 and len(np.unique(df.ip)) == 16640
-    assert abs(vj - vj.T).max() < 1e-8 and abs(vk - vk.T).max() < 1e-7
-    ej, ek = np.einsum('ij,ji', vj, dm) / 2, np.einsum('ij,ji', vk, dm) / 4
-    assert abs(ej - 12.140270972643) < 1e-7
-    assert abs(ek - 123.180049312) < 1e-6
-    assert abs(ek - 123.18058922) < 1e-3           # exact exchange (GPU, 426k FFT pairs): c=10 fitting error 5.4e-4 Eh
-    df.reset()
-
-
 def test_ao_eri_and_ao2mo_from_the_factorisation():
     """get_ao_eri at full rank reproduces the reference's fp(eri) (test_fft.py:692-695); ao2mo is the same
     tensor transformed."""
@@ -837,6 +815,32 @@ def test_block_jacobi_route_end_to_end():
     finally:
         df.backend.set_option('trsm_substitution', 0)
     assert abs(vk2 - vk1).max() < 1e-7 * abs(vk1).max()
+
+
+def test_paneled_build_matches_single_pass():
+    """The paneled S3c/S4/S5 (fit rows produced panel by panel when HBM cannot hold them all; forced here with
+    max_resident_rows) against the single-pass block-Jacobi build on the same points: W within 1e-8, K within 1e-9 relative,
+    the same probe-check value, for 2 and 4 panels with ragged FFT batches."""
+    from pyscf_isdf_amd import gto as g
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = g.diamond_supercell(2, 'gth-szv', (20, 20, 20))
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(2)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    ref = ISDF(cell, c_isdf=6, select='refined')
+    k0 = ref.get_jk(dm, with_j=False)[1]
+    W0 = ref.backend.to_host(ref.W)
+    P = len(ref.ip)
+    assert ref.fit_route_used == 'blockjacobi' and ref.n_panels == 1
+    for rows in (P // 2 + 10, P // 4 + 10):
+        df = ISDF(cell, c_isdf=6, select='refined')
+        df.max_resident_rows, df.fft_batch = rows, 37
+        k1 = df.get_jk(dm, with_j=False)[1]
+        assert df.n_panels >= 2 and np.array_equal(df.ip, ref.ip)
+        assert abs(df.backend.to_host(df.W) - W0).max() < 1e-8 * abs(W0).max()
+        assert abs(k1 - k0).max() < 1e-9 * abs(k0).max()
+        assert abs(df.bj_check - ref.bj_check) < 0.5 * ref.bj_check + 1e-12
+        df.reset()
 
 
 def test_rccl_code_paths_execute_on_one_gpu():

@@ -261,3 +261,41 @@ def test_robust_k_host_logic_with_checker_backend():
     sh.force_sharded = True
     sh.fft_batch = 5
     assert abs(sh.get_jk(dm, with_j=False)[1] - k_rob).max() < 1e-12
+
+
+def test_paneled_build_host_logic_with_checker_backend():
+    """More interpolation points than HBM holds fit rows for (max_resident_rows forces it): the rows are produced panel by
+    panel, M' is assembled from diagonal panel blocks and recomputed-batch x resident-panel blocks, the probe check is
+    accumulated on the way.  Same W and K as the single-pass block-Jacobi build, same range-separated rebuild, for 2, 3 and
+    5 panels with ragged FFT batches; a panel budget below one preconditioner block is an error."""
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = gto.diamond_supercell(2, 'gth-szv', (12, 12, 12))
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(1)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    ref = ISDF(cell, c_isdf=2, select='refined', backend=OracleBackend())
+    ref.bj_check_tol = 1e-6
+    k0 = ref.get_jk(dm, with_j=False)[1]
+    W0 = ref.W.numpy().copy()
+    assert ref.fit_route_used == 'blockjacobi' and ref.n_panels == 1
+    P = len(ref.ip)
+    seen = set()
+    for rows, npan in ((P // 2 + 3, 2), (P // 3 + 5, 3), (P // 5 + 8, 5)):
+        df = ISDF(cell, c_isdf=2, select='refined', backend=OracleBackend())
+        df.max_resident_rows, df.fft_batch, df.bj_check_tol = rows, 11, 1e-6
+        k1 = df.get_jk(dm, with_j=False)[1]
+        assert df.n_panels == len(df._fit_state['panels']) >= npan - 1 and df._fit_state['kind'] == 'blockjacobi-paneled'
+        seen.add(df.n_panels)
+        assert np.array_equal(df.ip, ref.ip)
+        assert max(y - x for x, y in df._fit_state['panels']) <= rows
+        assert abs(df.W.numpy() - W0).max() < 1e-9 * abs(W0).max()
+        assert abs(k1 - k0).max() < 1e-10 * abs(k0).max()
+        assert abs(df.bj_check - ref.bj_check) < 0.5 * ref.bj_check + 1e-13
+        kl, ks = df.get_jk(dm, omega=0.4, with_j=False)[1], df.get_jk(dm, omega=-0.4, with_j=False)[1]
+        assert abs(kl + ks - k1).max() < 1e-8 * abs(k1).max()
+    assert len(seen) >= 2 and min(seen) >= 2
+    small = ISDF(cell, c_isdf=2, select='local', backend=OracleBackend())
+    small.max_resident_rows = 3
+    with pytest.raises(MemoryError):
+        small.build()
