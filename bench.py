@@ -39,7 +39,8 @@ def parse_args():
     ap.add_argument('--refine-over', type=float, default=2.0)
     ap.add_argument('--no-accuracy', action='store_true',
                     help="skip the exact-exchange comparison (config.dE_K_vs_exact; 48 s at configs[2], after the timed region)")
-    ap.add_argument('--c-isdf', type=int, default=10)
+    ap.add_argument('--c-isdf', type=int, default=None,
+                    help='interpolation points per AO; default: 12 for the headline workload (the accuracy scan of DESIGN.md section 2), else 10')
     ap.add_argument('--fit-route', default=None, choices=['auto', 'cholesky', 'blockjacobi'])
     ap.add_argument('--robust-k', action='store_true', help='time the build + get_jk with the robust exchange (not the headline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -171,6 +172,8 @@ def spawn_ranks(n):
 
 def main():
     args = parse_args()
+    if args.c_isdf is None:
+        args.c_isdf = 12 if args.workload == 'diamond-444-dzvp-120' else 10
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     import torch

@@ -54,7 +54,8 @@ int isdf_release_workspace(isdf_handle h);
 /* Runtime switches.  "trsm_substitution": 0 (default) the fit's triangular solves with Cholesky factors go through rocBLAS
  * dtrsm, 1 through the substitution blocks of trsm.hip (plain forward/backward substitution on 64-row diagonal blocks +
  * dgemm updates: slower, no inverted diagonal blocks; an independent cross-check of rocBLAS's algorithm).  Unknown keys are
- * an error. */
+ * an error.  "own_fft": 1 (default) the Coulomb convolution runs through the hand-written five-pass FFT (fft_conv.hip) on
+ * meshes whose dimensions factor into 2, 3, 5, 7, 11, 13; 0 forces hipFFT (D2Z, kernel multiply, Z2D) everywhere. */
 int isdf_set_option(isdf_handle h, const char* key, int value);
 /* Range separation of the Gamma-point Coulomb kernel used by isdf_coulomb_W / _rows / _potential / isdf_get_j, as
  * pyscf/pbc/tools/pbc.py:408-418: omega > 0 long range (erf(omega r)/r), omega < 0 short range, 0 (default) plain 1/r.

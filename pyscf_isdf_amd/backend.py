@@ -27,8 +27,10 @@ class HipBackend:
         self.device = torch.device('cuda', device)
         torch.cuda.set_device(self.device)
         self.handle = _lib.Handle(device)
-        if os.environ.get('ISDF_TRSM') == 'subst':        # e.g. for rocprofv3 --pmc runs (include/mi355_isdf.h)
+        if os.environ.get('ISDF_TRSM') == 'subst':        # cross-check path (include/mi355_isdf.h)
             self.set_option('trsm_substitution', 1)
+        if os.environ.get('ISDF_OWN_FFT') == '0':         # A/B runs: hipFFT instead of fft_conv.hip
+            self.set_option('own_fft', 0)
 
     # ---- memory -------------------------------------------------------------------------------
     def empty(self, shape, dtype=torch.float64):

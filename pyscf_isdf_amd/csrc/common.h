@@ -43,6 +43,8 @@ struct isdf_ctx {
   int num_cu = 256;
   // triangular solves of the fit: 0 = rocBLAS dtrsm (default, faster), 1 = substitution blocks of trsm.hip
   int trsm_substitution = 0;
+  // Coulomb convolution: 1 = the hand-written five-pass FFT of fft_conv.hip where the mesh allows (default), 0 = hipFFT
+  int own_fft = 1;
   // range-separation parameter of the Gamma-point Coulomb kernel table (0 = plain 1/r); isdf_set_coulomb_omega
   double coul_omega = 0.0;
 };
@@ -50,6 +52,10 @@ struct isdf_ctx {
 int isdf_fail(isdf_handle h, int code, const char* fmt, ...);
 void* isdf_ws(isdf_handle h, const char* name, size_t bytes);   // nullptr on failure (error set)
 int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out);
+// fft_conv.hip: d_out rows = ifft(cg * fft(d_in rows)) with the scaled half-spectrum table cg; zbuf nb * n0 n1 (n2/2+1) complex
+bool conv_rows_own_supported(const int32_t mesh[3]);
+int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, const int32_t mesh[3], const double* cg,
+                  double2* zbuf);
 
 #define HIP_TRY(h, expr)                                                                    \
   do {                                                                                      \

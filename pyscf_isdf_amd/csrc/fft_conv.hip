@@ -1,0 +1,605 @@
+// S4: the Coulomb convolution V = ifft(coulG fft(rows)) of a batch of real fields, hand-written for gfx950.
+//
+// hipFFT runs a batched 3-D real transform as three unfused passes per direction plus our separate kernel multiply:
+// seven kernels, each reading and writing the whole batch (112 G bytes per row against 32 G algorithmic; measured 0.9 TB/s
+// algorithmic in round 1).  Here the same arithmetic takes FIVE passes (80 G bytes per row), every one a streaming kernel
+// whose 1-D transforms live in LDS:
+//
+//   1. z, real -> half complex   lines are contiguous; TWO real lines ride one complex transform (a + i b) and are
+//                                separated afterwards (A_k = (Z_k + conj Z_{n-k}) / 2, B_k = (Z_k - conj Z_{n-k}) / 2i)
+//   2. y forward                 lines strided by n2h; a workgroup takes all n1 elements of 16 ADJACENT lines, so every global
+//                                access is a 256-byte run and the LDS layout [element][line] is bank-conflict free
+//   3. x forward, x coulG, x inverse   the same kernel along the slowest axis, kernel multiply fused between the two
+//                                transforms (the table already carries the 1/G of the inverse, pbc.py:182-211)
+//   4. y inverse
+//   5. z, half complex -> real   the inverse of pass 1 (imaginary parts of the self-conjugate entries are ignored, as
+//                                hipFFT's Z2D does)
+//
+// The 1-D transform is a Stockham autosort FFT (decimation in frequency, out of place between two LDS buffers, natural order
+// in and out) over the mixed radices of n: 4, 2, 3, 5 hard-coded, 7 / 11 / 13 by a generic O(r^2) butterfly; twiddles
+// W_n^k = exp(-2 pi i k / n) come from a host-made double table.  One butterfly per thread and stage, consecutive threads on
+// consecutive lines.  Meshes with a prime factor above 13 (or a dimension above 1024) fall back to hipFFT in coulomb.hip.
+//
+// Two implementations of the stages.  FAST (every dimension 2-3-5 smooth: all production meshes): ONE LDS buffer - a stage
+// reads its butterflies' inputs, keeps the outputs in registers across a barrier and writes them back in place, so a
+// workgroup needs n x 16 lines x 16 B <= 32 KB and five workgroups share a CU (the passes are latency chains of load /
+// stages / store: occupancy is what hides them); twiddles staged in LDS; the number of lines per tile is a compile-time
+// power of two and the divisions by the stage stride go through a float reciprocal.  GENERIC (a factor 7, 11 or 13
+// somewhere): two LDS buffers, plain Stockham ping-pong.
+//
+// Reference semantics: pyscf/pbc/tools/pbc.py:149-211 (fft unscaled, ifft 1/N, C order over the mesh).
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MAXSTAGE = 12;
+
+struct Axis {
+  int n;
+  int nstage;
+  int radix[MAXSTAGE];
+  const double2* tw;     // n entries, exp(-2 pi i k / n)
+};
+
+__device__ inline double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ inline double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ inline double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// multiply by SIGN * i
+template <int SIGN>
+__device__ inline double2 mul_si(double2 a) { return SIGN > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x); }
+template <int SIGN>
+__device__ inline double2 twid(const double2* __restrict__ tw, int idx) {
+  double2 w = tw[idx];
+  if (SIGN > 0) w.y = -w.y;
+  return w;
+}
+
+// One Stockham stage of radix r on M lines held as x[element * Ls + line]:  n_cur = current sub-length, s = stride.
+template <int SIGN>
+__device__ inline void stockham_stage(const double2* __restrict__ x, double2* __restrict__ y, int N, int n_cur, int s, int r,
+                                      int Ls, int M, const double2* __restrict__ tw) {
+  const int mm = n_cur / r;
+  const int nbf = N / r;
+  for (int i = threadIdx.x; i < nbf * M; i += TPB) {
+    const int m = i % M, bf = i / M;
+    const int q = bf % s, p = bf / s;
+    const double2* xi = x + (int64_t)(q + s * p) * Ls + m;
+    double2* yo = y + (int64_t)(q + s * r * p) * Ls + m;
+    const int sin_ = s * mm * Ls;      // input step between the r legs
+    const int sout = s * Ls;           // output step
+    const int tstep = (p * s) % N;     // twiddle exponent of leg 1
+    if (r == 4) {
+      const double2 a0 = xi[0], a1 = xi[sin_], a2 = xi[2 * sin_], a3 = xi[3 * sin_];
+      const double2 u0 = cadd(a0, a2), u1 = csub(a0, a2), u2 = cadd(a1, a3), u3 = mul_si<SIGN>(csub(a1, a3));
+      yo[0] = cadd(u0, u2);
+      yo[sout] = cmul(cadd(u1, u3), twid<SIGN>(tw, tstep));
+      yo[2 * sout] = cmul(csub(u0, u2), twid<SIGN>(tw, (2 * tstep) % N));
+      yo[3 * sout] = cmul(csub(u1, u3), twid<SIGN>(tw, (3 * tstep) % N));
+    } else if (r == 2) {
+      const double2 a0 = xi[0], a1 = xi[sin_];
+      yo[0] = cadd(a0, a1);
+      yo[sout] = cmul(csub(a0, a1), twid<SIGN>(tw, tstep));
+    } else if (r == 3) {
+      const double2 a0 = xi[0], a1 = xi[sin_], a2 = xi[2 * sin_];
+      const double2 t1 = cadd(a1, a2);
+      const double2 t2 = make_double2(a0.x - 0.5 * t1.x, a0.y - 0.5 * t1.y);
+      const double2 d = csub(a1, a2);
+      const double2 t3 = mul_si<SIGN>(make_double2(0.86602540378443864676 * d.x, 0.86602540378443864676 * d.y));
+      yo[0] = cadd(a0, t1);
+      yo[sout] = cmul(cadd(t2, t3), twid<SIGN>(tw, tstep));
+      yo[2 * sout] = cmul(csub(t2, t3), twid<SIGN>(tw, (2 * tstep) % N));
+    } else if (r == 5) {
+      const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+      const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+      const double2 a0 = xi[0], a1 = xi[sin_], a2 = xi[2 * sin_], a3 = xi[3 * sin_], a4 = xi[4 * sin_];
+      const double2 t1 = cadd(a1, a4), t2 = cadd(a2, a3), t3 = csub(a1, a4), t4 = csub(a2, a3);
+      const double2 r1 = make_double2(a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y);
+      const double2 r2 = make_double2(a0.x + c2 * t1.x + c1 * t2.x, a0.y + c2 * t1.y + c1 * t2.y);
+      const double2 i1 = mul_si<SIGN>(make_double2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
+      const double2 i2 = mul_si<SIGN>(make_double2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+      yo[0] = make_double2(a0.x + t1.x + t2.x, a0.y + t1.y + t2.y);
+      yo[sout] = cmul(cadd(r1, i1), twid<SIGN>(tw, tstep));
+      yo[2 * sout] = cmul(cadd(r2, i2), twid<SIGN>(tw, (2 * tstep) % N));
+      yo[3 * sout] = cmul(csub(r2, i2), twid<SIGN>(tw, (3 * tstep) % N));
+      yo[4 * sout] = cmul(csub(r1, i1), twid<SIGN>(tw, (4 * tstep) % N));
+    } else {
+      // generic prime radix: b_j = sum_k a_k w_r^{jk}, w_r^t = W_N^{(N/r) t}
+      const int wr = N / r;
+      for (int j = 0; j < r; ++j) {
+        double2 b = xi[0];
+        for (int k = 1; k < r; ++k) b = cadd(b, cmul(xi[k * sin_], twid<SIGN>(tw, wr * ((j * k) % r))));
+        yo[j * sout] = cmul(b, twid<SIGN>(tw, (int)(((int64_t)j * tstep) % N)));
+      }
+    }
+  }
+}
+
+// All stages; returns the buffer that holds the result (natural order).
+template <int SIGN>
+__device__ inline double2* stockham_all(double2* x, double2* y, const Axis& ax, int Ls, int M) {
+  int n_cur = ax.n, s = 1;
+  for (int st = 0; st < ax.nstage; ++st) {
+    const int r = ax.radix[st];
+    stockham_stage<SIGN>(x, y, ax.n, n_cur, s, r, Ls, M, ax.tw);
+    __syncthreads();
+    n_cur /= r;
+    s *= r;
+    double2* t = x; x = y; y = t;
+  }
+  return x;
+}
+
+// Pass 1: real lines (n contiguous doubles each, nlines of them back to back) -> half-complex lines (nh = n/2 + 1).
+// A workgroup takes LP line pairs.
+__global__ __launch_bounds__(TPB) void z_r2c_kernel(const double* __restrict__ in, double2* __restrict__ out, int64_t nlines,
+                                                    Axis ax, int LP) {
+  extern __shared__ double2 lds[];
+  const int n = ax.n, nh = n / 2 + 1, Ls = LP + 1;
+  double2* x = lds;
+  double2* y = lds + (int64_t)n * Ls;
+  const int64_t line0 = (int64_t)blockIdx.x * 2 * LP;
+  const int nl = (int)min((int64_t)2 * LP, nlines - line0);     // lines of this tile
+  const int M = (nl + 1) / 2;
+  const double* src = in + line0 * n;
+  for (int c = threadIdx.x; c < 2 * M * n; c += TPB) {
+    const int l = c / n, e = c - l * n;
+    const double v = (l < nl) ? src[c] : 0.0;
+    double* dst = (double*)(x + (int64_t)e * Ls + (l >> 1));
+    dst[l & 1] = v;
+  }
+  __syncthreads();
+  const double2* z = stockham_all<-1>(x, y, ax, Ls, M);
+  double2* dstc = out + line0 * nh;
+  for (int c = threadIdx.x; c < nl * nh; c += TPB) {
+    const int l = c / nh, k = c - l * nh;
+    const int m = l >> 1;
+    const double2 zk = z[(int64_t)k * Ls + m];
+    const double2 zn = z[(int64_t)((n - k) % n) * Ls + m];
+    double2 r;
+    if ((l & 1) == 0) r = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));        // (Z_k + conj Z_{n-k}) / 2
+    else r = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));                   // (Z_k - conj Z_{n-k}) / 2i
+    dstc[c] = r;
+  }
+}
+
+// Pass 5: half-complex lines -> real lines (unnormalised inverse; the 1/N sits in the kernel table).
+__global__ __launch_bounds__(TPB) void z_c2r_kernel(const double2* __restrict__ in, double* __restrict__ out, int64_t nlines,
+                                                    Axis ax, int LP) {
+  extern __shared__ double2 lds[];
+  const int n = ax.n, nh = n / 2 + 1, Ls = LP + 1;
+  double2* x = lds;
+  double2* y = lds + (int64_t)n * Ls;
+  const int64_t line0 = (int64_t)blockIdx.x * 2 * LP;
+  const int nl = (int)min((int64_t)2 * LP, nlines - line0);
+  const int M = (nl + 1) / 2;
+  const double2* src = in + line0 * nh;
+  // Z_k = A_k + i B_k (k <= n/2),  Z_{n-k} = conj(A_k) + i conj(B_k);  A = even line, B = odd line of the pair
+  for (int c = threadIdx.x; c < M * nh; c += TPB) {
+    const int m = c / nh, k = c - m * nh;
+    double2 a = src[(int64_t)(2 * m) * nh + k];
+    double2 b = (2 * m + 1 < nl) ? src[(int64_t)(2 * m + 1) * nh + k] : make_double2(0.0, 0.0);
+    const bool selfconj = (k == 0) || (2 * k == n);
+    if (selfconj) { a.y = 0.0; b.y = 0.0; }
+    x[(int64_t)k * Ls + m] = make_double2(a.x - b.y, a.y + b.x);
+    if (!selfconj) x[(int64_t)(n - k) * Ls + m] = make_double2(a.x + b.y, -a.y + b.x);
+  }
+  __syncthreads();
+  const double2* z = stockham_all<1>(x, y, ax, Ls, M);
+  double* dst = out + line0 * n;
+  for (int c = threadIdx.x; c < nl * n; c += TPB) {
+    const int l = c / n, e = c - l * n;
+    const double* zz = (const double*)(z + (int64_t)e * Ls + (l >> 1));
+    dst[c] = zz[l & 1];
+  }
+}
+
+// Passes 2-4: 1-D transforms along a strided axis, in place.  data[o * os + e * es + m], e < n (the transformed axis),
+// m < Mtot adjacent lines (unit stride), o outer blocks.  MODE 0: forward, 1: inverse, 2: forward, multiply by
+// table[e * es + m], inverse.
+template <int MODE>
+__global__ __launch_bounds__(TPB) void strided_fft_kernel(double2* __restrict__ data, int64_t os, int64_t es, int Mtot, Axis ax,
+                                                          int ZC, int ntile, const double* __restrict__ table) {
+  extern __shared__ double2 lds[];
+  const int n = ax.n;
+  double2* x = lds;
+  double2* y = lds + (int64_t)n * ZC;
+  const int64_t outer = blockIdx.x / ntile;              // 1-D grid: (outer block, tile of adjacent lines)
+  const int m0 = (int)(blockIdx.x % ntile) * ZC;
+  const int M = min(ZC, Mtot - m0);
+  double2* base = data + outer * os + m0;
+  for (int c = threadIdx.x; c < n * ZC; c += TPB) {
+    const int e = c / ZC, m = c - e * ZC;
+    if (m < M) x[(int64_t)e * ZC + m] = base[(int64_t)e * es + m];
+  }
+  __syncthreads();
+  double2* z;
+  if (MODE == 1) {
+    z = stockham_all<1>(x, y, ax, ZC, M);
+  } else {
+    z = stockham_all<-1>(x, y, ax, ZC, M);
+    if (MODE == 2) {
+      const double* tb = table + m0;
+      for (int c = threadIdx.x; c < n * ZC; c += TPB) {
+        const int e = c / ZC, m = c - e * ZC;
+        if (m < M) {
+          const double g = tb[(int64_t)e * es + m];
+          double2 v = z[(int64_t)e * ZC + m];
+          v.x *= g;
+          v.y *= g;
+          z[(int64_t)e * ZC + m] = v;
+        }
+      }
+      __syncthreads();
+      double2* other = (z == x) ? y : x;
+      z = stockham_all<1>(z, other, ax, ZC, M);
+    }
+  }
+  for (int c = threadIdx.x; c < n * ZC; c += TPB) {
+    const int e = c / ZC, m = c - e * ZC;
+    if (m < M) base[(int64_t)e * es + m] = z[(int64_t)e * ZC + m];
+  }
+}
+
+
+// ---- FAST path: in-place stages with register-held outputs -----------------------------------------------------------
+// Invariant (host): n * ZCT <= 2048, so a stage has at most 8 / R butterflies per thread.
+template <int SIGN, int R>
+__device__ inline void butterfly_r(const double2* a, double2* b) {
+  if (R == 2) {
+    b[0] = cadd(a[0], a[1]);
+    b[1] = csub(a[0], a[1]);
+  } else if (R == 3) {
+    const double2 t1 = cadd(a[1], a[2]);
+    const double2 t2 = make_double2(a[0].x - 0.5 * t1.x, a[0].y - 0.5 * t1.y);
+    const double2 d = csub(a[1], a[2]);
+    const double2 t3 = mul_si<SIGN>(make_double2(0.86602540378443864676 * d.x, 0.86602540378443864676 * d.y));
+    b[0] = cadd(a[0], t1);
+    b[1] = cadd(t2, t3);
+    b[2] = csub(t2, t3);
+  } else if (R == 4) {
+    const double2 u0 = cadd(a[0], a[2]), u1 = csub(a[0], a[2]), u2 = cadd(a[1], a[3]), u3 = mul_si<SIGN>(csub(a[1], a[3]));
+    b[0] = cadd(u0, u2);
+    b[1] = cadd(u1, u3);
+    b[2] = csub(u0, u2);
+    b[3] = csub(u1, u3);
+  } else {
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+    const double2 t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+    const double2 r1 = make_double2(a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y);
+    const double2 r2 = make_double2(a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y);
+    const double2 i1 = mul_si<SIGN>(make_double2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
+    const double2 i2 = mul_si<SIGN>(make_double2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+    b[0] = make_double2(a[0].x + t1.x + t2.x, a[0].y + t1.y + t2.y);
+    b[1] = cadd(r1, i1);
+    b[2] = cadd(r2, i2);
+    b[3] = csub(r2, i2);
+    b[4] = csub(r1, i1);
+  }
+}
+
+template <int SIGN, int R, int ZCT>
+__device__ inline void stage_inplace(double2* __restrict__ buf, int N, int n_cur, int s, int Ls,
+                                     const double2* __restrict__ tw) {
+  constexpr int KMAX = (8 + R - 1) / R;
+  const int mm = n_cur / R;
+  const int total = (N / R) * ZCT;
+  const float inv_s = 1.0f / (float)s;
+  double2 out[KMAX][R];
+#pragma unroll
+  for (int u = 0; u < KMAX; ++u) {
+    const int i = threadIdx.x + u * TPB;
+    if (i < total) {
+      const int m = i & (ZCT - 1), bf = i / ZCT;
+      const int p = (int)(((float)bf + 0.5f) * inv_s), q = bf - p * s;
+      const double2* xi = buf + (q + s * p) * Ls + m;
+      const int sin_ = s * mm * Ls;
+      double2 a[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) a[k] = xi[k * sin_];
+      butterfly_r<SIGN, R>(a, out[u]);
+      const int tstep = p * s;           // < N
+      int t = tstep;
+#pragma unroll
+      for (int j = 1; j < R; ++j) {
+        out[u][j] = cmul(out[u][j], twid<SIGN>(tw, t));
+        t += tstep;
+        if (t >= N) t -= N;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < KMAX; ++u) {
+    const int i = threadIdx.x + u * TPB;
+    if (i < total) {
+      const int m = i & (ZCT - 1), bf = i / ZCT;
+      const int p = (int)(((float)bf + 0.5f) * inv_s), q = bf - p * s;
+      double2* yo = buf + (q + s * R * p) * Ls + m;
+      const int sout = s * Ls;
+#pragma unroll
+      for (int j = 0; j < R; ++j) yo[j * sout] = out[u][j];
+    }
+  }
+  __syncthreads();
+}
+
+template <int SIGN, int ZCT>
+__device__ inline void fft_inplace(double2* buf, const Axis& ax, int Ls, const double2* tw) {
+  int n_cur = ax.n, s = 1;
+  for (int st = 0; st < ax.nstage; ++st) {
+    const int r = ax.radix[st];
+    if (r == 4) stage_inplace<SIGN, 4, ZCT>(buf, ax.n, n_cur, s, Ls, tw);
+    else if (r == 2) stage_inplace<SIGN, 2, ZCT>(buf, ax.n, n_cur, s, Ls, tw);
+    else if (r == 3) stage_inplace<SIGN, 3, ZCT>(buf, ax.n, n_cur, s, Ls, tw);
+    else stage_inplace<SIGN, 5, ZCT>(buf, ax.n, n_cur, s, Ls, tw);
+    n_cur /= r;
+    s *= r;
+  }
+}
+
+// LDS: [n * Ls complex work buffer][n complex twiddles]
+template <int ZCT>
+__global__ __launch_bounds__(TPB) void z_r2c_fast_kernel(const double* __restrict__ in, double2* __restrict__ out,
+                                                         int64_t nlines, Axis ax) {
+  extern __shared__ double2 lds[];
+  const int n = ax.n, nh = n / 2 + 1;
+  constexpr int Ls = ZCT + 1;
+  double2* x = lds;
+  double2* tw = lds + n * Ls;
+  for (int k = threadIdx.x; k < n; k += TPB) tw[k] = ax.tw[k];
+  const int64_t line0 = (int64_t)blockIdx.x * 2 * ZCT;
+  const int nl = (int)min((int64_t)2 * ZCT, nlines - line0);
+  const double* src = in + line0 * n;
+  const float inv_n = 1.0f / (float)n;
+  for (int c = threadIdx.x; c < 2 * ZCT * n; c += TPB) {
+    const int l = (int)(((float)c + 0.5f) * inv_n), e = c - l * n;
+    const double v = (l < nl) ? src[c] : 0.0;
+    ((double*)(x + e * Ls + (l >> 1)))[l & 1] = v;
+  }
+  __syncthreads();
+  fft_inplace<-1, ZCT>(x, ax, Ls, tw);
+  double2* dstc = out + line0 * nh;
+  const float inv_nh = 1.0f / (float)nh;
+  for (int c = threadIdx.x; c < nl * nh; c += TPB) {
+    const int l = (int)(((float)c + 0.5f) * inv_nh), k = c - l * nh;
+    const int m = l >> 1;
+    const double2 zk = x[k * Ls + m];
+    const double2 zn = x[(k == 0 ? 0 : n - k) * Ls + m];
+    double2 r;
+    if ((l & 1) == 0) r = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
+    else r = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));
+    dstc[c] = r;
+  }
+}
+
+template <int ZCT>
+__global__ __launch_bounds__(TPB) void z_c2r_fast_kernel(const double2* __restrict__ in, double* __restrict__ out,
+                                                         int64_t nlines, Axis ax) {
+  extern __shared__ double2 lds[];
+  const int n = ax.n, nh = n / 2 + 1;
+  constexpr int Ls = ZCT + 1;
+  double2* x = lds;
+  double2* tw = lds + n * Ls;
+  for (int k = threadIdx.x; k < n; k += TPB) tw[k] = ax.tw[k];
+  const int64_t line0 = (int64_t)blockIdx.x * 2 * ZCT;
+  const int nl = (int)min((int64_t)2 * ZCT, nlines - line0);
+  const int M = (nl + 1) / 2;
+  const double2* src = in + line0 * nh;
+  const float inv_nh = 1.0f / (float)nh;
+  // Z_k = A_k + i B_k (k <= n/2),  Z_{n-k} = conj(A_k) + i conj(B_k);  A = even line, B = odd line of the pair
+  for (int c = threadIdx.x; c < M * nh; c += TPB) {
+    const int m = (int)(((float)c + 0.5f) * inv_nh), k = c - m * nh;
+    double2 a = src[(int64_t)(2 * m) * nh + k];
+    double2 b = (2 * m + 1 < nl) ? src[(int64_t)(2 * m + 1) * nh + k] : make_double2(0.0, 0.0);
+    const bool selfconj = (k == 0) || (2 * k == n);
+    if (selfconj) { a.y = 0.0; b.y = 0.0; }
+    x[k * Ls + m] = make_double2(a.x - b.y, a.y + b.x);
+    if (!selfconj) x[(n - k) * Ls + m] = make_double2(a.x + b.y, -a.y + b.x);
+  }
+  __syncthreads();
+  fft_inplace<1, ZCT>(x, ax, Ls, tw);
+  double* dst = out + line0 * n;
+  const float inv_n = 1.0f / (float)n;
+  for (int c = threadIdx.x; c < nl * n; c += TPB) {
+    const int l = (int)(((float)c + 0.5f) * inv_n), e = c - l * n;
+    dst[c] = ((const double*)(x + e * Ls + (l >> 1)))[l & 1];
+  }
+}
+
+template <int MODE, int ZCT>
+__global__ __launch_bounds__(TPB) void strided_fft_fast_kernel(double2* __restrict__ data, int64_t os, int64_t es, int Mtot,
+                                                               Axis ax, int ntile, const double* __restrict__ table) {
+  extern __shared__ double2 lds[];
+  const int n = ax.n;
+  double2* x = lds;
+  double2* tw = lds + n * ZCT;
+  for (int k = threadIdx.x; k < n; k += TPB) tw[k] = ax.tw[k];
+  const int64_t outer = blockIdx.x / ntile;
+  const int m0 = (int)(blockIdx.x % ntile) * ZCT;
+  const int M = min(ZCT, Mtot - m0);
+  double2* base = data + outer * os + m0;
+  for (int c = threadIdx.x; c < n * ZCT; c += TPB) {
+    const int e = c / ZCT, m = c & (ZCT - 1);
+    if (m < M) x[c] = base[(int64_t)e * es + m];
+  }
+  __syncthreads();
+  if (MODE == 1) {
+    fft_inplace<1, ZCT>(x, ax, ZCT, tw);
+  } else {
+    fft_inplace<-1, ZCT>(x, ax, ZCT, tw);
+    if (MODE == 2) {
+      const double* tb = table + m0;
+      for (int c = threadIdx.x; c < n * ZCT; c += TPB) {
+        const int e = c / ZCT, m = c & (ZCT - 1);
+        if (m < M) {
+          const double g = tb[(int64_t)e * es + m];
+          double2 v = x[c];
+          v.x *= g;
+          v.y *= g;
+          x[c] = v;
+        }
+      }
+      __syncthreads();
+      fft_inplace<1, ZCT>(x, ax, ZCT, tw);
+    }
+  }
+  for (int c = threadIdx.x; c < n * ZCT; c += TPB) {
+    const int e = c / ZCT, m = c & (ZCT - 1);
+    if (m < M) base[(int64_t)e * es + m] = x[c];
+  }
+}
+
+template <class F>
+void with_lines(int L, F f) {       // run f with the tile width as a compile-time constant
+  switch (L) {
+    case 16: f(std::integral_constant<int, 16>{}); break;
+    case 8: f(std::integral_constant<int, 8>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    default: f(std::integral_constant<int, 1>{}); break;
+  }
+}
+
+bool smooth235(const Axis& ax) {
+  for (int i = 0; i < ax.nstage; ++i)
+    if (ax.radix[i] > 5) return false;
+  return true;
+}
+int fast_lines(int n) {          // largest power of two <= 16 with n * lines <= 2048
+  for (int L = 16; L >= 1; L >>= 1)
+    if (n * L <= 2048) return L;
+  return 0;
+}
+
+bool factorise(int n, Axis* ax) {
+  ax->n = n;
+  ax->nstage = 0;
+  const int order[4] = {4, 2, 3, 5};
+  for (int r : order)
+    while (n % r == 0 && n > 1) {
+      if (ax->nstage >= MAXSTAGE) return false;
+      ax->radix[ax->nstage++] = r;
+      n /= r;
+    }
+  for (int p = 7; n > 1 && p <= 13; p += 2)
+    while (n % p == 0) {
+      if (ax->nstage >= MAXSTAGE) return false;
+      ax->radix[ax->nstage++] = p;
+      n /= p;
+    }
+  return n == 1;
+}
+
+int lines_per_tile(int n, int pad) {
+  // two LDS buffers of n x (L + pad) complex numbers within 64 KB (two workgroups per CU)
+  for (int L = 16; L >= 1; L >>= 1)
+    if ((size_t)2 * n * (L + pad) * sizeof(double2) <= 64 * 1024) return L;
+  return 0;
+}
+
+}  // namespace
+
+// Whether conv_rows_own can take this mesh.
+bool conv_rows_own_supported(const int32_t mesh[3]) {
+  for (int d = 0; d < 3; ++d) {
+    Axis ax;
+    if (mesh[d] < 1 || mesh[d] > 1024 || !factorise(mesh[d], &ax)) return false;
+    if (lines_per_tile(mesh[d], d == 2 ? 1 : 0) < 1) return false;
+  }
+  return true;
+}
+
+// d_out (nb rows of G reals) = ifft(cg * fft(d_in rows)) with cg the scaled half-spectrum table of coulomb.hip
+// (n0, n1, n2/2+1); zbuf: nb * gc complex scratch.  In place (d_out == d_in) allowed.
+int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, const int32_t mesh[3], const double* cg,
+                  double2* zbuf) {
+  const int n0 = mesh[0], n1 = mesh[1], n2 = mesh[2], n2h = n2 / 2 + 1;
+  Axis ax[3];
+  for (int d = 0; d < 3; ++d) {
+    if (!factorise(mesh[d], &ax[d])) return isdf_fail(h, ISDF_ERR_ARG, "conv_rows_own: unsupported mesh dimension %d", mesh[d]);
+    char name[32];
+    snprintf(name, sizeof(name), "fft_tw_%d", mesh[d]);
+    const bool fresh = h->ws.find(name) == h->ws.end();
+    double2* tw = (double2*)isdf_ws(h, name, sizeof(double2) * (size_t)mesh[d]);
+    if (!tw) return ISDF_ERR_HIP;
+    if (fresh) {
+      std::vector<double2> host(mesh[d]);
+      for (int k = 0; k < mesh[d]; ++k) {
+        const double t = -2.0 * 3.14159265358979323846 * (double)k / (double)mesh[d];
+        host[k] = make_double2(cos(t), sin(t));
+      }
+      HIP_TRY(h, hipMemcpyAsync(tw, host.data(), sizeof(double2) * (size_t)mesh[d], hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    ax[d].tw = tw;
+  }
+  const int64_t gc = (int64_t)n0 * n1 * n2h;
+  const int64_t nlines = (int64_t)nb * n0 * n1;
+  ARG_CHECK(h, nlines * 4 < 2147483647LL && (int64_t)nb * cdiv((int64_t)n1 * n2h, 1) < 2147483647LL);
+  const int LP = lines_per_tile(n2, 1);
+  const int ZY = lines_per_tile(n1, 0), ZX = lines_per_tile(n0, 0);
+  if (LP < 1 || ZY < 1 || ZX < 1) return isdf_fail(h, ISDF_ERR_ARG, "conv_rows_own: mesh too large for the LDS tiles");
+  const int64_t G = (int64_t)n0 * n1 * n2;
+  ProfScope ps(h, "coulomb_conv_own_5pass[byte]", 32.0 * (double)G * nb, 5);
+  const int FZ = fast_lines(n2), FY = fast_lines(n1), FX = fast_lines(n0);
+  if (smooth235(ax[0]) && smooth235(ax[1]) && smooth235(ax[2]) && FZ >= 1 && FY >= 1 && FX >= 1) {
+    const size_t ldsz = sizeof(double2) * ((size_t)n2 * (FZ + 1) + n2);
+    const size_t ldsy = sizeof(double2) * ((size_t)n1 * FY + n1), ldsx = sizeof(double2) * ((size_t)n0 * FX + n0);
+    const int nty = (int)cdiv(n2h, FY), ntx = (int)cdiv((int64_t)n1 * n2h, FX);
+    const dim3 gz((unsigned)cdiv(nlines, 2 * FZ)), gy((unsigned)((int64_t)nb * n0 * nty)), gx((unsigned)((int64_t)nb * ntx));
+    hipStream_t st = h->stream;
+    with_lines(FZ, [&](auto z) {
+      z_r2c_fast_kernel<decltype(z)::value><<<gz, dim3(TPB), ldsz, st>>>(d_in, zbuf, nlines, ax[2]);
+    });
+    with_lines(FY, [&](auto z) {
+      strided_fft_fast_kernel<0, decltype(z)::value><<<gy, dim3(TPB), ldsy, st>>>(zbuf, (int64_t)n1 * n2h, (int64_t)n2h, n2h, ax[1],
+                                                                                 nty, (const double*)nullptr);
+    });
+    with_lines(FX, [&](auto z) {
+      strided_fft_fast_kernel<2, decltype(z)::value><<<gx, dim3(TPB), ldsx, st>>>(zbuf, gc, (int64_t)n1 * n2h, n1 * n2h, ax[0], ntx, cg);
+    });
+    with_lines(FY, [&](auto z) {
+      strided_fft_fast_kernel<1, decltype(z)::value><<<gy, dim3(TPB), ldsy, st>>>(zbuf, (int64_t)n1 * n2h, (int64_t)n2h, n2h, ax[1],
+                                                                                 nty, (const double*)nullptr);
+    });
+    with_lines(FZ, [&](auto z) {
+      z_c2r_fast_kernel<decltype(z)::value><<<gz, dim3(TPB), ldsz, st>>>(zbuf, d_out, nlines, ax[2]);
+    });
+    KERNEL_CHECK(h);
+    return ISDF_OK;
+  }
+  // GENERIC path (a factor 7, 11 or 13): two LDS buffers
+  {
+    const size_t lds = (size_t)2 * n2 * (LP + 1) * sizeof(double2);
+    hipLaunchKernelGGL(z_r2c_kernel, dim3((unsigned)cdiv(nlines, 2 * LP)), dim3(TPB), lds, h->stream, d_in, zbuf, nlines,
+                       ax[2], LP);
+  }
+  {
+    const size_t lds = (size_t)2 * n1 * ZY * sizeof(double2);
+    const int nt = (int)cdiv(n2h, ZY);
+    hipLaunchKernelGGL(strided_fft_kernel<0>, dim3((unsigned)((int64_t)nb * n0 * nt)), dim3(TPB), lds,
+                       h->stream, zbuf, (int64_t)n1 * n2h, (int64_t)n2h, n2h, ax[1], ZY, nt, (const double*)nullptr);
+  }
+  {
+    const size_t lds = (size_t)2 * n0 * ZX * sizeof(double2);
+    const int nt = (int)cdiv((int64_t)n1 * n2h, ZX);
+    hipLaunchKernelGGL(strided_fft_kernel<2>, dim3((unsigned)((int64_t)nb * nt)), dim3(TPB), lds,
+                       h->stream, zbuf, gc, (int64_t)n1 * n2h, n1 * n2h, ax[0], ZX, nt, cg);
+  }
+  {
+    const size_t lds = (size_t)2 * n1 * ZY * sizeof(double2);
+    const int nt = (int)cdiv(n2h, ZY);
+    hipLaunchKernelGGL(strided_fft_kernel<1>, dim3((unsigned)((int64_t)nb * n0 * nt)), dim3(TPB), lds,
+                       h->stream, zbuf, (int64_t)n1 * n2h, (int64_t)n2h, n2h, ax[1], ZY, nt, (const double*)nullptr);
+  }
+  {
+    const size_t lds = (size_t)2 * n2 * (LP + 1) * sizeof(double2);
+    hipLaunchKernelGGL(z_c2r_kernel, dim3((unsigned)cdiv(nlines, 2 * LP)), dim3(TPB), lds, h->stream, zbuf, d_out, nlines,
+                       ax[2], LP);
+  }
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}

@@ -9,7 +9,7 @@ WORKLOADS = {
     'diamond-222-dzvp-80': (lambda: gto.diamond_supercell(2, 'gth-dzvp', (80, 80, 80)),
                             'configs[1]: diamond 2x2x2, gth-dzvp, 80^3, c_isdf=10'),
     'diamond-444-dzvp-120': (lambda: gto.diamond_supercell(4, 'gth-dzvp', (120, 120, 120)),
-                             'configs[2]: diamond 4x4x4, gth-dzvp, 120^3, c_isdf=10'),
+                             'configs[2]: diamond 4x4x4, gth-dzvp, 120^3'),
     'diamond-333-dzvp-96': (lambda: gto.diamond_supercell(3, 'gth-dzvp', (96, 96, 96)),
                             'intermediate: diamond 3x3x3, gth-dzvp, 96^3'),
     'water64-dzvp-160': (lambda: water64('gth-dzvp', (160, 160, 160)),

@@ -253,6 +253,35 @@ def test_coulomb_W(be, mk):
     assert abs(got[3:7] - ref[3:7]).max() < 1e-10 * abs(ref).max() and abs(got[:3]).max() == 0 and abs(got[7:]).max() == 0
 
 
+@pytest.mark.parametrize('mesh,nrow', [((12, 12, 12), 5), ((21, 21, 21), 3), ((10, 9, 8), 37), ((11, 9, 7), 4), ((16, 20, 24), 7),
+                                       ((26, 14, 22), 2), ((5, 3, 2), 9), ((1, 4, 6), 3), ((17, 8, 8), 3), ((40, 40, 40), 33)])
+def test_own_fft_convolution_matches_oracle_and_hipfft(be, mesh, nrow):
+    """S4 through the hand-written five-pass FFT (fft_conv.hip: radices 4/2/3/5 and the generic 7/11/13 butterflies, odd and
+    even lengths, odd line counts, several tiles) against the oracle's complex FFT + .real on a triclinic lattice
+    (<= 1e-12 of the largest value) and against the hipFFT path of the same library (own_fft = 0); (17, 8, 8) has a prime
+    factor above 13 and must take the hipFFT fallback with the same answer."""
+    rng = np.random.default_rng(sum(mesh) + nrow)
+    a = np.array([[4.1, 0.3, -0.2], [0.5, 3.7, 0.4], [-0.3, 0.6, 4.4]])
+    G = int(np.prod(mesh))
+    rows = rng.standard_normal((nrow, G))
+    ref = oisdf.coulomb_V(rows, a, np.asarray(mesh))
+    out = {}
+    for own in (1, 0):
+        be.set_option('own_fft', own)
+        d = be.to_device(rows)
+        be.coulomb_rows(d, np.asarray(mesh), a, max(1, nrow // 2 + 1))          # two batches, the second one smaller
+        out[own] = be.to_host(d)
+    be.set_option('own_fft', 1)
+    scale = abs(ref).max()
+    assert abs(out[1] - ref).max() < 1e-12 * scale
+    assert abs(out[0] - ref).max() < 1e-12 * scale
+    # out of place keeps the input
+    d_in = be.to_device(rows)
+    d_out = be.empty((nrow, G))
+    be.coulomb_rows(d_in, np.asarray(mesh), a, nrow, out=d_out)
+    assert np.array_equal(be.to_host(d_in), rows) and abs(be.to_host(d_out) - ref).max() < 1e-12 * scale
+
+
 def test_get_j_matches_fftdf_pin(be):
     """S6 vs the oracle AND the reference's known-answer fp(vj) (test_fft.py:643-644)."""
     cell = cells.cell_he_c()
