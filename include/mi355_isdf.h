@@ -61,6 +61,10 @@ int isdf_set_option(isdf_handle h, const char* key, int value);
  * pyscf/pbc/tools/pbc.py:408-418: omega > 0 long range (erf(omega r)/r), omega < 0 short range, 0 (default) plain 1/r.
  * (The k-point entry points take their kernel table from the caller.) */
 int isdf_set_coulomb_omega(isdf_handle h, double omega);
+/* Spherical truncation of the Coulomb kernel, exxdiv='vcut_sph' of the reference (pyscf/pbc/tools/pbc.py:312-317):
+ * 4 pi / G^2 (1 - cos(|G| rc)), G = 0 -> 2 pi rc^2, with rc = (3 Nk vol / 4 pi)^(1/3) chosen by the caller; rc = 0 (default)
+ * switches it off.  Applies to every kernel table built afterwards, isdf_coulG_q included; not combined with omega. */
+int isdf_set_coulomb_cutoff(isdf_handle h, double rc);
 
 /* Optional in-library profiling (bench.py's roofline leg): when enabled, the library brackets its
  * hot kernel launches with HIP events on the work stream and accumulates, per kernel name, the number

@@ -118,16 +118,17 @@ def fit_theta_normal_equations(aoT, piv):
     return np.linalg.lstsq(A, B, rcond=None)[0]
 
 
-def coulomb_V(theta, a, mesh, omega=None):
-    """V_P = ifft(coulG * fft(Theta_P)).real, rows over P (k, G); omega: range separation (pbc.py:408-418)."""
-    coulG = tools.get_coulG(a, mesh, omega=omega)
+def coulomb_V(theta, a, mesh, omega=None, rc=None):
+    """V_P = ifft(coulG * fft(Theta_P)).real, rows over P (k, G); omega: range separation (pbc.py:408-418); rc: spherical
+    truncation (exxdiv='vcut_sph', pbc.py:312-317)."""
+    coulG = tools.get_coulG(a, mesh, omega=omega, rc=rc)
     return tools.ifft(tools.fft(theta, mesh) * coulG, mesh).real
 
 
-def build_W(theta, a, mesh, omega=None):
+def build_W(theta, a, mesh, omega=None, rc=None):
     G = theta.shape[1]
     w = abs(np.linalg.det(a)) / G
-    V = coulomb_V(theta, a, mesh, omega)
+    V = coulomb_V(theta, a, mesh, omega, rc)
     return w * V.dot(theta.T)
 
 

@@ -44,8 +44,9 @@ def get_Gv(b, mesh):
     return Gv.reshape(-1, 3)
 
 
-def get_coulG(a, mesh, k=np.zeros(3), wrap_around=True, omega=None):
-    """Coulomb kernel on the FFT mesh for lattice ``a`` (3,3 Bohr); exxdiv=None semantics."""
+def get_coulG(a, mesh, k=np.zeros(3), wrap_around=True, omega=None, rc=None):
+    """Coulomb kernel on the FFT mesh for lattice ``a`` (3,3 Bohr); exxdiv=None semantics, or - rc given - the spherically
+    truncated kernel of exxdiv='vcut_sph' (pbc.py:312-317) with Rc = rc."""
     a = np.asarray(a, dtype=float)
     b = 2 * np.pi * np.linalg.inv(a.T)
     Gv = get_Gv(b, mesh)
@@ -67,9 +68,11 @@ def get_coulG(a, mesh, k=np.zeros(3), wrap_around=True, omega=None):
             kG[on_edge[:, x] == 1] -= 2 * box_edge[x]
             kG[on_edge[:, x] == -1] += 2 * box_edge[x]
     absG2 = np.einsum('gi,gi->g', kG, kG)
-    with np.errstate(divide='ignore'):
+    with np.errstate(divide='ignore', invalid='ignore'):
         coulG = 4 * np.pi / absG2
-    coulG[absG2 == 0] = 0
+        if rc:
+            coulG = coulG * (1.0 - np.cos(np.sqrt(absG2) * rc))
+    coulG[absG2 == 0] = 4 * np.pi * 0.5 * rc ** 2 if rc else 0
     if equal2boundary is not None:
         coulG[equal2boundary] = 0
     if omega:                                   # range separation, pyscf/pbc/tools/pbc.py:408-418

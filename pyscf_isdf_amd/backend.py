@@ -51,6 +51,9 @@ class HipBackend:
     def set_coulomb_omega(self, omega):
         self.handle.call('isdf_set_coulomb_omega', float(omega or 0.0))
 
+    def set_coulomb_cutoff(self, rc):
+        self.handle.call('isdf_set_coulomb_cutoff', float(rc or 0.0))
+
     def set_option(self, key, value):
         self.handle.call('isdf_set_option', key.encode(), int(value))
 

@@ -47,6 +47,8 @@ struct isdf_ctx {
   int own_fft = 1;
   // range-separation parameter of the Gamma-point Coulomb kernel table (0 = plain 1/r); isdf_set_coulomb_omega
   double coul_omega = 0.0;
+  // spherical truncation radius of the Coulomb kernel (exxdiv='vcut_sph', pbc.py:312-317); 0 = none.  isdf_set_coulomb_cutoff
+  double coul_rc = 0.0;
 };
 
 int isdf_fail(isdf_handle h, int code, const char* fmt, ...);

@@ -34,9 +34,16 @@ __device__ inline double range_factor(double g2, double omega) {
   const double e = exp(-0.25 * g2 / (omega * omega));
   return omega > 0.0 ? e : 1.0 - e;
 }
+// 4 pi / G^2 times the range-separation factor, or - rc > 0, exxdiv='vcut_sph' (pbc.py:312-317, PRB 77 193110) - times
+// 1 - cos(|G| rc), the transform of 1/r cut at r = rc; its G -> 0 limit is 2 pi rc^2
+__device__ inline double kernel_value(double g2, double omega, double rc) {
+  const double fourpi = 4.0 * 3.14159265358979323846;
+  if (rc > 0.0) return g2 == 0.0 ? 0.5 * fourpi * rc * rc : fourpi / g2 * (1.0 - cos(sqrt(g2) * rc));
+  return g2 == 0.0 ? 0.0 : fourpi / g2 * range_factor(g2, omega);
+}
 
 __global__ void coulG_half_kernel(double* __restrict__ out, int n0, int n1, int n2, Recip r,
-                                  double scale, double omega) {
+                                  double scale, double omega, double rc) {
   const int n2h = n2 / 2 + 1;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t tot = (int64_t)n0 * n1 * n2h;
@@ -44,13 +51,10 @@ __global__ void coulG_half_kernel(double* __restrict__ out, int n0, int n1, int 
   const int iz = (int)(idx % n2h);
   const int iy = (int)((idx / n2h) % n1);
   const int ix = (int)(idx / ((int64_t)n2h * n1));
-  if (ix == 0 && iy == 0 && iz == 0) { out[idx] = 0.0; return; }
-  const double fourpi = 4.0 * 3.14159265358979323846;
+  if (ix == 0 && iy == 0 && iz == 0) { out[idx] = scale * kernel_value(0.0, omega, rc); return; }
   const double g1 = g2_of(ix, iy, iz, n0, n1, n2, r);
   const double g2 = g2_of((n0 - ix) % n0, (n1 - iy) % n1, (n2 - iz) % n2, n0, n1, n2, r);
-  const double c1 = fourpi / g1 * range_factor(g1, omega);
-  const double c2 = fourpi / g2 * range_factor(g2, omega);
-  out[idx] = scale * 0.5 * (c1 + c2);
+  out[idx] = scale * 0.5 * (kernel_value(g1, omega, rc) + kernel_value(g2, omega, rc));
 }
 
 // Full-spectrum kernel table for a difference vector q (k-point exchange, pyscf/pbc/tools/pbc.py:230-420 with exxdiv=None),
@@ -59,7 +63,7 @@ __global__ void coulG_half_kernel(double* __restrict__ out, int n0, int n1, int 
 // reference's rounding) lie beyond the edge and are wrapped back by 2 (n_i//2) + 1 frequencies (pbc.py:272-302); a component
 // exactly ON the edge (|x_i| = 1) is ambiguous and its table entry is zeroed (pbc.py:400-401).
 __global__ void coulG_q_kernel(double* __restrict__ out, int n0, int n1, int n2, Recip r, double qf0, double qf1,
-                               double qf2, int wrap, double omega) {
+                               double qf2, int wrap, double omega, double rc) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t tot = (int64_t)n0 * n1 * n2;
   if (idx >= tot) return;
@@ -86,8 +90,7 @@ __global__ void coulG_q_kernel(double* __restrict__ out, int n0, int n1, int n2,
   const double gy = c[0] * r.b[1] + c[1] * r.b[4] + c[2] * r.b[7];
   const double gz = c[0] * r.b[2] + c[1] * r.b[5] + c[2] * r.b[8];
   const double g2 = gx * gx + gy * gy + gz * gz;
-  double v = (g2 == 0.0 || edge) ? 0.0 : 4.0 * 3.14159265358979323846 / g2 * range_factor(g2, omega);
-  out[idx] = v;
+  out[idx] = edge ? 0.0 : kernel_value(g2, omega, rc);
 }
 
 __global__ void mul_half_kernel(double2* __restrict__ z, const double* __restrict__ cg, int64_t gc,
@@ -124,7 +127,7 @@ static int get_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9
   Recip rr;
   for (int i = 0; i < 9; ++i) rr.b[i] = b[i];
   hipLaunchKernelGGL(coulG_half_kernel, dim3((unsigned)cdiv(gc, 256)), dim3(256), 0, h->stream, cg, mesh[0],
-                     mesh[1], mesh[2], rr, extra_scale / (double)G, h->coul_omega);
+                     mesh[1], mesh[2], rr, extra_scale / (double)G, h->coul_omega, h->coul_rc);
   KERNEL_CHECK(h);
   *out = cg;
   return ISDF_OK;
@@ -163,7 +166,7 @@ extern "C" int isdf_coulG_q(isdf_handle h, const int32_t mesh[3], const double a
   if (!nonzero) qf[0] = qf[1] = qf[2] = 0.0;
   const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
   hipLaunchKernelGGL(coulG_q_kernel, dim3((unsigned)cdiv(G, 256)), dim3(256), 0, h->stream, d_out, mesh[0], mesh[1],
-                     mesh[2], rr, qf[0], qf[1], qf[2], wrap, omega);
+                     mesh[2], rr, qf[0], qf[1], qf[2], wrap, omega, h->coul_rc);
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

@@ -71,6 +71,13 @@ int isdf_set_coulomb_omega(isdf_handle h, double omega) {
   return ISDF_OK;
 }
 
+int isdf_set_coulomb_cutoff(isdf_handle h, double rc) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, rc >= 0.0);
+  h->coul_rc = rc;
+  return ISDF_OK;
+}
+
 int isdf_set_option(isdf_handle h, const char* key, int value) {
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, key != nullptr);

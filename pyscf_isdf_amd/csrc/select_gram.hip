@@ -225,6 +225,10 @@ extern "C" int isdf_select_ip_gram(isdf_handle h, double* d_A, int m, int64_t ld
       }
       KERNEL_CHECK(h);
     }
+    // one host synchronisation per panel: at most `panel` launches are ever outstanding.  Unbounded, the ~20 000
+    // back-to-back launches of a configs[2] selection overran rocprofv3's counter-collection path (SIGSEGV in the tool at the
+    // first page past one of its buffers, profiles/r02_rocprofv3_pmc_abort_in_select_ip_gram.log); costs < 2 ms per build
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (k0 + nb < nip) {
       // trailing update A <- A - Lp^T Lp (rows of finished pivots become zero rows of the residual)
       int rc = gemm_rm(h, 'T', 'N', m, m, nb, -1.0, d_Lp, ldL, d_Lp, ldL, 1.0, d_A, ldA);

@@ -27,12 +27,13 @@ from .fit_route import FitRouteMixin
 from .sharded import ShardedMixin
 from .kpoints import KPointMixin
 from .hcore import HcoreMixin
+from .eri_surface import EriSurfaceMixin
 
 
-class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
+class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin):
     _keys = {'cell', 'kpts', 'grids', 'mesh', 'blockdim', 'exxdiv', 'c_isdf', 'select', 'tie_rtol'}
 
-    def __init__(self, cell, kpts=np.zeros((1, 3)), c_isdf=10, select='local', backend=None, comm=None):
+    def __init__(self, cell, kpts=np.zeros((1, 3)), c_isdf=10, select='refined', backend=None, comm=None):
         self.cell = cell
         self.stdout = getattr(cell, 'stdout', None) or sys.stdout
         self.verbose = getattr(cell, 'verbose', 0)
@@ -413,7 +414,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         self._refined_by_atom = [chosen[own == b] for b in range(natm)]
         return np.array([len(x) for x in self._refined_by_atom], dtype=np.int32)
 
-    def _refine_pick(self, aoC, cand, P_target, gram=None):
+    def _refine_pick(self, aoC, cand, P_target, gram=None, nh=0):
         """One pivoted Cholesky of the pair-density Gram matrix restricted to the candidate set (aoC: AO values at the
         candidates, (m, nao); isdf_gram_sq + isdf_select_ip_gram, pivot rule pyscf/lib/scipy_helper.py:71-110) picks the
         final P_target points.  Returns their grid indices in pivot order."""
@@ -421,7 +422,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         m = len(cand)
         P_target = min(int(P_target), m)
         A = be.empty((m, m)) if gram is None else gram
-        be.gram_sq(aoC, A)
+        be.gram_sq(aoC, A, nh)                      # nh > 0: k-point (complex) mode, aoC = [Re u | Im u] at the candidates
         piv2 = be.empty((P_target,), dtype=torch.int64)
         r2 = be.select_ip_gram(A, P_target, self.select_tol, self.tie_rtol, piv2)
         chosen = np.asarray(cand)[be.to_host(piv2)[:r2]]
@@ -538,6 +539,28 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
         elif st['kind'] == 'selection':
             be.W_from_factor(st['T'], 1, W)
 
+    def _vcut_sph_radius(self, nk):
+        """Rc of exxdiv='vcut_sph': the sphere with the volume of the nk-fold cell (pbc.py:313)."""
+        return float((3.0 * nk * self.cell.vol / (4.0 * np.pi)) ** (1.0 / 3.0))
+
+    def _W_kernel_variant(self, key, omega=None, cutoff=None):
+        """W rebuilt from the current fit with another Coulomb kernel (range-separated: omega; spherically truncated:
+        cutoff), cached under ``key`` until the next build.  The fit itself does not depend on the kernel."""
+        be = self.backend
+        if key not in self._W_omega:
+            t0 = time.perf_counter()
+            be.set_coulomb_omega(omega or 0.0)
+            be.set_coulomb_cutoff(cutoff or 0.0)
+            try:
+                W = be.empty(tuple(self.W.shape))
+                (self._finish_W_sharded if self._fit_state.get('sharded') else self._finish_W)(W)
+            finally:
+                be.set_coulomb_omega(0.0)
+                be.set_coulomb_cutoff(0.0)
+            self._W_omega[key] = W
+            self._tick('S4S5_coulomb_W_variant', t0)
+        return self._W_omega[key]
+
     def _get_jk_omega(self, dm, hermi, kpts, kpts_band, with_j, with_k, omega, exxdiv):
         """Range-separated J/K (FFTDF.get_jk(omega=...), pyscf/pbc/df/fft.py:298-303): the Coulomb kernel carries
         exp(-G^2/4 omega^2) (omega > 0, long range) or 1 - exp(...) (omega < 0, short range) as pbc.py:408-418 has it.
@@ -587,11 +610,24 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin):
             self._built = False
         if exxdiv is None:
             exxdiv = self.exxdiv
-        if exxdiv not in (None, 'None', 'ewald'):
-            raise NotImplementedError("exxdiv=%r: only None and 'ewald' are implemented" % (exxdiv,))
+        if exxdiv not in (None, 'None', 'ewald', 'vcut_sph'):
+            raise NotImplementedError("exxdiv=%r: None, 'ewald' and 'vcut_sph' are implemented" % (exxdiv,))
         if not self._built:
             self.build()
         be = self.backend
+        if exxdiv == 'vcut_sph' and with_k:
+            # K with the spherically truncated kernel (pbc.py:312-317): its own W, built once from the same fit; J keeps 1/r
+            if self.robust_k:
+                raise NotImplementedError("exxdiv='vcut_sph' with robust_k is not implemented")
+            vj = self.get_jk(dm, hermi, kpts, kpts_band, True, False, None, 'None')[0] if with_j else None
+            W_plain, self.W = self.W, self._W_kernel_variant('vcut_sph', cutoff=self._vcut_sph_radius(1))
+            try:
+                vk = self.get_jk(dm, hermi, kpts, kpts_band, False, True, None, 'None')[1]
+            finally:
+                self.W = W_plain
+            return vj, vk
+        if exxdiv == 'vcut_sph':
+            exxdiv = None
         dm_in = np.asarray(dm)
         if np.iscomplexobj(dm_in):
             if abs(dm_in.imag).max() > 1e-12:

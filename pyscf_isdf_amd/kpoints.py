@@ -65,7 +65,10 @@ class KPointMixin:
             perm = np.argsort(owner, kind='stable').astype(np.int64)
             counts = np.bincount(owner, minlength=cell.natm)
             blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)
-            nip = np.minimum(self.nip_per_atom() * kfac, counts).astype(np.int32)
+            nip_final = np.minimum(self.nip_per_atom() * kfac, counts).astype(np.int32)
+            nip = nip_final
+            if self.select == 'refined':            # per-atom candidates, then one pivoted Cholesky among them (isdf._refine_pick)
+                nip = np.minimum(np.ceil(self.nip_per_atom() * kfac * float(self.refine_over)).astype(np.int64), counts).astype(np.int32)
             kmax = int(nip.max())
             Xs = be.empty((2 * nh, G))
             be.gather_cols(X, be.to_device(perm), Xs)
@@ -75,7 +78,17 @@ class KPointMixin:
             del Xs, L
             piv_h = be.to_host(piv)
             clusters = self._bj_clusters()
-            self.ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for cl in clusters for b in cl]).astype(np.int64)
+            per_atom = [perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(cell.natm)]
+            if self.select == 'refined':
+                cand = np.concatenate(per_atom).astype(np.int64)
+                aoC = be.empty((len(cand), 2 * nh))
+                be.gather_aoP(X, be.to_device(cand), aoC)
+                chosen = self._refine_pick(aoC, cand, int(nip_final.sum()), nh=nh)
+                del aoC
+                own = owner[chosen]
+                per_atom = [chosen[own == b] for b in range(cell.natm)]
+                rank = np.array([len(x) for x in per_atom], dtype=np.int32)
+            self.ip = np.concatenate([per_atom[b] for cl in clusters for b in cl]).astype(np.int64)
             ip_dev = be.to_device(self.ip)
         P = len(self.ip)
         t0 = self._tick('S2_select_ip', t0)
@@ -189,9 +202,9 @@ class KPointMixin:
         kpts_band the result lives on the band k-points, (nband, N, N) [(N, N) for a single (3,) band vector], as
         df_jk._format_jks shapes it (pyscf/pbc/df/df_jk.py:1426-1444)."""
         ex = exxdiv if exxdiv is not None else self.exxdiv
-        if ex not in (None, 'None', 'ewald'):
-            raise NotImplementedError("k-point ISDF: only exxdiv=None and 'ewald' are implemented")
-        if omega and ex == 'ewald':
+        if ex not in (None, 'None', 'ewald', 'vcut_sph'):
+            raise NotImplementedError("k-point ISDF: exxdiv None, 'ewald' and 'vcut_sph' are implemented")
+        if omega and ex in ('ewald', 'vcut_sph'):
             raise NotImplementedError('range-separated J/K: only exxdiv=None is implemented')
         cell, be, comm = self.cell, self.backend, self.comm
         kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
@@ -238,6 +251,16 @@ class KPointMixin:
                 t0 = self._tick('S4S5_coulomb_W_omega', t0)
             Wq_set = self._W_omega[key]
             be.set_coulomb_omega(omega)                          # the J kernel table lives on the device
+        elif ex == 'vcut_sph' and with_k:
+            # exchange with the spherically truncated kernel (pbc.py:312-317, Rc from the nk-fold cell): its own W^q set
+            if 'vcut_sph' not in self._W_omega:
+                be.set_coulomb_cutoff(self._vcut_sph_radius(nk))
+                try:
+                    self._W_omega['vcut_sph'], _, t0 = self._build_Wq(None, t0)
+                finally:
+                    be.set_coulomb_cutoff(0.0)
+                t0 = self._tick('S4S5_coulomb_W_variant', t0)
+            Wq_set = self._W_omega['vcut_sph']
         try:
             vj, vk = self._jk_from_Wq(Wq_set, dms, nk, bidx, planes, out_shape, with_j, with_k, ex, herm_dm, kpts, t0)
         finally:

@@ -110,6 +110,15 @@ def test_coulG_q_kernel_matches_reference_pins_and_oracle(be):
                 assert abs(got - ref).max() < 1e-12 * abs(ref).max()
     with pytest.raises(Exception):
         be.coulG_q([9, 9, 9], eye, np.array([0, 2 * np.pi * 5, 0]))             # outside the first FFT box (pbc.py:281)
+    # exxdiv='vcut_sph' (pbc.py:312-317): 4 pi/|q+G|^2 (1 - cos(|q+G| Rc)), |q+G| = 0 -> 2 pi Rc^2
+    be.set_coulomb_cutoff(5.3)
+    try:
+        for qv in (np.zeros(3), np.array([0.13, -0.2, 0.31])):
+            ref = otools.get_coulG(al, [10, 8, 6], qv, rc=5.3)
+            got = be.to_host(be.coulG_q([10, 8, 6], al, qv))
+            assert abs(got - ref).max() < 1e-11 * abs(ref).max() and abs(got[0] - ref[0]) < 1e-12 * ref[0]
+    finally:
+        be.set_coulomb_cutoff(0.0)
 
 
 def test_coulomb_Wq(be):
@@ -131,7 +140,7 @@ def test_coulomb_Wq(be):
         assert abs(be.to_host(Wc) - ref).max() < 1e-10 * abs(ref).max()
 
 
-@pytest.mark.parametrize('select', ['global', 'local'])
+@pytest.mark.parametrize('select', ['global', 'local', 'refined'])
 def test_isdf_kpts_end_to_end(select):
     """ISDF(cell, kpts).get_jk: J exact (vs the reference formula), K converging to the exact k-point
     exchange; and equal to the oracle's k-ISDF on the same points."""
@@ -357,3 +366,38 @@ def test_get_pp_reference_pins():
     ref = opp.get_pp(cell._atm, cell._bas, cell._env, cell.atom_coords(), cell.atom_charges(), ps, cell.lattice_vectors(),
                      cell.mesh, coords, [ao], np.zeros((1, 3)))[0]
     assert v0.dtype == np.float64 and abs(v0 - ref).max() < 1e-10
+
+
+def test_supercell_kmesh_cross_check_on_gpu():
+    """k2gamma on the GPU: a [2,2,1] k-mesh on the He2 triclinic cell against the Gamma point of its 2x2x1 supercell (the kind of
+    cross-check pyscf/pbc/scf/test/test_khf.py:73 makes, here for J and K themselves).  J is exact on both sides: the mapped
+    k-blocked J equals the supercell J to 1e-9 and the energies per cell to 1e-10; the two ISDF K agree to their fit error
+    (both at numerical full rank) - which ties the k-point kernels (collocation with phases, coulG(q) with wrap-around,
+    Z2Z convolution, W^q, complex Hadamard K) to the Gamma-point kernels through an identity, not through a shared oracle."""
+    from pyscf_isdf_amd.isdf import ISDF
+    from pyscf_isdf_amd import k2gamma
+    cell = cells.cell_he2_triclinic()
+    cell.mesh = np.array([10, 9, 9])
+    kmesh = [2, 2, 1]
+    kpts = cell.make_kpts(kmesh)
+    nao, nk = cell.nao_nr(), 4
+    scell, phase = k2gamma.get_phase(cell, kpts)
+    rng = np.random.default_rng(8)
+    c = rng.standard_normal((nk, nao, 2))
+    dms = np.einsum('kpi,kqi->kpq', c, c)                       # all four points are time-reversal invariant: real D^k
+    dm_sc = k2gamma.to_supercell_ao_integrals(cell, kpts, dms)
+    assert abs(dm_sc.imag).max() < 1e-13
+    dfk = ISDF(cell, kpts=kpts, c_isdf=30, select='global')
+    dfk.select_tol, dfk.k_ip_factor = 0.0, 4
+    vj, vk = dfk.get_jk(dms, kpts=kpts)
+    dfs = ISDF(scell, c_isdf=30, select='global')
+    dfs.select_tol = 0.0
+    vjs, vks = dfs.get_jk(dm_sc.real)
+    vj_map = k2gamma.to_supercell_ao_integrals(cell, kpts, vj)
+    vk_map = k2gamma.to_supercell_ao_integrals(cell, kpts, vk)
+    assert abs(vj_map.imag).max() < 1e-9 and abs(vj_map.real - vjs).max() < 1e-9
+    assert abs(np.einsum('kij,kji', vj, dms).real - np.einsum('ij,ji', vjs, dm_sc.real)) / 2 / nk < 1e-10
+    assert abs(vk_map.real - vks).max() < 1e-4 * abs(vks).max()
+    ek_k = np.einsum('kij,kji', vk, dms).real / 4 / nk
+    ek_s = np.einsum('ij,ji', vks, dm_sc.real) / 4 / nk
+    assert abs(ek_k - ek_s) < 1e-5 * abs(ek_s)

@@ -553,6 +553,26 @@ def test_robust_k_matches_oracle_and_reduces_the_error(be):
     assert abs(sh.get_jk(dm, with_j=False)[1] - k_rob).max() < 1e-9 * abs(k_rob).max()
 
 
+def test_exxdiv_vcut_sph_matches_oracle_pipeline():
+    """exxdiv='vcut_sph' at the Gamma point on the GPU (half-spectrum kernel table with the truncated kernel, W rebuilt once
+    from the same fit) == the same host driver over the CPU oracle: K within 1e-8 relative; J untouched."""
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(3)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    out = {}
+    for name, backend in (('gpu', None), ('cpu', OracleBackend())):
+        df = ISDF(cell, c_isdf=3, select='local', backend=backend)
+        df.fit_route = 'cholesky'
+        vj0, vk0 = df.get_jk(dm)
+        vj1, vk1 = df.get_jk(dm, exxdiv='vcut_sph')
+        assert abs(vj1 - vj0).max() < 1e-12 and abs(vk1 - vk0).max() > 1e-3 * abs(vk0).max()
+        out[name] = vk1
+    assert abs(out['gpu'] - out['cpu']).max() < 1e-8 * abs(out['cpu']).max()
+
+
 def test_exxdiv_ewald_adds_madelung_SDS():
     """exxdiv='ewald' = exxdiv=None + madelung * S D S (df_jk.py:1446-1452) with the grid-quadrature overlap."""
     from pyscf_isdf_amd.isdf import ISDF

@@ -50,14 +50,16 @@ def test_partition_matches_bruteforce_oracle():
 def test_isdf_surface_and_errors():
     cell = cells.cell_he_c()
     df = ISDF(cell)
-    for name in ('build', 'reset', 'dump_flags', 'check_sanity', 'get_jk', 'get_naoaux', 'update_mf', 'get_ao_eri', 'get_eri'):
+    for name in ('build', 'reset', 'dump_flags', 'check_sanity', 'get_jk', 'get_naoaux', 'update_mf', 'get_ao_eri', 'get_eri',
+                 'ao2mo', 'get_mo_eri', 'get_ao_pairs_G', 'get_ao_pairs', 'get_mo_pairs_G', 'get_mo_pairs', 'loop', 'ao2mo_7d',
+                 'get_nuc', 'get_pp', 'range_coulomb', 'to_gpu'):          # pyscf/pbc/df/fft.py:298-359
         assert callable(getattr(df, name))
     assert list(df.mesh) == [21, 21, 21] and df.grids.weights.shape == (9261,)
     assert abs(df.grids.weights.sum() - cell.vol) < 1e-9
     with pytest.raises(NotImplementedError):                       # range separation: exxdiv=None only
         ISDF(cell, kpts=np.array([[0.1, 0., 0.], [0., 0., 0.]])).get_jk(np.zeros((2, 6, 6)), omega=0.3, exxdiv='ewald')
     with pytest.raises(NotImplementedError):
-        df.get_jk(np.eye(6), exxdiv='vcut_sph')
+        df.get_jk(np.eye(6), exxdiv='vcut_ws')
     with pytest.raises(NotImplementedError):
         ISDF(cell, kpts=np.array([[0.1, 0., 0.], [0., 0., 0.]])).get_jk(np.zeros((2, 6, 6)), exxdiv='vcut_ws')
 

@@ -93,7 +93,7 @@ def _run_kcase(comm):
     rng = np.random.default_rng(2)
     c = rng.standard_normal((2, nao, nao)) + 1j * rng.standard_normal((2, nao, nao))
     dms = np.einsum('kpi,kqi->kpq', c[:, :, :2], c[:, :, :2].conj())
-    df = ISDF(cell, kpts=kpts, c_isdf=4, select='local', backend=OracleBackend(), comm=comm)
+    df = ISDF(cell, kpts=kpts, c_isdf=4, select='refined', backend=OracleBackend(), comm=comm)
     vj, vk = df.get_jk(dms, kpts=kpts)
     return df.ip.copy(), vj, vk
 

@@ -299,3 +299,76 @@ def test_paneled_build_host_logic_with_checker_backend():
     small.max_resident_rows = 3
     with pytest.raises(MemoryError):
         small.build()
+
+
+def test_pair_transforms_and_loop_host_logic_with_checker_backend():
+    """The rest of the with_df surface (pyscf/pbc/df/fft.py:317-345): get_ao_pairs_G reproduces the reference's fp(eri)
+    through (ij|kl) = sum_G conj((G|ij)) coulG vol/G^2 (G|kl) (fft_ao2mo.py:154-184, pin test_fft.py:695), compact and full
+    layouts agree, get_mo_pairs_G is the transformed tensor, and loop() yields three-index blocks whose squares sum to the
+    object's own ERIs (the contract of FFTDF.loop), with get_naoaux() rows in total."""
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    nao = cell.nao_nr()
+    df = ISDF(cell, c_isdf=4, select='global', backend=OracleBackend())
+    G = int(np.prod(cell.mesh))
+    coulG = tools.get_coulG(cell.lattice_vectors(), cell.mesh)
+    pc = df.get_ao_pairs_G(compact=True)
+    assert pc.shape == (G, nao * (nao + 1) // 2) and pc.dtype == np.complex128
+    eri = (pc.conj().T * (coulG * cell.vol / G ** 2)).dot(pc).real
+    assert abs(tools.fp(eri) - 0.80425358275734926) < 1e-8
+    pf = df.get_ao_pairs_G(compact=False)
+    i, j = np.tril_indices(nao)
+    assert pf.shape == (G, nao * nao) and abs(pf.reshape(G, nao, nao)[:, i, j] - pc).max() < 1e-12
+    sl = df.get_ao_pairs_G(shls_slice=(0, 1, 1, 3))
+    loc = cell.ao_loc_nr()
+    assert abs(sl - pf.reshape(G, nao, nao)[:, loc[0]:loc[1], loc[1]:loc[3]].reshape(G, -1)).max() < 1e-12
+    rng = np.random.default_rng(0)
+    ci, cj = rng.standard_normal((nao, 2)), rng.standard_normal((nao, 3))
+    pm = df.get_mo_pairs_G((ci, cj))
+    assert abs(pm - np.einsum('gpq,pi,qj->gij', pf.reshape(G, nao, nao), ci, cj).reshape(G, -1)).max() < 1e-10
+    # a pair of different k-points: the transform of conj(phi^k1) phi^k2 exp(-i q.r), exact exchange-type integral against oracle
+    kpts = np.array([[0.1, 0.2, -0.1], [0.3, -0.1, 0.2]])
+    pk = df.get_ao_pairs_G(kpts)
+    assert pk.shape == (G, nao * nao)
+    coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    a1 = oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpts=kpts, rule='point')
+    ref = tools.fft((a1[0].conj()[:, :, None] * a1[1][:, None, :]).reshape(G, -1).T * np.exp(-1j * coords.dot(kpts[1] - kpts[0])), cell.mesh).T
+    assert abs(pk - ref).max() < 1e-10
+    blocks = list(df.loop(blksize=7))
+    L = np.vstack(blocks)
+    assert all(len(b) <= 7 for b in blocks) and L.shape[1] == nao * (nao + 1) // 2 and len(L) <= df.get_naoaux()
+    assert abs(L.T.dot(L) - df.get_ao_eri(compact=True)).max() < 1e-9
+    with pytest.raises(NotImplementedError):
+        df.ao2mo_7d(np.zeros((1, nao, 2)))
+
+
+def test_vcut_sph_exchange_host_logic_with_checker_backend():
+    """exxdiv='vcut_sph' at the Gamma point through the host driver: K with the kernel 4 pi/G^2 (1 - cos(|G| Rc)), G = 0 ->
+    2 pi Rc^2, Rc = (3 vol / 4 pi)^(1/3) (pyscf/pbc/tools/pbc.py:312-317), equals the oracle's W built with that kernel on
+    the same points; J and the plain K are unchanged; the variant is cached until the next build."""
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(2)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    df = ISDF(cell, c_isdf=3, select='local', backend=OracleBackend())
+    df.fit_route = 'cholesky'
+    vj0, vk0 = df.get_jk(dm)
+    vj1, vk1 = df.get_jk(dm, exxdiv='vcut_sph')
+    assert abs(vj1 - vj0).max() < 1e-13 and list(df._W_omega) == ['vcut_sph']
+    rc = (3 * cell.vol / (4 * np.pi)) ** (1. / 3)
+    aoT = np.ascontiguousarray(oao.eval_ao(cell._atm, cell._bas, cell._env, cell.get_uniform_grids(),
+                                           gto.get_lattice_Ls(cell, rcut=gto.estimate_rcut_per_shell(cell).max()),
+                                           gto.estimate_rcut_per_shell(cell), rule='point').T)
+    th = oisdf.fit_theta_global_chol(aoT, df.ip, reg_rel=df.reg_used)
+    W = oisdf.build_W(th, cell.lattice_vectors(), cell.mesh, rc=rc)
+    k_or = oisdf.get_k(np.ascontiguousarray(aoT[:, df.ip].T), W, dm)
+    assert abs(vk1 - k_or).max() < 1e-9 * abs(k_or).max()
+    assert abs(vk1 - vk0).max() > 1e-3 * abs(vk0).max()
+    assert abs(df.get_jk(dm, with_j=False)[1] - vk0).max() < 1e-13           # the plain W is still in place
+    df.build()
+    assert df._W_omega == {}

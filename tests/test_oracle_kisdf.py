@@ -106,3 +106,52 @@ def test_kpoint_ao_eri_host_logic_with_checker_backend():
     assert abs(otools.fp(eri4) - (0.33709288394542991 - 0.94185725001175313j)) < 2e-4
     with pytest.raises(ValueError):
         df.get_ao_eri(kpts[:3])
+
+
+def test_supercell_kmesh_cross_check_with_checker_backend():
+    """k2gamma: a [2,1,1] k-mesh on the He2 cell == the Gamma point of the 2x1x1 supercell (the cross-check of
+    pyscf/pbc/scf/test/test_khf.py:73, here on J and K themselves): the k-blocked J maps onto the supercell J to 1e-9
+    (both exact), energies per cell agree, K agrees to the fit error at (numerical) full rank, and the phase table is unitary."""
+    import cells
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    from pyscf_isdf_amd import k2gamma
+    cell = cells.cell_he2_triclinic()
+    cell.mesh = np.array([9, 9, 9])
+    kmesh = [2, 1, 1]
+    kpts = cell.make_kpts(kmesh)
+    nao, nk = cell.nao_nr(), 2
+    assert k2gamma.kpts_to_kmesh(cell, kpts) == kmesh
+    scell, phase = k2gamma.get_phase(cell, kpts)
+    assert abs(phase.conj().T.dot(phase) - np.eye(nk)).max() < 1e-14 and scell.nao_nr() == nk * nao
+    assert list(scell.mesh) == [18, 9, 9]
+    rng = np.random.default_rng(8)
+    c = rng.standard_normal((nk, nao, 2))
+    dms = np.einsum('kpi,kqi->kpq', c, c)                       # real symmetric at the two time-reversal invariant points
+    dm_sc = k2gamma.to_supercell_ao_integrals(cell, kpts, dms)
+    assert abs(dm_sc.imag).max() < 1e-13
+    assert abs(k2gamma.to_kpts_ao_integrals(cell, kpts, dm_sc) - dms).max() < 1e-13
+    dfk = ISDF(cell, kpts=kpts, c_isdf=30, select='global', backend=OracleBackend())
+    dfk.select_tol, dfk.k_ip_factor = 0.0, 2
+    vj, vk = dfk.get_jk(dms, kpts=kpts)
+    dfs = ISDF(scell, c_isdf=30, select='global', backend=OracleBackend())
+    dfs.select_tol = 0.0
+    vjs, vks = dfs.get_jk(dm_sc.real)
+    vj_map = k2gamma.to_supercell_ao_integrals(cell, kpts, vj)
+    vk_map = k2gamma.to_supercell_ao_integrals(cell, kpts, vk)
+    assert abs(vj_map.imag).max() < 1e-10 and abs(vj_map.real - vjs).max() < 1e-9
+    ej_k = np.einsum('kij,kji', vj, dms).real / 2 / nk
+    ej_s = np.einsum('ij,ji', vjs, dm_sc.real) / 2 / nk
+    assert abs(ej_k - ej_s) < 1e-10
+    assert abs(vk_map.real - vks).max() < 1e-4 * abs(vks).max()
+    ek_k = np.einsum('kij,kji', vk, dms).real / 4 / nk
+    ek_s = np.einsum('ij,ji', vks, dm_sc.real) / 4 / nk
+    assert abs(ek_k - ek_s) < 1e-5 * abs(ek_s)
+    # exxdiv='vcut_sph' (pbc.py:312-317): the k-mesh's cutoff sphere has the volume of nk cells = the supercell's own, so
+    # the identity holds for the truncated kernel as well; J is untouched, K changes by a finite amount
+    vjc, vkc = dfk.get_jk(dms, kpts=kpts, exxdiv='vcut_sph')
+    vjsc, vksc = dfs.get_jk(dm_sc.real, exxdiv='vcut_sph')
+    assert abs(vjc - vj).max() < 1e-12 and abs(vjsc - vjs).max() < 1e-12
+    assert abs(k2gamma.to_supercell_ao_integrals(cell, kpts, vkc).real - vksc).max() < 1e-4 * abs(vksc).max()
+    assert abs(vksc - vks).max() > 1e-3 * abs(vks).max()
+    assert sorted(k for k in dfk._W_omega) == ['vcut_sph'] and 'vcut_sph' in dfs._W_omega

@@ -9,7 +9,8 @@ dst, srcs = sys.argv[1], sys.argv[2:]
 
 def short(name):
     m = re.search(r'(gemm_nt_mfma_kernel(?:_[bd])?(?:<(?:true|false)>)?|update_kernel|eval_ao_kernel\w*|Cijk_\w{0,24}|fft_rtc_\w+?_len\d+\w*?dim\d|pair_rows\w*|'
-                  r'mul_coulG\w*|take_pivot\w*|square\w*kernel|transpose\w*kernel|trsm\w*|potrf\w*|larf\w*|syrk\w*)', name)
+                  r'mul_coulG\w*|take_pivot\w*|z_r2c\w*kernel(?:<[^>]*>)?|z_c2r\w*kernel(?:<[^>]*>)?|strided_fft\w*kernel(?:<[^>]*>)?|gram_pivot_step_kernel|block_forward_kernel|skinny_rows_kernel|select_update\w*|'
+                  r'square\w*kernel|transpose\w*kernel|trsm\w*|potrf\w*|larf\w*|syrk\w*)', name)
     return m.group(1) if m else name[:60]
 
 
