@@ -4,9 +4,11 @@
 // reference's pivoted_cholesky_python applied to A itself, organised like LAPACK's dpstrf:
 //
 //   * right-looking in panels of nb pivots: after a panel, the trailing matrix is updated in place,
-//     A <- A - Lp^T Lp (one m x m x nb GEMM), so a pivot column is one contiguous row of A (A stays symmetric) minus the
-//     contributions of the CURRENT panel only — 8*m*(1 + j_in_panel) bytes per pivot instead of 8*m*j for the
-//     left-looking form (33 TB -> 0.6 TB at m = 33280, P = 16640);
+//     A <- A - Lp^T Lp, so a pivot column is one row of A minus the contributions of the CURRENT panel only —
+//     8*m*(1 + j_in_panel) bytes per pivot instead of 8*m*j for the left-looking form (33 TB -> 0.6 TB at m = 33280,
+//     P = 16640).  Only the BLOCK-LOWER part of A is kept up to date (column strips of SW columns, each updated from its
+//     own first row down: half the flops of the full m x m x nb product); entry (p, i) of the symmetric matrix is read as
+//     A[p][i] where row p lies in or below i's strip and as A[i][p] otherwise;
 //   * ONE launch per pivot.  Every workgroup owns 256 columns.  It first finds the pivot redundantly from the
 //     per-workgroup maxima of the previous step (nwg doubles) and the 256 residual diagonals of the first workgroup
 //     within the tie tolerance, then stages the panel entries of the pivot (pl[t] = Lp[t, p]) in LDS and updates its own
@@ -20,6 +22,7 @@
 namespace {
 
 constexpr int TPB = 256;
+constexpr int SW = 2048;       // strip width of the block-lower trailing update (a multiple of TPB)
 
 struct GramState {
   double tol;
@@ -158,7 +161,8 @@ __global__ __launch_bounds__(TPB) void gram_pivot_step_kernel(
       row = 0.0;
       dnew = -1.0;
     } else {
-      double col = A[(int64_t)p * ldA + i];
+      // symmetric read from the block-lower part: (p, i) is current iff p >= first row of i's strip
+      double col = (p >= (i / SW) * SW) ? A[(int64_t)p * ldA + i] : A[(int64_t)i * ldA + p];
       const double* __restrict__ pL = Lp + i;
 #pragma unroll 8
       for (int t = 0; t < jl; ++t) col = fma(-pL[(int64_t)t * ldL], s_pl[t], col);
@@ -230,9 +234,13 @@ extern "C" int isdf_select_ip_gram(isdf_handle h, double* d_A, int m, int64_t ld
     // first page past one of its buffers, profiles/r02_rocprofv3_pmc_abort_in_select_ip_gram.log); costs < 2 ms per build
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (k0 + nb < nip) {
-      // trailing update A <- A - Lp^T Lp (rows of finished pivots become zero rows of the residual)
-      int rc = gemm_rm(h, 'T', 'N', m, m, nb, -1.0, d_Lp, ldL, d_Lp, ldL, 1.0, d_A, ldA);
-      if (rc != ISDF_OK) return rc;
+      // trailing update A <- A - Lp^T Lp on the block-lower part: strip [c0, c1) from its first row down
+      for (int c0 = 0; c0 < m; c0 += SW) {
+        const int c1 = c0 + SW < m ? c0 + SW : m;
+        int rc = gemm_rm(h, 'T', 'N', m - c0, c1 - c0, nb, -1.0, d_Lp + c0, ldL, d_Lp + c0, ldL, 1.0,
+                         d_A + (int64_t)c0 * ldA + c0, ldA);
+        if (rc != ISDF_OK) return rc;
+      }
     }
   }
   GramState hst;

@@ -54,10 +54,20 @@ class FitRouteMixin:
         big = int(np.diff(ip_off).max())
         if nrows_max < big:
             raise MemoryError('ISDF: not enough device memory for one block of %d fit rows' % big)
+        # the LAST panel is made as large as memory allows: rows of earlier panels are the ones that get recomputed
+        # (panel p is recomputed once for every later panel), so the early panels should be the small ones
         npan = max(1, -(-P // int(nrows_max)))
         while True:
-            # cut at the block boundaries nearest to k P / npan
-            cuts = sorted({int(ip_off[np.abs(ip_off - k * P / npan).argmin()]) for k in range(1, npan)} | {0, P})
+            cuts = [P]
+            for k in range(npan - 1):
+                want = max(cuts[-1] - int(nrows_max), 0)
+                # first block boundary at or above `want` (the panel above it then has at most nrows_max rows)
+                b = int(ip_off[np.searchsorted(ip_off, want, side='left')])
+                if b >= cuts[-1]:
+                    break
+                cuts.append(b)
+            cuts.append(0)
+            cuts = sorted(set(cuts))
             panels = [(x, y) for x, y in zip(cuts[:-1], cuts[1:]) if y > x]
             if all(y - x <= nrows_max for x, y in panels):
                 return panels

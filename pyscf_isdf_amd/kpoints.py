@@ -101,7 +101,7 @@ class KPointMixin:
         self._qs, self._qindex = pbc_tools.unique_q(kpts_scf, band)      # index[k1 in band][k2 in kpts]
         nq = len(self._qs)
         w = cell.vol / G
-        batch = self.fft_batch or max(1, min(P, int((3 << 30) // (8 * G)) // 128 * 128 or 64))
+        batch = self.fft_batch or max(1, min(P, int((4 << 30) // (8 * G)) // 256 * 256 or int((4 << 30) // (8 * G)) // 128 * 128 or 64))   # 256-row multiples: the 256x128 GEMM tile
         partner = -np.ones(nq, dtype=int)
         for iq in range(nq):
             for jq in range(nq):

@@ -128,3 +128,47 @@ def test_config4_water64_largest_single_gpu_mesh_vs_exact_exchange():
     k_exact = df.get_k_exact(mo_coeff=c, mo_occ=occ)
     assert abs(_ek(vk, dm) - _ek(k_exact, dm)) < 1e-5 * cell.natm
     df.reset()
+
+
+def test_config3_mgo_kmesh_properties_reduced_cell():
+    """configs[3] (MgO rocksalt, gth-dzvp, 2x2x2 k-mesh) on the 2x2x2 cell with a 64^3 mesh (the 3x3x3 / 96^3 run takes two
+    minutes on one GPU and is recorded in profiles/r02_cfg4_mgo333_k222_single_gpu.log): size-independent properties of the
+    k-point path - J and K Hermitian at every k, linear in the density matrices, the +-q pairing consistent
+    (J, K from D and from conj(D) at -k related by complex conjugation: the 2x2x2 mesh maps onto itself under k -> -k; exact
+    for J, to the fit error for K)."""
+    import torch
+    from pyscf_isdf_amd.isdf import ISDF
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
+        pytest.skip('needs a large device')
+    name = 'mgo-222-dzvp-k222'
+    cell = workloads.make_cell(name)
+    kpts = workloads.make_kpts(name, cell)
+    nk, nao = len(kpts), cell.nao_nr()
+    rng = np.random.default_rng(20240203)
+    occ = np.zeros(nao); occ[:cell.nelectron // 2] = 2
+    dms = []
+    for k in range(nk):
+        c = np.linalg.qr(rng.standard_normal((nao, nao)) + 1j * rng.standard_normal((nao, nao)))[0]
+        dms.append((c * occ).dot(c.conj().T))
+    dms = np.array(dms)
+    df = ISDF(cell, kpts=kpts, c_isdf=10, select='refined')
+    vj, vk = df.get_jk(dms, kpts=kpts)
+    assert vj.shape == vk.shape == (nk, nao, nao)
+    assert abs(vj - vj.conj().transpose(0, 2, 1)).max() < 1e-9 and abs(vk - vk.conj().transpose(0, 2, 1)).max() < 1e-8 * abs(vk).max()
+    vj2, vk2 = df.get_jk(np.stack([dms, -0.5 * dms]), kpts=kpts)
+    assert abs(vj2[1] + 0.5 * vj).max() < 1e-9 and abs(vk2[1] + 0.5 * vk).max() < 1e-9 * abs(vk).max()
+    # time reversal: the mesh is symmetric under k -> -k (mod G); with D'^{k} = conj(D^{-k}) the results obey K'^{k} = conj(K^{-k})
+    a = cell.lattice_vectors()
+    frac = kpts.dot(a.T) / (2 * np.pi)
+    minus = [int(np.argmin(abs(((frac + f) - np.round(frac + f))).sum(axis=1))) for f in frac]      # index of -k (mod G)
+    dms_tr = np.array([dms[minus[k]].conj() for k in range(nk)])
+    vj_tr, vk_tr = df.get_jk(dms_tr, kpts=kpts)
+    # J is exact: the relation holds to rounding.  The ISDF K obeys it to its FIT error only: -k = k + G0 on this mesh, and the
+    # fitted exchange at q = k2 - k1 and at q - G0 differ by the interpolation error of exp(i G0.r) x the pair products
+    # (measured 1.6e-5 relative at c = 10) - the same size as the error against the exact exchange
+    assert abs(vj_tr - np.array([vj[minus[k]].conj() for k in range(nk)])).max() < 1e-9
+    assert abs(vk_tr - np.array([vk[minus[k]].conj() for k in range(nk)])).max() < 1e-4 * abs(vk).max()
+    ej = np.einsum('kij,kji', vj, dms).real / 2 / nk
+    ek = np.einsum('kij,kji', vk, dms).real / 4 / nk
+    assert ej > 0 and ek > 0
+    df.reset()

@@ -171,6 +171,18 @@ def test_select_ip_gram_matches_oracle_ragged_and_ties(be):
     assert np.array_equal(piv, oisdf.pivoted_cholesky_gram(dup.T.dot(dup) ** 2, 12)[0])
 
 
+def test_select_ip_gram_block_lower_update_several_strips(be):
+    """m = 4500 > the 2048-column strips of the trailing update: only the block-lower part of the matrix is kept current and
+    pivot columns are read through the symmetric rule (row p where it lies in or below the column's strip, column p
+    otherwise).  700 pivots in panels of 256 (two trailing updates): identical pivots to the oracle."""
+    rng = np.random.default_rng(33)
+    ao = rng.standard_normal((60, 4500)) * np.exp(-2.0 * rng.random(4500))
+    A = ao.T.dot(ao) ** 2
+    pr, _ = oisdf.pivoted_cholesky_gram(A, 700)
+    r, piv, _ = _select_gram_gpu(be, A, 700)
+    assert r == 700 and np.array_equal(piv, pr)
+
+
 def test_refined_selection_end_to_end_matches_oracle_pipeline():
     """select='refined' on the GPU == the same host driver over the CPU oracle (identical points; K within 1e-9
     relative), on a rattled cell (no symmetry ties) with candidates 2x over-complete."""
@@ -909,3 +921,22 @@ def test_rccl_code_paths_execute_on_one_gpu():
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'nccl_one_rank.py')
     r = subprocess.run([sys.executable, script, str(port)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'RCCL-ONE-RANK OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """world_size 2 over RCCL (one GPU per rank): the grid-sharded build against the single-GPU path.  Skipped on one-GPU boxes."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'nccl_two_rank.py')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), script], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'RCCL-TWO-RANK OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
