@@ -205,6 +205,14 @@ int isdf_block_chol(isdf_handle h, const double* d_A, int P, int nblk, const int
                     double shift_rel, double* d_D, double* shift_used);
 int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nblk, const int32_t* blk_off, int side,
                      int trans, double* d_X, int64_t n, int64_t ldx);
+/* The block solves on the matrix cores: isdf_block_invert forms Dinv = blockdiag(D_b^-1) (P x P, lower triangular blocks, exact
+ * zeros elsewhere) from the factors of isdf_block_chol; isdf_block_apply overwrites the rows of every block with
+ * Dinv_b X_b (d_X: rows blk_off[0]..blk_off[nblk], n columns, leading dimension ldx; d_Dinv may point at a diagonal
+ * sub-block, ldd its leading dimension) - the MFMA form of isdf_block_solve(side 0, trans 0): one read and one write of X. */
+int isdf_block_invert(isdf_handle h, const double* d_D, int P, int nblk, const int32_t* blk_off, double* d_Dinv);
+int isdf_block_apply(isdf_handle h, const double* d_Dinv, int64_t ldd, int nblk, const int32_t* blk_off,
+                     double* d_X, int64_t n, int64_t ldx);
+
 /* d_A <- d_A + shift_rel * max(diag d_A) * I. */
 int isdf_shift_diag(isdf_handle h, double* d_A, int P, double shift_rel);
 int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel, double* d_scratch, double* reg_used);

@@ -208,6 +208,20 @@ class HipBackend:
         self.handle.call('isdf_block_solve', self._p(D), D.stride(0), len(blk_off) - 1, _np_ptr(blk_off), int(side), int(trans),
                          self._p(X), int(n), X.stride(0))
 
+    def block_invert(self, D, blk_off, Dinv):
+        """Dinv (P, P) <- blockdiag(D_b^-1)."""
+        self._stream()
+        blk_off = np.ascontiguousarray(blk_off, dtype=np.int32)
+        assert D.is_contiguous() and Dinv.is_contiguous() and Dinv.shape == D.shape
+        self.handle.call('isdf_block_invert', self._p(D), D.shape[0], len(blk_off) - 1, _np_ptr(blk_off), self._p(Dinv))
+
+    def block_apply(self, Dinv, blk_off, X):
+        """X (rows of the blocks, n) <- Dinv_b X_b in place (MFMA); Dinv may be a diagonal sub-block view."""
+        self._stream()
+        blk_off = np.ascontiguousarray(blk_off, dtype=np.int32)
+        self.handle.call('isdf_block_apply', self._p(Dinv), Dinv.stride(0), len(blk_off) - 1, _np_ptr(blk_off), self._p(X),
+                         X.shape[1], X.stride(0))
+
     def shift_diag(self, A, shift_rel):
         self._stream()
         self.handle.call('isdf_shift_diag', self._p(A), A.shape[0], float(shift_rel))

@@ -125,6 +125,9 @@ int trsm_lower_right(isdf_handle h, bool trans, int m, int64_t n, const double* 
 // every diagonal block of a block-diagonal lower factor in one launch: X[blk_b, :] <- D_b^-1 X[blk_b, :] (blk_off on the host)
 int block_forward_solve(isdf_handle h, const double* D, int64_t ldd, int nblk, const int32_t* blk_off_host, double* X,
                         int64_t ldx, int64_t n);
+// X[blk_b, :] <- Dinv_b X[blk_b, :] with explicit block inverses (lower triangular), MFMA kernel of trsm.hip
+int block_apply_inverse(isdf_handle h, const double* Dinv, int64_t ldd, int nblk, const int32_t* blk_off_host, double* X,
+                        int64_t ldx, int64_t n);
 int transpose_rm(isdf_handle h, const double* src, int64_t lds, int64_t rows, int64_t cols, double* dst, int64_t ldd);
 // The fit's triangular solves with a row-major lower factor L: dispatch on h->trsm_substitution between rocBLAS dtrsm
 // (column-major view: the same buffer is the upper factor U = L^T) and trsm_lower_*.

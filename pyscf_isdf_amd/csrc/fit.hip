@@ -418,6 +418,34 @@ extern "C" int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nbl
   return ISDF_OK;
 }
 
+namespace {
+__global__ void block_identity_kernel(double* __restrict__ E, int P, const int32_t* __restrict__ blk_of_row) {
+  // E (P x P) <- 0 with ones on the diagonal (the right-hand side whose block solves are the block inverses)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)P * P) E[i] = (i / P == i % P) ? 1.0 : 0.0;
+  (void)blk_of_row;
+}
+}  // namespace
+
+extern "C" int isdf_block_invert(isdf_handle h, const double* d_D, int P, int nblk, const int32_t* blk_off, double* d_Dinv) {
+  // Dinv <- blockdiag(D_b^-1): forward solves of the block factors against the identity.  Entries above the diagonal and
+  // outside the blocks are exact zeros (forward substitution of a unit vector never touches the rows above it).
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_D && d_Dinv && blk_off && P > 0 && nblk > 0 && blk_off[0] == 0 && blk_off[nblk] <= P);
+  hipLaunchKernelGGL(block_identity_kernel, dim3((unsigned)cdiv((int64_t)P * P, 256)), dim3(256), 0, h->stream, d_Dinv, P,
+                     (const int32_t*)nullptr);
+  KERNEL_CHECK(h);
+  return block_forward_solve(h, d_D, P, nblk, blk_off, d_Dinv, P, P);
+}
+
+extern "C" int isdf_block_apply(isdf_handle h, const double* d_Dinv, int64_t ldd, int nblk, const int32_t* blk_off,
+                                double* d_X, int64_t n, int64_t ldx) {
+  // X (rows of the blocks, n columns) <- Dinv_b X_b, the MFMA form of isdf_block_solve(side 0, trans 0)
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_Dinv && d_X && blk_off && nblk > 0 && n > 0 && ldx >= n && blk_off[0] == 0 && blk_off[nblk] <= ldd);
+  return block_apply_inverse(h, d_Dinv, ldd, nblk, blk_off, d_X, ldx, n);
+}
+
 extern "C" int isdf_shift_diag(isdf_handle h, double* d_A, int P, double shift_rel) {
   // A <- A + shift_rel * max(diag A) * I  (the fit's regularisation, applied before the block scaling of S3c so that
   // both fit routes solve the same regularised normal equations)

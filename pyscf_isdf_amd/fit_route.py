@@ -24,11 +24,27 @@ class FitRouteMixin:
         self.reg_used = self.reg_rel + extra
         return A, Dblk
 
+    def _block_inverse(self, Dblk, ip_off):
+        """blockdiag(D_b^-1) for the MFMA form of the block solves over the grid (isdf_block_apply); formed once per build
+        from the factors every rank holds.  None when block_apply_mfma is off (then: substitution, isdf_block_solve)."""
+        if not self.block_apply_mfma:
+            return None
+        key = (Dblk.data_ptr(), getattr(self, '_build_serial', 0), len(ip_off))
+        if getattr(self, '_Dinv_key', None) != key:
+            Dinv = self._buffer('Dinv', tuple(Dblk.shape))
+            self.backend.block_invert(Dblk, ip_off, Dinv)
+            self._Dinv, self._Dinv_key = Dinv, key
+        return self._Dinv
+
     def _bj_rows(self, aoP, nh, ao, ng, Dblk, ip_off, out):
         """out (P, ng) <- Y' = D^-1 (aoP ao)^2 on ng grid columns."""
         be = self.backend
         be.pair_gram_rows(aoP, ao, ng, out, nh)
-        be.block_solve(Dblk, ip_off, 0, 0, out)
+        Dinv = self._block_inverse(Dblk, ip_off)
+        if Dinv is not None:
+            be.block_apply(Dinv, ip_off, out)
+        else:
+            be.block_solve(Dblk, ip_off, 0, 0, out)
 
     # ---- paneled S3c/S4/S5: more fit rows than HBM holds at once -------------------------------------------------
     def _resident_rows(self, G, P):
@@ -82,7 +98,12 @@ class FitRouteMixin:
         assert ip_off[i0] == r0 and ip_off[i1] == r1
         G = self.ao.shape[1]
         be.pair_gram_rows(self.aoP[r0:r1], self.ao, G, out, 0)
-        be.block_solve(st['Dblk'][r0:r1, r0:r1], (ip_off[i0:i1 + 1] - r0).astype(np.int32), 0, 0, out)
+        Dinv = self._block_inverse(st['Dblk'], ip_off)
+        sub = (ip_off[i0:i1 + 1] - r0).astype(np.int32)
+        if Dinv is not None:
+            be.block_apply(Dinv[r0:r1, r0:r1], sub, out)
+        else:
+            be.block_solve(st['Dblk'][r0:r1, r0:r1], sub, 0, 0, out)
 
     def _finish_W_paneled(self, W, probe=None):
         """S3c + S4 + S5 when the P fit rows do not fit into HBM together (c_isdf above ~10 at configs[2] on one GPU).

@@ -47,6 +47,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
                                           # 'refined': local candidates (refine_over x too many), then ONE pivoted Cholesky
                                           # restricted to the candidate set picks the final points
         self.refine_over = 2.0            # 'refined': candidates per atom = refine_over * c_isdf * nao_atom
+        self.cand_ao_cutoff = None        # 'refined', Bohr: the CANDIDATE stage of an atom's block sees only the AOs of atoms
+                                          # within this distance (minimum image); None: all AOs.  The final pick always uses all.
         self.tie_rtol = 1e-10
         self.select_tol = -1.0           # stop when the largest residual diagonal <= tol; < 0: m*eps*max diag (scipy_helper.py:88-90)
         self.reg_rel = 1e-12             # relative diagonal shift of A_PP in the global fit
@@ -74,6 +76,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
                                          # Theta itself and keeps V = conv(Theta) on the device; K costs 4 N G P flop
         self.explicit_theta = False      # True: form Theta itself (second O(P^2 G) solve); same W in exact arithmetic
         self.fft_batch = None             # rows per FFT batch (None: sized from free memory)
+        self.block_apply_mfma = True      # block solves over the grid through explicit block inverses on the matrix cores
         self.max_resident_rows = None     # fit rows held in HBM at once (None: from free memory); fewer than the number of
                                           # points -> the rows are produced panel by panel (block-Jacobi route)
         self.n_panels = 1
@@ -153,6 +156,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         self._band_built = None
         self._ovlp = None
         self._built = False
+        self._build_serial = getattr(self, '_build_serial', 0) + 1
 
     def dump_flags(self, verbose=None):
         out = self.stdout
@@ -288,11 +292,13 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
                 self._rows_plan = (key,) + self._resident_rows(G, Pmax)
             rows_single, rows_panel = self._rows_plan[1:]
             paneled = Pmax > rows_single and not self._want_theta and self.fit_route != 'cholesky'
-            rows_buf = max(min(Pmax, rows_panel) if paneled else Pmax, nao + kmax)
+            rows_buf = max(min(Pmax, rows_panel) if paneled else Pmax, 2 * nao + kmax)
             scratch = self._buffer('theta', (rows_buf, G))
             ao_sel = scratch[:nao]
             L = scratch[nao:nao + kmax]
             be.gather_cols(self.ao, d_perm, ao_sel)
+            if self.select == 'refined' and self.cand_ao_cutoff:
+                ao_sel = self._local_ao_rows(ao_sel, scratch[nao + kmax:], blk_off, a)
             piv = be.empty((cell.natm, kmax), dtype=torch.int64)
             rank = be.select_ip(ao_sel, blk_off, nip, self.select_tol, self.tie_rtol, L, piv)
             del ao_sel, L, scratch
@@ -395,6 +401,27 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
                 warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e) in a paneled build, '
                               'where the Cholesky route is not available: W carries rounding noise of that relative size'
                               % (self.bj_check, self.bj_check_tol))
+
+    def _local_ao_rows(self, ao_sel, out_rows, blk_off, a):
+        """Candidate stage with local AOs: for the block of atom b keep only the AO rows of atoms within cand_ao_cutoff of b
+        (minimum image), packed to the front and zero-padded to a common row count - the selection kernels stream
+        8 (rows + j) m bytes per pivot, and far AOs contribute next to nothing to a block's pair-density Gram matrix.
+        ao_sel: (nao, G) block-major; returns a (nloc_max, G) view of out_rows."""
+        cell = self.cell
+        aosl = _aoslice_by_atom(cell)
+        frac = np.asarray(cell.atom_coords(), dtype=float).dot(np.linalg.inv(a))
+        d = frac[:, None, :] - frac[None, :, :]
+        d -= np.round(d)
+        near = np.linalg.norm(d.dot(a), axis=2) < float(self.cand_ao_cutoff)
+        lists = [np.concatenate([np.arange(aosl[c, 0], aosl[c, 1]) for c in np.nonzero(near[b])[0]]) for b in range(cell.natm)]
+        nloc = max(len(x) for x in lists)
+        loc = out_rows[:nloc]
+        loc.zero_()
+        for b, rows in enumerate(lists):
+            s0, s1 = int(blk_off[b]), int(blk_off[b + 1])
+            if s1 > s0:
+                loc[:len(rows), s0:s1] = ao_sel[self.backend.to_device(rows.astype(np.int64)), s0:s1]
+        return loc
 
     def _refine_selection(self, perm, blk_off, piv_h, rank, P_target, owner):
         """select='refined' on one GPU: the per-atom selections (refine_over x too many points each) are only CANDIDATES;

@@ -161,6 +161,22 @@ class OracleBackend:
                 # X op(D)^-1 = (op(D)^-T X^T)^T
                 x[:, s] = scipy.linalg.solve_triangular(d[s, s], x[:, s].T, lower=True, trans='N' if trans else 'T').T
 
+    def block_invert(self, D, blk_off, Dinv):
+        d = D.numpy()
+        out = np.zeros_like(d)
+        for b in range(len(blk_off) - 1):
+            s = slice(blk_off[b], blk_off[b + 1])
+            if s.stop > s.start:
+                out[s, s] = scipy.linalg.solve_triangular(d[s, s], np.eye(s.stop - s.start), lower=True)
+        Dinv.copy_(torch.from_numpy(out))
+
+    def block_apply(self, Dinv, blk_off, X):
+        d, x = Dinv.numpy(), X.numpy()
+        for b in range(len(blk_off) - 1):
+            s = slice(blk_off[b], blk_off[b + 1])
+            if s.stop > s.start:
+                x[s] = d[s, s].dot(x[s])
+
     def shift_diag(self, A, shift_rel):
         a = A.numpy()
         a[np.diag_indices(len(a))] += shift_rel * a.diagonal().max()

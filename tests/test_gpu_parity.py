@@ -812,6 +812,45 @@ def test_block_jacobi_route_building_blocks(be):
     assert abs(be.to_host(W) - Ai.dot(M).dot(Ai)).max() < 1e-9 * abs(Ai.dot(M).dot(Ai)).max()
 
 
+@pytest.mark.parametrize('sizes,n', [([156, 130, 7, 64, 201], 1000), ([16], 33), ([100, 100], 64), ([330, 5], 257)])
+def test_block_invert_and_mfma_block_apply(be, sizes, n):
+    """isdf_block_invert + isdf_block_apply (explicit block inverses applied with v_mfma_f64_16x16x4, ragged blocks, ragged
+    column tiles, the three column-tile widths) against numpy triangular solves: Dinv exact zeros above the diagonal and
+    outside the blocks, X <- D_b^-1 X_b to 1e-12 relative; also on a diagonal sub-range (the paneled build's use)."""
+    import scipy.linalg
+    rng = np.random.default_rng(sum(sizes) + n)
+    off = np.append(0, np.cumsum(sizes)).astype(np.int32)
+    P = int(off[-1])
+    D = np.zeros((P, P))
+    for b in range(len(sizes)):
+        s = slice(off[b], off[b + 1])
+        M = rng.standard_normal((sizes[b], sizes[b]))
+        D[s, s] = np.linalg.cholesky(M.dot(M.T) + sizes[b] * np.eye(sizes[b]))
+    X = rng.standard_normal((P, n))
+    dD, dX = be.to_device(D), be.to_device(X)
+    dI = be.empty((P, P))
+    be.block_invert(dD, off, dI)
+    Dinv = be.to_host(dI)
+    ref = X.copy()
+    for b in range(len(sizes)):
+        s = slice(off[b], off[b + 1])
+        assert abs(Dinv[s, s] - scipy.linalg.solve_triangular(D[s, s], np.eye(sizes[b]), lower=True)).max() < 1e-12
+        ref[s] = scipy.linalg.solve_triangular(D[s, s], X[s], lower=True)
+    mask = np.zeros((P, P), dtype=bool)
+    for b in range(len(sizes)):
+        s = slice(off[b], off[b + 1])
+        mask[s, s] = np.tril(np.ones((sizes[b], sizes[b]), dtype=bool))
+    assert np.all(Dinv[~mask] == 0.0)
+    be.block_apply(dI, off, dX)
+    assert abs(be.to_host(dX) - ref).max() < 1e-12 * abs(ref).max()
+    if len(sizes) > 2:                                    # blocks 1..2 only, through views (leading dimensions of the parents)
+        r0, r1 = int(off[1]), int(off[3])
+        dX2 = be.to_device(X)
+        be.block_apply(dI[r0:r1, r0:r1], (off[1:4] - r0).astype(np.int32), dX2[r0:r1])
+        got = be.to_host(dX2)
+        assert abs(got[r0:r1] - ref[r0:r1]).max() < 1e-12 * abs(ref).max() and np.array_equal(got[:r0], X[:r0]) and np.array_equal(got[r1:], X[r1:])
+
+
 def test_auto_route_probe_check_accepts_and_falls_back():
     """fit_route='auto': the probe check accepts the block-Jacobi route; when its mismatch exceeds the tolerance
     (forced here with a tiny tolerance) the build warns and rebuilds W with the Cholesky route."""

@@ -16,13 +16,20 @@ ref = None
 for sel in selects:
     for cc in cs:
         over = None
-        if ':' in sel:                      # 'refined:3' = refined selection with refine_over = 3
-            sel_, over = sel.split(':')[0], float(sel.split(':')[1])
+        cut = None
+        if ':' in sel:                      # 'refined:3' = refined selection with refine_over = 3; 'refined:2:7': + cand_ao_cutoff 7 Bohr
+            parts = sel.split(':')
+            sel_, over = parts[0], float(parts[1])
+            cut = float(parts[2]) if len(parts) > 2 else None
         else:
             sel_ = sel
         df = ISDF(cell, c_isdf=cc, select=sel_)
         if over is not None:
             df.refine_over = over
+        if cut is not None:
+            df.cand_ao_cutoff = cut
+        if os.environ.get('ISDF_CAND_CUTOFF'):
+            df.cand_ao_cutoff = float(os.environ['ISDF_CAND_CUTOFF'])
         if os.environ.get('ISDF_FIT_ROUTE'):
             df.fit_route = os.environ['ISDF_FIT_ROUTE']
         t0 = time.perf_counter()
