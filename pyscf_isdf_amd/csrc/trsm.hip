@@ -144,16 +144,20 @@ int subst(isdf_handle h, bool trans, const double* L, int64_t ldl, int nb, doubl
 // LDS.  HBM traffic = one read and one write of X; 2 nb^2 n flop per block at MFMA rate instead of nb^2 n scalar-operand
 // FMAs (block_forward_kernel above: 0.94 TB/s at configs[2]).
 typedef double d4v __attribute__((ext_vector_type(4)));
+// k is walked in chunks of 32 with the order inside a chunk PERMUTED consistently for both operands: k-step j of a chunk uses
+// k = k0 + 8 fk + j (fk = lane >> 4), so lane (row, fk) needs A[row][k0 + 8 fk + 0..7] - eight CONTIGUOUS doubles, a 64-byte
+// run per lane and 256-byte runs per row - instead of eight values strided by four.  The next chunk's eight loads are in
+// flight while the current chunk's 8 x TN/16 MFMAs run.
 template <int TN>
 __global__ __launch_bounds__(256) void block_apply_mfma_kernel(const double* __restrict__ Dinv, int64_t ldd,
                                                                const int32_t* __restrict__ blk_off, double* __restrict__ X,
                                                                int64_t ldx, int64_t n) {
   extern __shared__ double sB[];
-  constexpr int LDB = TN + 16;
+  constexpr int LDB = TN + 2;
   const int b = blockIdx.y;
   const int off = blk_off[b], m = blk_off[b + 1] - off;
   if (m <= 0) return;
-  const int mpad = (m + 15) & ~15;
+  const int mpad = (m + 31) & ~31;
   const int64_t c0 = (int64_t)blockIdx.x * TN;
   const int ncol = (int)min((int64_t)TN, n - c0);
   double* Xb = X + (int64_t)off * ldx + c0;
@@ -164,22 +168,30 @@ __global__ __launch_bounds__(256) void block_apply_mfma_kernel(const double* __r
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int fr = lane & 15, fk = lane >> 4;
-  for (int rt = wave; rt < mpad / 16; rt += 4) {
+  for (int rt = wave; rt < (m + 15) / 16; rt += 4) {
     d4v acc[TN / 16];
 #pragma unroll
     for (int ct = 0; ct < TN / 16; ++ct) acc[ct] = (d4v){0.0, 0.0, 0.0, 0.0};
     const int arow = rt * 16 + fr;
     const bool rowok = arow < m;
-    const double* pa = Dinv + (int64_t)(off + (rowok ? arow : 0)) * ldd + off + fk;
-    const double* pb = sB + fk * LDB + fr;
-    const int kend = min(mpad, (rt + 1) * 16);
-    double a_next = (rowok && fk < m) ? pa[0] : 0.0;
-    for (int k0 = 0; k0 < kend; k0 += 4) {
-      const double a = a_next;
-      if (k0 + 4 < kend) a_next = (rowok && k0 + 4 + fk < m) ? pa[k0 + 4] : 0.0;
+    const double* pa = Dinv + (int64_t)(off + (rowok ? arow : 0)) * ldd + off + 8 * fk;
+    const double* pb = sB + (8 * fk) * LDB + fr;
+    const int kend = min(mpad, ((rt + 1) * 16 + 31) & ~31);      // lower triangular: k < 16 (rt + 1), in whole chunks
+    double a_cur[8], a_nxt[8];
 #pragma unroll
-      for (int ct = 0; ct < TN / 16; ++ct)
-        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[k0 * LDB + ct * 16], acc[ct], 0, 0, 0);
+    for (int j = 0; j < 8; ++j) a_cur[j] = (rowok && 8 * fk + j < m) ? pa[j] : 0.0;
+    for (int k0 = 0; k0 < kend; k0 += 32) {
+      if (k0 + 32 < kend) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a_nxt[j] = (rowok && k0 + 32 + 8 * fk + j < m) ? pa[k0 + 32 + j] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int ct = 0; ct < TN / 16; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[j], pb[(k0 + j) * LDB + ct * 16], acc[ct], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a_cur[j] = a_nxt[j];
     }
 #pragma unroll
     for (int ct = 0; ct < TN / 16; ++ct)
@@ -196,23 +208,23 @@ int block_apply_inverse(isdf_handle h, const double* Dinv, int64_t ldd, int nblk
   ARG_CHECK(h, Dinv && X && blk_off_host && nblk > 0 && n > 0 && nblk <= 65535);
   int mmax = 0;
   for (int b = 0; b < nblk; ++b) mmax = std::max(mmax, blk_off_host[b + 1] - blk_off_host[b]);
-  const int mpad = (mmax + 15) & ~15;
+  const int mpad = (mmax + 31) & ~31;
   ARG_CHECK(h, mmax > 0);
   int32_t* d_off = (int32_t*)isdf_ws(h, "trsm_blk_off", sizeof(int32_t) * (size_t)(nblk + 1));
   if (!d_off) return ISDF_ERR_HIP;
   HIP_TRY(h, hipMemcpyAsync(d_off, blk_off_host, sizeof(int32_t) * (size_t)(nblk + 1), hipMemcpyHostToDevice, h->stream));
   ProfScope ps(h, "block_apply_mfma_kernel[byte]", 16.0 * (double)blk_off_host[nblk] * (double)n);
-  // 64 columns per workgroup while the block's rows fit 64 KB of LDS (two workgroups per CU), else 32, else 16
-  if ((size_t)mpad * (64 + 16) * sizeof(double) <= 64 * 1024) {
+  // 64 columns per workgroup while the block's rows fit 52 KB of LDS (three workgroups per CU), else 32, else 16
+  if ((size_t)mpad * (64 + 2) * sizeof(double) <= 52 * 1024) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(block_apply_mfma_kernel<64>), dim3((unsigned)cdiv(n, 64), (unsigned)nblk), dim3(256),
-                       (size_t)mpad * (64 + 16) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n);
-  } else if ((size_t)mpad * (32 + 16) * sizeof(double) <= 128 * 1024) {
+                       (size_t)mpad * (64 + 2) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n);
+  } else if ((size_t)mpad * (32 + 2) * sizeof(double) <= 80 * 1024) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(block_apply_mfma_kernel<32>), dim3((unsigned)cdiv(n, 32), (unsigned)nblk), dim3(256),
-                       (size_t)mpad * (32 + 16) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n);
+                       (size_t)mpad * (32 + 2) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n);
   } else {
-    ARG_CHECK(h, (size_t)mpad * (16 + 16) * sizeof(double) <= 160 * 1024);
+    ARG_CHECK(h, (size_t)mpad * (16 + 2) * sizeof(double) <= 160 * 1024);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(block_apply_mfma_kernel<16>), dim3((unsigned)cdiv(n, 16), (unsigned)nblk), dim3(256),
-                       (size_t)mpad * (16 + 16) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n);
+                       (size_t)mpad * (16 + 2) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n);
   }
   KERNEL_CHECK(h);
   return ISDF_OK;

@@ -83,6 +83,11 @@ vk_first = df.get_jk(dm, with_j=False)[1]
 t1 = time.perf_counter()
 vk_ex = df.get_k_exact(mo_coeff=cocc, mo_occ=np.full(nocc, 2.0))
 print('exact K at the converged orbitals: %.1f s' % (time.perf_counter() - t1), flush=True)
+if len(sys.argv) > 5 and sys.argv[5] == 'norobust':
+    ek = lambda k: np.einsum('ij,ji', k, dm) / 4
+    print('E_K exact %.10f   plain ISDF dE_K %.3e (max|dK| %.2e)   [%d atoms; robust K skipped]' %
+          (ek(vk_ex), ek(vk_first) - ek(vk_ex), abs(vk_first - vk_ex).max(), cell.natm), flush=True)
+    sys.exit(0)
 df.robust_k = drive_plain
 t1 = time.perf_counter()
 df.build()
