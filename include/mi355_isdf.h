@@ -65,6 +65,13 @@ int isdf_set_coulomb_omega(isdf_handle h, double omega);
  * 4 pi / G^2 (1 - cos(|G| rc)), G = 0 -> 2 pi rc^2, with rc = (3 Nk vol / 4 pi)^(1/3) chosen by the caller; rc = 0 (default)
  * switches it off.  Applies to every kernel table built afterwards, isdf_coulG_q included; not combined with omega. */
 int isdf_set_coulomb_cutoff(isdf_handle h, double rc);
+/* Wigner-Seitz truncated kernel, exxdiv='vcut_ws' (pyscf/pbc/tools/pbc.py:318-346, table of :422-480): short-range part
+ * 4 pi/|q+G|^2 (1 - exp(-|q+G|^2 / 4 alpha^2)) (zero vector: pi/alpha^2) + d_vq[index of q+G on the reciprocal lattice of
+ * the nk-fold cell ak (rows), table mesh `mesh`] for |components of q+G| <= maxq.  d_vq is a caller-owned device table that
+ * must outlive the setting; alpha <= 0 switches it off.  Applies to the tables built afterwards (isdf_coulG_q, the Gamma
+ * half-spectrum table); takes precedence over omega / cutoff. */
+int isdf_set_coulomb_ws(isdf_handle h, double alpha, const double ak[9], const int32_t mesh[3], const double maxq[3],
+                        const double* d_vq);
 
 /* Optional in-library profiling (bench.py's roofline leg): when enabled, the library brackets its
  * hot kernel launches with HIP events on the work stream and accumulates, per kernel name, the number

@@ -118,10 +118,10 @@ def fit_theta_normal_equations(aoT, piv):
     return np.linalg.lstsq(A, B, rcond=None)[0]
 
 
-def coulomb_V(theta, a, mesh, omega=None, rc=None):
+def coulomb_V(theta, a, mesh, omega=None, rc=None, ws=None):
     """V_P = ifft(coulG * fft(Theta_P)).real, rows over P (k, G); omega: range separation (pbc.py:408-418); rc: spherical
     truncation (exxdiv='vcut_sph', pbc.py:312-317)."""
-    coulG = tools.get_coulG(a, mesh, omega=omega, rc=rc)
+    coulG = tools.get_coulG(a, mesh, omega=omega, rc=rc, ws=ws)
     return tools.ifft(tools.fft(theta, mesh) * coulG, mesh).real
 
 

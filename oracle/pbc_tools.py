@@ -44,7 +44,7 @@ def get_Gv(b, mesh):
     return Gv.reshape(-1, 3)
 
 
-def get_coulG(a, mesh, k=np.zeros(3), wrap_around=True, omega=None, rc=None):
+def get_coulG(a, mesh, k=np.zeros(3), wrap_around=True, omega=None, rc=None, ws=None):
     """Coulomb kernel on the FFT mesh for lattice ``a`` (3,3 Bohr); exxdiv=None semantics, or - rc given - the spherically
     truncated kernel of exxdiv='vcut_sph' (pbc.py:312-317) with Rc = rc."""
     a = np.asarray(a, dtype=float)
@@ -72,13 +72,49 @@ def get_coulG(a, mesh, k=np.zeros(3), wrap_around=True, omega=None, rc=None):
         coulG = 4 * np.pi / absG2
         if rc:
             coulG = coulG * (1.0 - np.cos(np.sqrt(absG2) * rc))
+        if ws is not None:
+            coulG = coulG * (1.0 - np.exp(-absG2 / (4 * ws['alpha'] ** 2)))
     coulG[absG2 == 0] = 4 * np.pi * 0.5 * rc ** 2 if rc else 0
+    if ws is not None:
+        # exxdiv='vcut_ws' (pbc.py:318-346): the short-range part above (its G -> 0 limit is pi / alpha^2) plus the precomputed
+        # transform of erf(alpha r)/r truncated to the Wigner-Seitz cell of the nk-fold lattice, looked up at k + G
+        coulG[absG2 == 0] = np.pi / ws['alpha'] ** 2
+        gxyz = np.dot(kG, ws['a'].T) / (2 * np.pi)
+        gxyz = gxyz.round(decimals=6).astype(int)
+        kmesh = np.asarray(ws['mesh'])
+        gxyz = (gxyz + kmesh) % kmesh
+        qidx = (gxyz[:, 0] * kmesh[1] + gxyz[:, 1]) * kmesh[2] + gxyz[:, 2]
+        inside = (abs(kG) <= ws['maxq']).all(axis=1)
+        coulG[inside] += ws['vq'][qidx[inside]]
     if equal2boundary is not None:
         coulG[equal2boundary] = 0
     if omega:                                   # range separation, pyscf/pbc/tools/pbc.py:408-418
         e = np.exp(-.25 / omega ** 2 * absG2)
         coulG = coulG * (e if omega > 0 else 1 - e)
     return coulG
+
+
+def precompute_exx(a, nk):
+    """The Wigner-Seitz truncated kernel table of exxdiv='vcut_ws' (pbc.py:422-480, PRB 87 165122): on the lattice a * nk
+    (the cell the k-mesh stands for) tabulate erf(alpha r)/r with r the distance to the NEAREST lattice corner, alpha =
+    5 / (half the smallest plane spacing), on a mesh of 4 int(3 alpha L_i) points per axis, and transform it."""
+    import scipy.special
+    ak = np.asarray(a, dtype=float) * np.asarray(nk, dtype=float)[:, None]
+    Lc = 1.0 / np.linalg.norm(np.linalg.inv(ak), axis=0)
+    alpha = 5.0 / (Lc.min() / 2.0)
+    mesh = np.array([4 * int(L * alpha * 3.0) for L in Lc])
+    frac = np.stack(np.meshgrid(*[np.arange(n) / n for n in mesh], indexing='ij'), axis=-1).reshape(-1, 3)
+    rs = frac.dot(ak)
+    corners = np.array([[i, j, k] for i in (0, 1) for j in (0, 1) for k in (0, 1)], dtype=float).dot(ak)
+    r = np.min([np.linalg.norm(rs - c, axis=1) for c in corners], axis=0)
+    vR = scipy.special.erf(alpha * r) / (r + 1e-200)
+    vR[r < 1e-9] = 2 * alpha / np.sqrt(np.pi)
+    vol = abs(np.linalg.det(ak))
+    vG = (vol / len(rs)) * fft(vR, mesh)
+    if abs(vG.imag).max() > 1e-6:
+        raise RuntimeError('Unconventional lattice was found')
+    bk = 2 * np.pi * np.linalg.inv(ak.T)
+    return dict(alpha=alpha, a=ak, mesh=mesh, vq=vG.real.copy(), maxq=abs(get_Gv(bk, mesh)).max(axis=0))
 
 
 def fp(a):

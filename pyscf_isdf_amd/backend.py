@@ -54,6 +54,19 @@ class HipBackend:
     def set_coulomb_cutoff(self, rc):
         self.handle.call('isdf_set_coulomb_cutoff', float(rc or 0.0))
 
+    def set_coulomb_ws(self, ws):
+        """ws: dict(alpha, a, mesh, maxq, vq) from pbc_tools.wigner_seitz_kernel, or None to switch the kernel off."""
+        if ws is None:
+            self.handle.call('isdf_set_coulomb_ws', 0.0, None, None, None, None)
+            self._ws_table = None
+            return
+        ak = np.ascontiguousarray(ws['a'], dtype=np.float64)
+        mesh = np.ascontiguousarray(ws['mesh'], dtype=np.int32)
+        maxq = np.ascontiguousarray(ws['maxq'], dtype=np.float64)
+        self._ws_table = self.to_device(np.ascontiguousarray(ws['vq'], dtype=np.float64))     # kept alive while set
+        self.handle.call('isdf_set_coulomb_ws', float(ws['alpha']), _np_ptr(ak), _np_ptr(mesh), _np_ptr(maxq),
+                         self._p(self._ws_table))
+
     def set_option(self, key, value):
         self.handle.call('isdf_set_option', key.encode(), int(value))
 

@@ -29,6 +29,15 @@ struct ProfEntry {
   int64_t launches = 0;
 };
 
+// exxdiv='vcut_ws' (pyscf/pbc/tools/pbc.py:318-346): parameters of the Wigner-Seitz truncated kernel; alpha = 0: off
+struct WsKernel {
+  double alpha = 0.0;
+  double ak[9] = {0};        // lattice of the nk-fold cell (rows)
+  int mesh[3] = {0, 0, 0};   // mesh of the precomputed table
+  double maxq[3] = {0, 0, 0};
+  const double* vq = nullptr;  // device table, mesh[0]*mesh[1]*mesh[2] doubles (caller-owned)
+};
+
 struct isdf_ctx {
   int profiling = 0;
   std::map<std::string, ProfEntry> prof;
@@ -49,6 +58,7 @@ struct isdf_ctx {
   double coul_omega = 0.0;
   // spherical truncation radius of the Coulomb kernel (exxdiv='vcut_sph', pbc.py:312-317); 0 = none.  isdf_set_coulomb_cutoff
   double coul_rc = 0.0;
+  WsKernel wsk;
 };
 
 int isdf_fail(isdf_handle h, int code, const char* fmt, ...);

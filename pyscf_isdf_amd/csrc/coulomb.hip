@@ -62,8 +62,40 @@ __global__ void coulG_half_kernel(double* __restrict__ out, int n0, int n1, int 
 // the mesh edge (n_i//2 + 1/2) b_i is x_i = (f_i + qf_i) / (n_i//2 + 1/2).  Components with |x_i| >= 1 (to 9 decimals, the
 // reference's rounding) lie beyond the edge and are wrapped back by 2 (n_i//2) + 1 frequencies (pbc.py:272-302); a component
 // exactly ON the edge (|x_i| = 1) is ambiguous and its table entry is zeroed (pbc.py:400-401).
+// exxdiv='vcut_ws': short-range part 4 pi/g^2 (1 - exp(-g^2/4 alpha^2)) (g = 0: pi/alpha^2) plus the precomputed table of
+// the long-range part truncated to the Wigner-Seitz cell, looked up at the integer coordinates of k + G on the nk-fold
+// cell's reciprocal lattice (pbc.py:318-346) for vectors inside the table's range
+__device__ inline double ws_kernel_value(double gx, double gy, double gz, double g2, const WsKernel& ws) {
+  const double pi = 3.14159265358979323846;
+  double v = g2 == 0.0 ? pi / (ws.alpha * ws.alpha) : 4.0 * pi / g2 * (1.0 - exp(-g2 / (4.0 * ws.alpha * ws.alpha)));
+  if (fabs(gx) <= ws.maxq[0] && fabs(gy) <= ws.maxq[1] && fabs(gz) <= ws.maxq[2]) {
+    int id[3];
+    for (int d = 0; d < 3; ++d) {
+      const double t = (gx * ws.ak[3 * d] + gy * ws.ak[3 * d + 1] + gz * ws.ak[3 * d + 2]) / (2.0 * pi);
+      const int gi = (int)(rint(t * 1e6) / 1e6);                 // round(6 decimals) then truncation, as the reference
+      id[d] = ((gi % ws.mesh[d]) + ws.mesh[d]) % ws.mesh[d];
+    }
+    v += ws.vq[((int64_t)id[0] * ws.mesh[1] + id[1]) * ws.mesh[2] + id[2]];
+  }
+  return v;
+}
+
+__global__ void half_from_full_kernel(const double* __restrict__ full, double* __restrict__ out, int n0, int n1, int n2,
+                                      double scale) {
+  // symmetrised half-spectrum table from a full table: c_sym = (c(idx) + c(mirror idx)) / 2  (see coulG_half_kernel)
+  const int n2h = n2 / 2 + 1;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n0 * n1 * n2h) return;
+  const int iz = (int)(idx % n2h);
+  const int iy = (int)((idx / n2h) % n1);
+  const int ix = (int)(idx / ((int64_t)n2h * n1));
+  const int64_t a = ((int64_t)ix * n1 + iy) * n2 + iz;
+  const int64_t b = ((int64_t)((n0 - ix) % n0) * n1 + (n1 - iy) % n1) * n2 + (n2 - iz) % n2;
+  out[idx] = scale * 0.5 * (full[a] + full[b]);
+}
+
 __global__ void coulG_q_kernel(double* __restrict__ out, int n0, int n1, int n2, Recip r, double qf0, double qf1,
-                               double qf2, int wrap, double omega, double rc) {
+                               double qf2, int wrap, double omega, double rc, WsKernel ws) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t tot = (int64_t)n0 * n1 * n2;
   if (idx >= tot) return;
@@ -90,7 +122,7 @@ __global__ void coulG_q_kernel(double* __restrict__ out, int n0, int n1, int n2,
   const double gy = c[0] * r.b[1] + c[1] * r.b[4] + c[2] * r.b[7];
   const double gz = c[0] * r.b[2] + c[1] * r.b[5] + c[2] * r.b[8];
   const double g2 = gx * gx + gy * gy + gz * gz;
-  out[idx] = edge ? 0.0 : kernel_value(g2, omega, rc);
+  out[idx] = edge ? 0.0 : (ws.alpha > 0.0 ? ws_kernel_value(gx, gy, gz, g2, ws) : kernel_value(g2, omega, rc));
 }
 
 __global__ void mul_half_kernel(double2* __restrict__ z, const double* __restrict__ cg, int64_t gc,
@@ -126,6 +158,18 @@ static int get_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9
                        tp * (a[1] * a[5] - a[2] * a[4]), tp * (a[2] * a[3] - a[0] * a[5]), tp * (a[0] * a[4] - a[1] * a[3])};
   Recip rr;
   for (int i = 0; i < 9; ++i) rr.b[i] = b[i];
+  if (h->wsk.alpha > 0.0) {
+    // tabulated kernel (exxdiv='vcut_ws'): full table at q = 0, then the symmetrised half spectrum
+    double* full = (double*)isdf_ws(h, "coulG_full", sizeof(double) * G);
+    if (!full) return ISDF_ERR_HIP;
+    hipLaunchKernelGGL(coulG_q_kernel, dim3((unsigned)cdiv(G, 256)), dim3(256), 0, h->stream, full, mesh[0], mesh[1], mesh[2],
+                       rr, 0.0, 0.0, 0.0, 0, 0.0, 0.0, h->wsk);
+    hipLaunchKernelGGL(half_from_full_kernel, dim3((unsigned)cdiv(gc, 256)), dim3(256), 0, h->stream, full, cg, mesh[0], mesh[1],
+                       mesh[2], extra_scale / (double)G);
+    KERNEL_CHECK(h);
+    *out = cg;
+    return ISDF_OK;
+  }
   hipLaunchKernelGGL(coulG_half_kernel, dim3((unsigned)cdiv(gc, 256)), dim3(256), 0, h->stream, cg, mesh[0],
                      mesh[1], mesh[2], rr, extra_scale / (double)G, h->coul_omega, h->coul_rc);
   KERNEL_CHECK(h);
@@ -166,7 +210,7 @@ extern "C" int isdf_coulG_q(isdf_handle h, const int32_t mesh[3], const double a
   if (!nonzero) qf[0] = qf[1] = qf[2] = 0.0;
   const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
   hipLaunchKernelGGL(coulG_q_kernel, dim3((unsigned)cdiv(G, 256)), dim3(256), 0, h->stream, d_out, mesh[0], mesh[1],
-                     mesh[2], rr, qf[0], qf[1], qf[2], wrap, omega, h->coul_rc);
+                     mesh[2], rr, qf[0], qf[1], qf[2], wrap, omega, h->coul_rc, h->wsk);
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

@@ -78,6 +78,18 @@ int isdf_set_coulomb_cutoff(isdf_handle h, double rc) {
   return ISDF_OK;
 }
 
+int isdf_set_coulomb_ws(isdf_handle h, double alpha, const double ak[9], const int32_t mesh[3], const double maxq[3],
+                        const double* d_vq) {
+  if (!h) return ISDF_ERR_ARG;
+  if (alpha <= 0.0) { h->wsk = WsKernel(); return ISDF_OK; }
+  ARG_CHECK(h, ak && mesh && maxq && d_vq && mesh[0] > 0 && mesh[1] > 0 && mesh[2] > 0);
+  h->wsk.alpha = alpha;
+  for (int i = 0; i < 9; ++i) h->wsk.ak[i] = ak[i];
+  for (int i = 0; i < 3; ++i) { h->wsk.mesh[i] = mesh[i]; h->wsk.maxq[i] = maxq[i]; }
+  h->wsk.vq = d_vq;
+  return ISDF_OK;
+}
+
 int isdf_set_option(isdf_handle h, const char* key, int value) {
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, key != nullptr);

@@ -570,20 +570,33 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         """Rc of exxdiv='vcut_sph': the sphere with the volume of the nk-fold cell (pbc.py:313)."""
         return float((3.0 * nk * self.cell.vol / (4.0 * np.pi)) ** (1.0 / 3.0))
 
-    def _W_kernel_variant(self, key, omega=None, cutoff=None):
+    def _ws_kernel(self, nk):
+        """Table of the Wigner-Seitz truncated kernel for an nk k-mesh on this cell (pbc_tools.wigner_seitz_kernel), cached."""
+        from . import pbc_tools
+        key = tuple(int(x) for x in nk)
+        cache = getattr(self, '_ws_tables', None)
+        if cache is None or cache[0] is not self.cell:
+            cache = self._ws_tables = (self.cell, {})
+        if key not in cache[1]:
+            cache[1][key] = pbc_tools.wigner_seitz_kernel(self.cell.lattice_vectors(), key)
+        return cache[1][key]
+
+    def _W_kernel_variant(self, key, omega=None, cutoff=None, ws=None):
         """W rebuilt from the current fit with another Coulomb kernel (range-separated: omega; spherically truncated:
-        cutoff), cached under ``key`` until the next build.  The fit itself does not depend on the kernel."""
+        cutoff; Wigner-Seitz truncated: ws), cached under ``key`` until the next build.  The fit does not depend on the kernel."""
         be = self.backend
         if key not in self._W_omega:
             t0 = time.perf_counter()
             be.set_coulomb_omega(omega or 0.0)
             be.set_coulomb_cutoff(cutoff or 0.0)
+            be.set_coulomb_ws(ws)
             try:
                 W = be.empty(tuple(self.W.shape))
                 (self._finish_W_sharded if self._fit_state.get('sharded') else self._finish_W)(W)
             finally:
                 be.set_coulomb_omega(0.0)
                 be.set_coulomb_cutoff(0.0)
+                be.set_coulomb_ws(None)
             self._W_omega[key] = W
             self._tick('S4S5_coulomb_W_variant', t0)
         return self._W_omega[key]
@@ -637,23 +650,28 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             self._built = False
         if exxdiv is None:
             exxdiv = self.exxdiv
-        if exxdiv not in (None, 'None', 'ewald', 'vcut_sph'):
-            raise NotImplementedError("exxdiv=%r: None, 'ewald' and 'vcut_sph' are implemented" % (exxdiv,))
+        if exxdiv not in (None, 'None', 'ewald', 'vcut_sph', 'vcut_ws'):
+            raise NotImplementedError("exxdiv=%r: None, 'ewald', 'vcut_sph' and 'vcut_ws' are implemented" % (exxdiv,))
         if not self._built:
             self.build()
         be = self.backend
-        if exxdiv == 'vcut_sph' and with_k:
-            # K with the spherically truncated kernel (pbc.py:312-317): its own W, built once from the same fit; J keeps 1/r
+        if exxdiv in ('vcut_sph', 'vcut_ws') and with_k:
+            # K with a truncated kernel (spherical: pbc.py:312-317; Wigner-Seitz: pbc.py:318-346): its own W, built once from
+            # the same fit; J keeps 1/r
             if self.robust_k:
-                raise NotImplementedError("exxdiv='vcut_sph' with robust_k is not implemented")
+                raise NotImplementedError("exxdiv=%r with robust_k is not implemented" % exxdiv)
             vj = self.get_jk(dm, hermi, kpts, kpts_band, True, False, None, 'None')[0] if with_j else None
-            W_plain, self.W = self.W, self._W_kernel_variant('vcut_sph', cutoff=self._vcut_sph_radius(1))
+            if exxdiv == 'vcut_sph':
+                Wv = self._W_kernel_variant('vcut_sph', cutoff=self._vcut_sph_radius(1))
+            else:
+                Wv = self._W_kernel_variant('vcut_ws', ws=self._ws_kernel((1, 1, 1)))
+            W_plain, self.W = self.W, Wv
             try:
                 vk = self.get_jk(dm, hermi, kpts, kpts_band, False, True, None, 'None')[1]
             finally:
                 self.W = W_plain
             return vj, vk
-        if exxdiv == 'vcut_sph':
+        if exxdiv in ('vcut_sph', 'vcut_ws'):
             exxdiv = None
         dm_in = np.asarray(dm)
         if np.iscomplexobj(dm_in):

@@ -202,9 +202,9 @@ class KPointMixin:
         kpts_band the result lives on the band k-points, (nband, N, N) [(N, N) for a single (3,) band vector], as
         df_jk._format_jks shapes it (pyscf/pbc/df/df_jk.py:1426-1444)."""
         ex = exxdiv if exxdiv is not None else self.exxdiv
-        if ex not in (None, 'None', 'ewald', 'vcut_sph'):
-            raise NotImplementedError("k-point ISDF: exxdiv None, 'ewald' and 'vcut_sph' are implemented")
-        if omega and ex in ('ewald', 'vcut_sph'):
+        if ex not in (None, 'None', 'ewald', 'vcut_sph', 'vcut_ws'):
+            raise NotImplementedError("k-point ISDF: exxdiv None, 'ewald', 'vcut_sph' and 'vcut_ws' are implemented")
+        if omega and ex in ('ewald', 'vcut_sph', 'vcut_ws'):
             raise NotImplementedError('range-separated J/K: only exxdiv=None is implemented')
         cell, be, comm = self.cell, self.backend, self.comm
         kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
@@ -261,6 +261,16 @@ class KPointMixin:
                     be.set_coulomb_cutoff(0.0)
                 t0 = self._tick('S4S5_coulomb_W_variant', t0)
             Wq_set = self._W_omega['vcut_sph']
+        elif ex == 'vcut_ws' and with_k:
+            # exchange with the Wigner-Seitz truncated kernel (pbc.py:318-346) of the k-mesh's supercell: its own W^q set
+            if 'vcut_ws' not in self._W_omega:
+                be.set_coulomb_ws(self._ws_kernel(_monkhorst_pack_size(cell, kpts)))
+                try:
+                    self._W_omega['vcut_ws'], _, t0 = self._build_Wq(None, t0)
+                finally:
+                    be.set_coulomb_ws(None)
+                t0 = self._tick('S4S5_coulomb_W_variant', t0)
+            Wq_set = self._W_omega['vcut_ws']
         try:
             vj, vk = self._jk_from_Wq(Wq_set, dms, nk, bidx, planes, out_shape, with_j, with_k, ex, herm_dm, kpts, t0)
         finally:

@@ -25,6 +25,7 @@ SIGNATURES = {
     'isdf_workspace_bytes': (c_i64, [c_vp]),
     'isdf_set_coulomb_omega': (c_int, [c_vp, c_dbl]),
     'isdf_set_coulomb_cutoff': (c_int, [c_vp, c_dbl]),
+    'isdf_set_coulomb_ws': (c_int, [c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp]),
     'isdf_set_option': (c_int, [c_vp, ctypes.c_char_p, c_int]),
     'isdf_release_workspace': (c_int, [c_vp]),
     'isdf_prof_enable': (c_int, [c_vp, c_int]),

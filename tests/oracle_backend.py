@@ -20,6 +20,11 @@ class OracleBackend:
     def set_coulomb_cutoff(self, rc):
         self.rc = rc or None
 
+    ws = None
+
+    def set_coulomb_ws(self, ws):
+        self.ws = ws
+
     def set_option(self, key, value):
         pass
 
@@ -236,13 +241,13 @@ class OracleBackend:
 
     def coulomb_rows(self, rows, mesh, a, batch, out=None):
         out = rows if out is None else out
-        out.copy_(torch.from_numpy(oisdf.coulomb_V(rows.numpy(), a, mesh, self.omega, self.rc)))
+        out.copy_(torch.from_numpy(oisdf.coulomb_V(rows.numpy(), a, mesh, self.omega, self.rc, self.ws)))
 
     def coulomb_W(self, theta, mesh, a, row0, nrows, batch, W, upper_only=False):
         G = int(np.prod(mesh))
         w = abs(np.linalg.det(a)) / G
         th = theta.numpy()
-        V = oisdf.coulomb_V(th[row0:row0 + nrows], a, mesh, self.omega, self.rc)
+        V = oisdf.coulomb_V(th[row0:row0 + nrows], a, mesh, self.omega, self.rc, self.ws)
         W[row0:row0 + nrows, :th.shape[0]] = torch.from_numpy(w * V.dot(th.T))
 
     def symmetrize_upper(self, W):
@@ -329,7 +334,7 @@ class OracleBackend:
             theta[:, :ng] = torch.from_numpy(scipy.linalg.cho_solve((chol.numpy(), True), B))
 
     def coulG_q(self, mesh, a, q, omega=None, wrap_around=True, out=None):
-        t = torch.from_numpy(tools.get_coulG(a, mesh, q, wrap_around=wrap_around, omega=omega, rc=self.rc))
+        t = torch.from_numpy(tools.get_coulG(a, mesh, q, wrap_around=wrap_around, omega=omega, rc=self.rc, ws=self.ws))
         if out is None:
             return t
         out.copy_(t)

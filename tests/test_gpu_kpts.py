@@ -119,6 +119,23 @@ def test_coulG_q_kernel_matches_reference_pins_and_oracle(be):
             assert abs(got - ref).max() < 1e-11 * abs(ref).max() and abs(got[0] - ref[0]) < 1e-12 * ref[0]
     finally:
         be.set_coulomb_cutoff(0.0)
+    # exxdiv='vcut_ws': the REFERENCE's constant for the diamond primitive cell, mesh 11^3, 2x2x2 k-mesh, k = kpts[2]
+    # (pyscf/pbc/tools/test/test_pbc.py:26-41), through the product's table (pbc_tools.wigner_seitz_kernel) and the device lookup
+    a_d = np.array([[0., 1.7834, 1.7834], [1.7834, 0., 1.7834], [1.7834, 1.7834, 0.]]) / 0.52917721092
+    dcell = gto.Cell(atom=[('C', (0., 0., 0.)), ('C', (0.8917, 0.8917, 0.8917))], a=a_d * 0.52917721092, basis='gth-szv',
+                     mesh=(11, 11, 11), pseudo='gth-pade')
+    k2 = dcell.make_kpts([2, 2, 2])[2]
+    ws = pbc_tools.wigner_seitz_kernel(dcell.lattice_vectors(), [2, 2, 2])
+    be.set_coulomb_ws(ws)
+    try:
+        got = be.to_host(be.coulG_q([11, 11, 11], dcell.lattice_vectors(), k2))
+        got0 = be.to_host(be.coulG_q([11, 11, 11], dcell.lattice_vectors(), np.zeros(3)))
+    finally:
+        be.set_coulomb_ws(None)
+    assert abs(otools.fp(got) - 1.3245365170998518) < 1e-8
+    ows = otools.precompute_exx(dcell.lattice_vectors(), [2, 2, 2])
+    assert abs(got - otools.get_coulG(dcell.lattice_vectors(), [11, 11, 11], k2, ws=ows)).max() < 1e-11 * abs(got).max()
+    assert abs(got0 - otools.get_coulG(dcell.lattice_vectors(), [11, 11, 11], np.zeros(3), ws=ows)).max() < 1e-11 * abs(got0).max()
 
 
 def test_coulomb_Wq(be):

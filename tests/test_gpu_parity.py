@@ -565,8 +565,8 @@ def test_robust_k_matches_oracle_and_reduces_the_error(be):
     assert abs(sh.get_jk(dm, with_j=False)[1] - k_rob).max() < 1e-9 * abs(k_rob).max()
 
 
-def test_exxdiv_vcut_sph_matches_oracle_pipeline():
-    """exxdiv='vcut_sph' at the Gamma point on the GPU (half-spectrum kernel table with the truncated kernel, W rebuilt once
+def test_exxdiv_vcut_sph_and_vcut_ws_match_oracle_pipeline():
+    """exxdiv='vcut_sph' / 'vcut_ws' at the Gamma point on the GPU (half-spectrum kernel table with the truncated kernel, W rebuilt once
     from the same fit) == the same host driver over the CPU oracle: K within 1e-8 relative; J untouched."""
     from oracle_backend import OracleBackend
     from pyscf_isdf_amd.isdf import ISDF
@@ -581,8 +581,11 @@ def test_exxdiv_vcut_sph_matches_oracle_pipeline():
         vj0, vk0 = df.get_jk(dm)
         vj1, vk1 = df.get_jk(dm, exxdiv='vcut_sph')
         assert abs(vj1 - vj0).max() < 1e-12 and abs(vk1 - vk0).max() > 1e-3 * abs(vk0).max()
-        out[name] = vk1
-    assert abs(out['gpu'] - out['cpu']).max() < 1e-8 * abs(out['cpu']).max()
+        vj2, vk2 = df.get_jk(dm, exxdiv='vcut_ws')                  # Wigner-Seitz truncation: tabulated kernel, Gamma half table
+        assert abs(vj2 - vj0).max() < 1e-12 and sorted(df._W_omega) == ['vcut_sph', 'vcut_ws']
+        out[name] = (vk1, vk2)
+    for i in (0, 1):
+        assert abs(out['gpu'][i] - out['cpu'][i]).max() < 1e-8 * abs(out['cpu'][i]).max()
 
 
 def test_exxdiv_ewald_adds_madelung_SDS():

@@ -59,9 +59,9 @@ def test_isdf_surface_and_errors():
     with pytest.raises(NotImplementedError):                       # range separation: exxdiv=None only
         ISDF(cell, kpts=np.array([[0.1, 0., 0.], [0., 0., 0.]])).get_jk(np.zeros((2, 6, 6)), omega=0.3, exxdiv='ewald')
     with pytest.raises(NotImplementedError):
-        df.get_jk(np.eye(6), exxdiv='vcut_ws')
+        df.get_jk(np.eye(6), exxdiv='no-such-treatment')
     with pytest.raises(NotImplementedError):
-        ISDF(cell, kpts=np.array([[0.1, 0., 0.], [0., 0., 0.]])).get_jk(np.zeros((2, 6, 6)), exxdiv='vcut_ws')
+        ISDF(cell, kpts=np.array([[0.1, 0., 0.], [0., 0., 0.]])).get_jk(np.zeros((2, 6, 6)), exxdiv='no-such-treatment')
 
 
 def test_unique_q():

@@ -155,3 +155,37 @@ def test_supercell_kmesh_cross_check_with_checker_backend():
     assert abs(k2gamma.to_supercell_ao_integrals(cell, kpts, vkc).real - vksc).max() < 1e-4 * abs(vksc).max()
     assert abs(vksc - vks).max() > 1e-3 * abs(vks).max()
     assert sorted(k for k in dfk._W_omega) == ['vcut_sph'] and 'vcut_sph' in dfs._W_omega
+    # exxdiv='vcut_ws' on this triclinic lattice: the reference refuses it (test_pbc.py:43-52, pbc.py:466-473) and so do we
+    with pytest.raises(RuntimeError):
+        dfk.get_jk(dms, kpts=kpts, exxdiv='vcut_ws')
+
+
+def test_supercell_kmesh_identity_with_the_wigner_seitz_kernel():
+    """exxdiv='vcut_ws' (pbc.py:318-346): the kernel is truncated to the Wigner-Seitz cell of the nk-fold lattice, which IS the
+    supercell's own lattice - so a [2,1,1] k-mesh on the cubic He/C test cell and the Gamma point of its 2x1x1 supercell must give
+    the same exchange (to the fit error), different from the untruncated one; J is untouched."""
+    import cells
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    from pyscf_isdf_amd import k2gamma
+    cell = cells.cell_he_c()
+    cell.mesh = np.array([9, 9, 9])
+    kpts = cell.make_kpts([2, 1, 1])
+    nao, nk = cell.nao_nr(), 2
+    scell, phase = k2gamma.get_phase(cell, kpts)
+    rng = np.random.default_rng(9)
+    c = rng.standard_normal((nk, nao, 2))
+    dms = np.einsum('kpi,kqi->kpq', c, c)
+    dm_sc = k2gamma.to_supercell_ao_integrals(cell, kpts, dms).real
+    dfk = ISDF(cell, kpts=kpts, c_isdf=25, select='global', backend=OracleBackend())
+    dfk.select_tol, dfk.k_ip_factor = 0.0, 2
+    dfs = ISDF(scell, c_isdf=25, select='global', backend=OracleBackend())
+    dfs.select_tol = 0.0
+    vj, vk = dfk.get_jk(dms, kpts=kpts)
+    vjw, vkw = dfk.get_jk(dms, kpts=kpts, exxdiv='vcut_ws')
+    vjs, vks = dfs.get_jk(dm_sc)
+    vjsw, vksw = dfs.get_jk(dm_sc, exxdiv='vcut_ws')
+    assert abs(vjw - vj).max() < 1e-12 and abs(vjsw - vjs).max() < 1e-12
+    assert abs(k2gamma.to_supercell_ao_integrals(cell, kpts, vk).real - vks).max() < 2e-4 * abs(vks).max()
+    assert abs(k2gamma.to_supercell_ao_integrals(cell, kpts, vkw).real - vksw).max() < 2e-4 * abs(vksw).max()
+    assert abs(vksw - vks).max() > 1e-3 * abs(vks).max()

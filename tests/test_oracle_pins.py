@@ -106,3 +106,22 @@ def test_get_pp_pins():
     assert abs(tools.fp(v[1]) - (-5.5387702576467603 + 1.0439333717227581j)) < 1e-8
     assert abs(tools.fp(v[2]) - (-6.0530899866313366 + 0.2817289667029651j)) < 1e-8
     assert abs(tools.fp(v[3]) - (-5.6011543542444446 + 0.27597306418805201j)) < 1e-8
+
+
+def test_coulG_vcut_ws_and_ewald_match_reference_pins():
+    """oracle.pbc_tools.get_coulG with exxdiv='vcut_ws' (precompute_exx) reproduces the reference's fp(coulG) for the diamond
+    primitive cell, mesh 11^3, 2x2x2 k-mesh, k = kpts[2] (pyscf/pbc/tools/test/test_pbc.py:26-41); and the exx='ewald' kernel
+    of test_pbc.py:75-76 (the plain kernel + nk vol madelung at G = 0) pins oracle kernel and product madelung together."""
+    import numpy as np
+    from oracle import pbc_tools as otools
+    from pyscf_isdf_amd import gto
+    a = np.array([[0., 1.7834, 1.7834], [1.7834, 0., 1.7834], [1.7834, 1.7834, 0.]]) / 0.52917721092
+    cell = gto.Cell(atom=[('C', (0., 0., 0.)), ('C', (0.8917, 0.8917, 0.8917))], a=a * 0.52917721092, basis='gth-szv', mesh=(11, 11, 11),
+                    pseudo='gth-pade')
+    kpts = cell.make_kpts([2, 2, 2])
+    ws = otools.precompute_exx(cell.lattice_vectors(), [2, 2, 2])
+    coulG = otools.get_coulG(cell.lattice_vectors(), [11, 11, 11], kpts[2], ws=ws)
+    assert abs(otools.fp(coulG) - 1.3245365170998518) < 1e-8
+    unit = gto.Cell(atom=[('C', (0., 0., 0.))], a=np.eye(3), basis='gth-szv', mesh=(11, 9, 7), pseudo='gth-pade', unit='Bohr')
+    plain = otools.get_coulG(np.eye(3), [11, 9, 7])
+    assert abs(otools.fp(plain) + gto.madelung(unit) * unit.vol - 4.888843468914021) < 1e-8
