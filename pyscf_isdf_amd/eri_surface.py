@@ -1,7 +1,7 @@
 """The rest of FFTDF's ``with_df`` surface that post-HF callers reach (pyscf/pbc/df/fft.py:317-345): ``get_ao_pairs_G``,
 ``get_mo_pairs_G`` (exact pair-density transforms, pyscf/pbc/df/fft_ao2mo.py:219-340) and ``loop`` (three-index blocks for the
 molecular DF code, fft.py:326-345).  Small-system helpers: AO values come from the device collocation, the pair products and
-their transforms are assembled on the host like the ERI helpers of isdf.py.  ``ao2mo_7d`` is not provided."""
+their transforms are assembled on the host like the ERI helpers of isdf.py.  ``ao2mo_7d`` is the exact transform of the reference (not the ISDF factorisation)."""
 import numpy as np
 from . import gto
 
@@ -101,7 +101,70 @@ class EriSurfaceMixin:
         for p0 in range(0, len(L), blksize):
             yield L[p0:p0 + blksize]
 
+    def get_kconserv(self, kpts):
+        """kconserv[k, l, m] = n with k_k - k_l + k_m - k_n a reciprocal lattice vector (pyscf/pbc/lib/kpts_helper.py:260-283)."""
+        kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
+        nk = len(kpts)
+        a = np.asarray(self.cell.lattice_vectors(), dtype=float) / (2 * np.pi)
+        out = np.zeros((nk, nk, nk), dtype=int)
+        for k in range(nk):
+            for l in range(nk):
+                for m in range(nk):
+                    t = (kpts[k] - kpts[l] + kpts[m])[None, :] - kpts                  # (nk, 3): candidates for zero mod G
+                    s = t.dot(a.T)
+                    hit = np.nonzero(abs(s - np.rint(s)).sum(axis=1) < 1e-9)[0]
+                    if len(hit) == 0:
+                        raise ValueError('k-points are not closed under momentum conservation')
+                    out[k, l, m] = hit[0]
+        return out
+
     def ao2mo_7d(self, mo_coeff_kpts, kpts=None, factor=1, out=None):
-        raise NotImplementedError('ao2mo_7d (pyscf/pbc/df/fft_ao2mo.py:342) is not provided by the ISDF object: quartets that '
-                                  'conserve momentum only up to a reciprocal lattice vector need pair products outside the '
-                                  'fitted span; use get_ao_eri / ao2mo per momentum-conserving quartet')
+        """All momentum-conserving MO integrals of a k-mesh, (nk, nk, nk, nmo_i, nmo_j, nmo_k, nmo_l) with the fourth k-point
+        fixed by conservation modulo a reciprocal lattice vector: FFTDF.ao2mo_7d (pyscf/pbc/df/fft_ao2mo.py:342-425).
+        EXACT, like the reference (pair densities on the grid, one FFT pair per (k,l) pair density), not through the ISDF
+        factorisation: quartets that conserve momentum only up to a reciprocal lattice vector involve pair products
+        exp(i G0.r) conj(u) u outside the fitted span.  A post-HF helper for small cells: AO values from the device
+        collocation, transforms and contractions on the host."""
+        cell = self.cell
+        kpts = self.kpts if kpts is None else np.asarray(kpts, dtype=float).reshape(-1, 3)
+        nk = len(kpts)
+        if isinstance(mo_coeff_kpts, np.ndarray) and mo_coeff_kpts.ndim == 3:
+            mo_coeff_kpts = [mo_coeff_kpts] * 4
+        mo_coeff_kpts = [np.asarray(x) for x in mo_coeff_kpts]
+        mesh = [int(x) for x in self.mesh]
+        G = int(np.prod(mesh))
+        coords = self.grids.coords
+        aos = [self._ao_values_host(k) for k in kpts]                                # (G, nao) each
+        mos = [[aos[k].dot(mo_coeff_kpts[n][k]).T for k in range(nk)] for n in range(4)]     # (nmo, G)
+        nmo = [x.shape[2] for x in mo_coeff_kpts]
+        shape = (nk, nk, nk) + tuple(nmo)
+        gamma = abs(kpts).sum() < 1e-9
+        dtype = np.result_type(*mo_coeff_kpts) if gamma else np.complex128
+        if out is None:
+            out = np.empty(shape, dtype=dtype)
+        assert out.shape == shape
+        kconserv = self.get_kconserv(kpts)
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        done = set()
+        for ki in range(nk):
+            for kj in range(nk):
+                if (ki, kj) in done:
+                    continue
+                q = kpts[kj] - kpts[ki]
+                same_q = [(i, j) for i in range(nk) for j in range(nk) if abs(kpts[j] - kpts[i] - q).max() < 1e-9]
+                coulG = self.backend.to_host(self.backend.coulG_q(np.asarray(mesh, dtype=np.int32), a, q)) * (cell.vol / G) * factor
+                phase = np.exp(-1j * coords.dot(q))
+                z = []
+                for kk in range(nk):
+                    kl = kconserv[ki, kj, kk]
+                    pairs = (mos[2][kk].conj()[:, None, :] * mos[3][kl][None, :, :]).reshape(-1, G) * phase.conj()
+                    v = np.fft.ifftn(pairs.reshape(-1, *mesh), axes=(1, 2, 3)).reshape(-1, G) * coulG
+                    v = np.fft.fftn(v.reshape(-1, *mesh), axes=(1, 2, 3)).reshape(-1, G) * phase
+                    z.append(v)
+                for i, j in same_q:
+                    pij = (mos[0][i].conj()[:, None, :] * mos[1][j][None, :, :]).reshape(-1, G)
+                    for kk in range(nk):
+                        t = pij.dot(z[kk].T)
+                        out[i, j, kk] = (t.real if dtype == np.double else t).reshape(shape[3:])
+                    done.add((i, j))
+        return out

@@ -305,7 +305,7 @@ def test_pair_transforms_and_loop_host_logic_with_checker_backend():
     """The rest of the with_df surface (pyscf/pbc/df/fft.py:317-345): get_ao_pairs_G reproduces the reference's fp(eri)
     through (ij|kl) = sum_G conj((G|ij)) coulG vol/G^2 (G|kl) (fft_ao2mo.py:154-184, pin test_fft.py:695), compact and full
     layouts agree, get_mo_pairs_G is the transformed tensor, and loop() yields three-index blocks whose squares sum to the
-    object's own ERIs (the contract of FFTDF.loop), with get_naoaux() rows in total."""
+    object's own ERIs (the contract of FFTDF.loop), with get_naoaux() rows in total.  (ao2mo_7d: tests/test_oracle_kisdf.py.)"""
     from oracle_backend import OracleBackend
     from pyscf_isdf_amd.isdf import ISDF
     cell = cells.cell_he_c()
@@ -341,8 +341,6 @@ def test_pair_transforms_and_loop_host_logic_with_checker_backend():
     L = np.vstack(blocks)
     assert all(len(b) <= 7 for b in blocks) and L.shape[1] == nao * (nao + 1) // 2 and len(L) <= df.get_naoaux()
     assert abs(L.T.dot(L) - df.get_ao_eri(compact=True)).max() < 1e-9
-    with pytest.raises(NotImplementedError):
-        df.ao2mo_7d(np.zeros((1, nao, 2)))
 
 
 def test_vcut_sph_exchange_host_logic_with_checker_backend():
