@@ -219,6 +219,11 @@ int isdf_block_solve(isdf_handle h, const double* d_D, int P, int nblk, const in
 int isdf_block_invert(isdf_handle h, const double* d_D, int P, int nblk, const int32_t* blk_off, double* d_Dinv);
 int isdf_block_apply(isdf_handle h, const double* d_Dinv, int64_t ldd, int nblk, const int32_t* blk_off,
                      double* d_X, int64_t n, int64_t ldx);
+/* isdf_pair_gram_rows followed by isdf_block_apply with the square folded into the second: d_B (P, ng) <- Dinv_b (aoP ao)^2
+ * for the P = blk_off[nblk] points of the given blocks (real mode). */
+int isdf_pair_rows_block_apply(isdf_handle h, const double* d_aoP, int P, int nao, const double* d_ao, int64_t ng,
+                               int64_t ld, const double* d_Dinv, int64_t ldd, int nblk, const int32_t* blk_off,
+                               double* d_B, int64_t ldb);
 
 /* d_A <- d_A + shift_rel * max(diag d_A) * I. */
 int isdf_shift_diag(isdf_handle h, double* d_A, int P, double shift_rel);

@@ -235,6 +235,14 @@ class HipBackend:
         self.handle.call('isdf_block_apply', self._p(Dinv), Dinv.stride(0), len(blk_off) - 1, _np_ptr(blk_off), self._p(X),
                          X.shape[1], X.stride(0))
 
+    def pair_rows_block_apply(self, aoP, ao, ng, Dinv, blk_off, B):
+        """B (P, ng) <- Dinv_b (aoP ao)^2 (real mode); Dinv may be a diagonal sub-block view matching aoP's rows."""
+        self._stream()
+        blk_off = np.ascontiguousarray(blk_off, dtype=np.int32)
+        assert aoP.stride(1) == 1 and aoP.stride(0) == aoP.shape[1]
+        self.handle.call('isdf_pair_rows_block_apply', self._p(aoP), aoP.shape[0], aoP.shape[1], self._p(ao), int(ng), ao.stride(0),
+                         self._p(Dinv), Dinv.stride(0), len(blk_off) - 1, _np_ptr(blk_off), self._p(B), B.stride(0))
+
     def shift_diag(self, A, shift_rel):
         self._stream()
         self.handle.call('isdf_shift_diag', self._p(A), A.shape[0], float(shift_rel))

@@ -137,7 +137,7 @@ int block_forward_solve(isdf_handle h, const double* D, int64_t ldd, int nblk, c
                         int64_t ldx, int64_t n);
 // X[blk_b, :] <- Dinv_b X[blk_b, :] with explicit block inverses (lower triangular), MFMA kernel of trsm.hip
 int block_apply_inverse(isdf_handle h, const double* Dinv, int64_t ldd, int nblk, const int32_t* blk_off_host, double* X,
-                        int64_t ldx, int64_t n);
+                        int64_t ldx, int64_t n, bool square_input = false);
 int transpose_rm(isdf_handle h, const double* src, int64_t lds, int64_t rows, int64_t cols, double* dst, int64_t ldd);
 // The fit's triangular solves with a row-major lower factor L: dispatch on h->trsm_substitution between rocBLAS dtrsm
 // (column-major view: the same buffer is the upper factor U = L^T) and trsm_lower_*.

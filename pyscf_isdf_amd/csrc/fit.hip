@@ -446,6 +446,20 @@ extern "C" int isdf_block_apply(isdf_handle h, const double* d_Dinv, int64_t ldd
   return block_apply_inverse(h, d_Dinv, ldd, nblk, blk_off, d_X, ldx, n);
 }
 
+extern "C" int isdf_pair_rows_block_apply(isdf_handle h, const double* d_aoP, int P, int nao, const double* d_ao, int64_t ng,
+                                          int64_t ld, const double* d_Dinv, int64_t ldd, int nblk, const int32_t* blk_off,
+                                          double* d_B, int64_t ldb) {
+  // B (P rows = the rows of the blocks, ng) <- Dinv_b (aoP ao)^2: the pair-gram rows and the block solves of the S3c route
+  // in two passes over B instead of three - the product aoP ao (rocBLAS), then the MFMA block apply, which squares its
+  // input while staging it
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_aoP && d_ao && d_Dinv && d_B && blk_off && P > 0 && nao > 0 && ng > 0 && ld >= ng && ldb >= ng && nblk > 0);
+  ARG_CHECK(h, blk_off[0] == 0 && blk_off[nblk] == P);
+  int rc = gemm_rm(h, 'N', 'N', P, ng, nao, 1.0, d_aoP, nao, d_ao, ld, 0.0, d_B, ldb);
+  if (rc) return rc;
+  return block_apply_inverse(h, d_Dinv, ldd, nblk, blk_off, d_B, ldb, ng, true);
+}
+
 extern "C" int isdf_shift_diag(isdf_handle h, double* d_A, int P, double shift_rel) {
   // A <- A + shift_rel * max(diag A) * I  (the fit's regularisation, applied before the block scaling of S3c so that
   // both fit routes solve the same regularised normal equations)

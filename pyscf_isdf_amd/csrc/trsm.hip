@@ -148,7 +148,9 @@ typedef double d4v __attribute__((ext_vector_type(4)));
 // k = k0 + 8 fk + j (fk = lane >> 4), so lane (row, fk) needs A[row][k0 + 8 fk + 0..7] - eight CONTIGUOUS doubles, a 64-byte
 // run per lane and 256-byte runs per row - instead of eight values strided by four.  The next chunk's eight loads are in
 // flight while the current chunk's 8 x TN/16 MFMAs run.
-template <int TN>
+// SQ: the input is squared while it is staged (X holds phi_P phi^T, the pair-gram rows are its element-wise square): saves the
+// separate square pass over the rows.
+template <int TN, bool SQ>
 __global__ __launch_bounds__(256) void block_apply_mfma_kernel(const double* __restrict__ Dinv, int64_t ldd,
                                                                const int32_t* __restrict__ blk_off, double* __restrict__ X,
                                                                int64_t ldx, int64_t n) {
@@ -163,7 +165,9 @@ __global__ __launch_bounds__(256) void block_apply_mfma_kernel(const double* __r
   double* Xb = X + (int64_t)off * ldx + c0;
   for (int idx = threadIdx.x; idx < mpad * TN; idx += 256) {
     const int r = idx / TN, c = idx - r * TN;
-    sB[r * LDB + c] = (r < m && c < ncol) ? Xb[(int64_t)r * ldx + c] : 0.0;
+    double v = (r < m && c < ncol) ? Xb[(int64_t)r * ldx + c] : 0.0;
+    if (SQ) v = v * v;
+    sB[r * LDB + c] = v;
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) void block_apply_mfma_kernel(const double* __r
 }
 
 int block_apply_inverse(isdf_handle h, const double* Dinv, int64_t ldd, int nblk, const int32_t* blk_off_host, double* X,
-                        int64_t ldx, int64_t n) {
+                        int64_t ldx, int64_t n, bool square_input) {
   ARG_CHECK(h, Dinv && X && blk_off_host && nblk > 0 && n > 0 && nblk <= 65535);
   int mmax = 0;
   for (int b = 0; b < nblk; ++b) mmax = std::max(mmax, blk_off_host[b + 1] - blk_off_host[b]);
@@ -215,17 +219,18 @@ int block_apply_inverse(isdf_handle h, const double* Dinv, int64_t ldd, int nblk
   HIP_TRY(h, hipMemcpyAsync(d_off, blk_off_host, sizeof(int32_t) * (size_t)(nblk + 1), hipMemcpyHostToDevice, h->stream));
   ProfScope ps(h, "block_apply_mfma_kernel[byte]", 16.0 * (double)blk_off_host[nblk] * (double)n);
   // 64 columns per workgroup while the block's rows fit 52 KB of LDS (three workgroups per CU), else 32, else 16
+#define ISDF_BA_LAUNCH(TN_, SQ_)                                                                                       \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(block_apply_mfma_kernel<TN_, SQ_>), dim3((unsigned)cdiv(n, TN_), (unsigned)nblk),     \
+                     dim3(256), (size_t)mpad * (TN_ + 2) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n)
   if ((size_t)mpad * (64 + 2) * sizeof(double) <= 52 * 1024) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(block_apply_mfma_kernel<64>), dim3((unsigned)cdiv(n, 64), (unsigned)nblk), dim3(256),
-                       (size_t)mpad * (64 + 2) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n);
+    if (square_input) ISDF_BA_LAUNCH(64, true); else ISDF_BA_LAUNCH(64, false);
   } else if ((size_t)mpad * (32 + 2) * sizeof(double) <= 80 * 1024) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(block_apply_mfma_kernel<32>), dim3((unsigned)cdiv(n, 32), (unsigned)nblk), dim3(256),
-                       (size_t)mpad * (32 + 2) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n);
+    if (square_input) ISDF_BA_LAUNCH(32, true); else ISDF_BA_LAUNCH(32, false);
   } else {
     ARG_CHECK(h, (size_t)mpad * (16 + 2) * sizeof(double) <= 160 * 1024);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(block_apply_mfma_kernel<16>), dim3((unsigned)cdiv(n, 16), (unsigned)nblk), dim3(256),
-                       (size_t)mpad * (16 + 2) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n);
+    if (square_input) ISDF_BA_LAUNCH(16, true); else ISDF_BA_LAUNCH(16, false);
   }
+#undef ISDF_BA_LAUNCH
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

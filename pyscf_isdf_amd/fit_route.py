@@ -39,8 +39,11 @@ class FitRouteMixin:
     def _bj_rows(self, aoP, nh, ao, ng, Dblk, ip_off, out):
         """out (P, ng) <- Y' = D^-1 (aoP ao)^2 on ng grid columns."""
         be = self.backend
-        be.pair_gram_rows(aoP, ao, ng, out, nh)
         Dinv = self._block_inverse(Dblk, ip_off)
+        if Dinv is not None and not nh:
+            be.pair_rows_block_apply(aoP, ao, ng, Dinv, ip_off, out)        # the square rides the block apply's staging
+            return
+        be.pair_gram_rows(aoP, ao, ng, out, nh)
         if Dinv is not None:
             be.block_apply(Dinv, ip_off, out)
         else:
@@ -97,12 +100,12 @@ class FitRouteMixin:
         i0, i1 = int(np.searchsorted(ip_off, r0)), int(np.searchsorted(ip_off, r1))
         assert ip_off[i0] == r0 and ip_off[i1] == r1
         G = self.ao.shape[1]
-        be.pair_gram_rows(self.aoP[r0:r1], self.ao, G, out, 0)
         Dinv = self._block_inverse(st['Dblk'], ip_off)
         sub = (ip_off[i0:i1 + 1] - r0).astype(np.int32)
         if Dinv is not None:
-            be.block_apply(Dinv[r0:r1, r0:r1], sub, out)
+            be.pair_rows_block_apply(self.aoP[r0:r1], self.ao, G, Dinv[r0:r1, r0:r1], sub, out)
         else:
+            be.pair_gram_rows(self.aoP[r0:r1], self.ao, G, out, 0)
             be.block_solve(st['Dblk'][r0:r1, r0:r1], sub, 0, 0, out)
 
     def _finish_W_paneled(self, W, probe=None):

@@ -46,6 +46,7 @@ SIGNATURES = {
     'isdf_block_solve': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_i64, c_i64]),
     'isdf_block_invert': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'isdf_block_apply': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_i64]),
+    'isdf_pair_rows_block_apply': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64]),
     'isdf_shift_diag': (c_int, [c_vp, c_vp, c_int, c_dbl]),
     'isdf_chol_inplace': (c_int, [c_vp, c_vp, c_int, c_dbl, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_factor_solve': (c_int, [c_vp, c_vp, c_int, c_vp, c_i64, c_i64]),

@@ -182,6 +182,10 @@ class OracleBackend:
             if s.stop > s.start:
                 x[s] = d[s, s].dot(x[s])
 
+    def pair_rows_block_apply(self, aoP, ao, ng, Dinv, blk_off, B):
+        self.pair_gram_rows(aoP, ao, ng, B, 0)
+        self.block_apply(Dinv, blk_off, B[:, :ng])
+
     def shift_diag(self, A, shift_rel):
         a = A.numpy()
         a[np.diag_indices(len(a))] += shift_rel * a.diagonal().max()

@@ -846,6 +846,16 @@ def test_block_invert_and_mfma_block_apply(be, sizes, n):
     assert np.all(Dinv[~mask] == 0.0)
     be.block_apply(dI, off, dX)
     assert abs(be.to_host(dX) - ref).max() < 1e-12 * abs(ref).max()
+    # the fused form: rows <- Dinv_b (aoP ao)^2 with the square applied while the block apply stages its input
+    aoP, ao = rng.standard_normal((P, 9)), rng.standard_normal((9, n))
+    B = aoP.dot(ao) ** 2
+    refB = B.copy()
+    for b in range(len(sizes)):
+        s = slice(off[b], off[b + 1])
+        refB[s] = scipy.linalg.solve_triangular(D[s, s], B[s], lower=True)
+    dB = be.empty((P, n))
+    be.pair_rows_block_apply(be.to_device(aoP), be.to_device(ao), n, dI, off, dB)
+    assert abs(be.to_host(dB) - refB).max() < 1e-12 * abs(refB).max()
     if len(sizes) > 2:                                    # blocks 1..2 only, through views (leading dimensions of the parents)
         r0, r1 = int(off[1]), int(off[3])
         dX2 = be.to_device(X)
