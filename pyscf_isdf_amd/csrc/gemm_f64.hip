@@ -543,10 +543,10 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
   static const int variant = getenv("ISDF_GEMM_VARIANT") ? atoi(getenv("ISDF_GEMM_VARIANT")) : -1;
   const bool alignedB = (lda % 2 == 0) && (ldb % 2 == 0) && (K % 32 == 0) && (((uintptr_t)A) % 16 == 0) &&
                         (((uintptr_t)B) % 16 == 0) && (!kscale || ((uintptr_t)kscale) % 16 == 0);
-  // auto: the 256x128 kernel (B) whenever M fills 256-row tiles (row padding < 10 %): after the issue-order work it leads on
+  // auto: the 256x128 kernel (B) whenever M fills 256-row tiles (row padding < 15 %): after the issue-order work it leads on
   // every such shape measured, the k-point W^q batches most of all (MgO 2x2x2: 3.8 s against 4.5 s with D); variant D (A
   // direct to registers, 128x128, two workgroups per CU) for the other aligned shapes, variant A for unaligned operands
-  const bool fitsB = (double)(cdiv(M, BM2) * BM2) <= 1.10 * (double)M;
+  const bool fitsB = (double)(cdiv(M, BM2) * BM2) <= 1.15 * (double)M;
   const bool useB = alignedB && M > BM && (variant == 1 || (variant == -1 && fitsB));
   const bool useD = alignedB && !useB && (variant == 3 || variant == -1);
   g.ntm = (int)cdiv(M, useB ? BM2 : BM); g.ntn = (int)cdiv(N, BN);

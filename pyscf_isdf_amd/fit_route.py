@@ -80,10 +80,14 @@ class FitRouteMixin:
             cuts = [P]
             for k in range(npan - 1):
                 want = max(cuts[-1] - int(nrows_max), 0)
-                # first block boundary at or above `want` (the panel above it then has at most nrows_max rows)
-                b = int(ip_off[np.searchsorted(ip_off, want, side='left')])
-                if b >= cuts[-1]:
+                # a block boundary at or above `want` (the panel above it then has at most nrows_max rows); among the next
+                # few, the one that leaves the rows below it closest to a multiple of 256 from below: they are recomputed in
+                # 512-row batches and the last, partial batch should still fill the GEMM's 256-row tiles
+                i0 = int(np.searchsorted(ip_off, want, side='left'))
+                cand = [int(x) for x in ip_off[i0:] if x < cuts[-1] and x < want + 768]
+                if not cand:
                     break
+                b = min(cand, key=lambda x: ((-x) % 256, x)) if want > 0 else 0
                 cuts.append(b)
             cuts.append(0)
             cuts = sorted(set(cuts))
