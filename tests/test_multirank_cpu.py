@@ -81,6 +81,29 @@ def test_two_ranks_match_one_rank(route):
     assert abs(vj1 - vj2).max() < 1e-10 and abs(vk1 - vk2).max() < 1e-8 * abs(vk1).max()
 
 
+@pytest.mark.timeout(300)
+def test_three_ranks_ragged_shares_match_one_rank():
+    """world_size 3: nothing divides evenly (720 grid points -> 240 each but 2 atoms over 3 ranks, 24 points -> 8 rows per rank in
+    batches of 5, one rank without an atom block): the refined-selection build on the block-Jacobi route must reproduce the
+    single-rank result."""
+    _setup_path()
+    from pyscf_isdf_amd.parallel import Comm
+    ip1, W1, vj1, vk1, used1, chk1 = _run_case(Comm(), None, 'refined')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q, 'refined')) for r in range(3)]
+    for p in procs:
+        p.start()
+    ip3, W3, vj3, vk3, used3, chk3 = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(ip1, ip3) and used1 == used3
+    assert abs(W1 - W3).max() < 1e-9 * abs(W1).max()
+    assert abs(vj1 - vj3).max() < 1e-10 and abs(vk1 - vk3).max() < 1e-8 * abs(vk1).max()
+
+
 def _run_kcase(comm):
     _setup_path()
     import cells
