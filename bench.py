@@ -306,6 +306,10 @@ def main():
             roof = dict(bound='hbm', kernel=dom['kernel'], achieved=round(dom['achieved'], 1), peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=round(dom['achieved'] / HBM_PEAK_GBS, 4), traffic=None, avg_launch_ms=round(dom['avg_ms'], 3),
                         launches=dom['launches'])
+        # the HBM-bound hand-written kernels next to it (algorithmic bytes / HIP-event time), largest first
+        hbm = [dict(kernel=r['kernel'], achieved=round(r['achieved'], 1), unit='GB/s', peak=HBM_PEAK_GBS,
+                    frac=round(r['achieved'] / HBM_PEAK_GBS, 4), seconds_per_step=round(r['total_ms'] / 1e3 / max(args.steps, 1), 3))
+               for r in own if r['unit'] == 'GB/s' and r['total_ms'] / max(args.steps, 1) >= 50.0]
         G = int(np.prod(cell.mesh))
         nao = cell.nao_nr()
         P = len(df.ip)
@@ -325,6 +329,7 @@ def main():
                          {'EJ': float(np.einsum('kij,kji', vj, dm).real / 2 / len(kpts)),
                           'EK': float(np.einsum('kij,kji', vk, dm).real / 4 / len(kpts))}),
             'roofline': roof,
+            'roofline_hbm_kernels': hbm,
         }
         out['cold_first_step_s'] = None if cold_first_step is None else round(cold_first_step, 3)
         out['config']['refine_over'] = args.refine_over if args.select == 'refined' else None
