@@ -555,9 +555,25 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
   // partial workspace at most 2 GiB
   const int64_t slots = (int64_t)h->num_cu * (useB ? 1 : 2);
   int64_t nslab = cdiv(8 * slots, ntiles);
-  nslab = std::min<int64_t>(nslab, std::max<int64_t>(1, K / 2048));
-  nslab = std::min<int64_t>(nslab, std::max<int64_t>(1, ((int64_t)2 << 30) / ((int64_t)M * N * 8)));
-  nslab = std::max<int64_t>(nslab, 1);
+  const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, K / 2048),
+                                                             std::max<int64_t>(1, ((int64_t)2 << 30) / ((int64_t)M * N * 8))));
+  nslab = std::max<int64_t>(1, std::min<int64_t>(nslab, cap));
+  {
+    // wave quantisation: the units are dealt to `slots` resident workgroups, so the launch takes ceil(units / slots) unit
+    // times.  Among slab counts between the target and twice the target pick the one whose last round is fullest
+    // (512 x 15132 output: 238 tiles; 9 slabs = 8.37 rounds -> 9, 15 slabs = 13.95 rounds -> 14: 7 % less idle time)
+    static const int tune = getenv("ISDF_GEMM_SLAB_TUNE") ? atoi(getenv("ISDF_GEMM_SLAB_TUNE")) : 1;
+    if (tune && ntiles * nslab > slots) {
+      double best = 1e30;
+      int64_t pick = nslab;
+      for (int64_t c = nslab; c <= std::min<int64_t>(2 * nslab, cap); ++c) {
+        const double units = (double)ntiles * c;
+        const double waste = (double)(cdiv((int64_t)units, slots) * slots) / units;
+        if (waste < best - 1e-9) { best = waste; pick = c; }
+      }
+      nslab = pick;
+    }
+  }
   g.kslab = cdiv(cdiv(K, nslab), 2 * BK) * (2 * BK);   // even number of chunks per slab
   g.nslab = (int)cdiv(K, g.kslab);
   g.nunits = ntiles * g.nslab;
