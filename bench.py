@@ -19,6 +19,7 @@ import time
 
 import numpy as np
 
+T_PROCESS_START = time.perf_counter()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -43,6 +44,10 @@ def parse_args():
                     help='interpolation points per AO; default: 12 for the headline workload (the accuracy scan of DESIGN.md section 2), else 10')
     ap.add_argument('--fit-route', default=None, choices=['auto', 'cholesky', 'blockjacobi'])
     ap.add_argument('--robust-k', action='store_true', help='time the build + get_jk with the robust exchange (not the headline)')
+    ap.add_argument('--accuracy-budget-s', type=float, default=420.0,
+                    help='if the process has already run longer than this when the timed region ends (many steps), the 48 s exact-'
+                         'exchange evaluation is skipped and E_K(exact) of this workload and density is taken from the committed '
+                         'profiles/r02_bench_cfg3.json (it does not depend on the ISDF settings); stated in accuracy.source')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--stage-report', default=None, help='write the per-kernel table to this file')
     return ap.parse_args()
@@ -339,16 +344,35 @@ def main():
         out['config']['dE_K_vs_exact'] = None
         if world == 1 and kpts is None and not args.no_accuracy and not args.robust_k:
             ta = time.perf_counter()
-            _, c_mo, occ_mo = workloads.make_dm(cell)
-            vk_ex = df.get_k_exact(mo_coeff=c_mo, mo_occ=occ_mo)
-            ek_ex = float(np.einsum('ij,ji', vk_ex, dm) / 4)
-            out['config']['dE_K_vs_exact'] = float(out['energies']['EK'] - ek_ex)
-            out['accuracy'] = {'E_K_exact': ek_ex, 'dE_K_Eh': out['config']['dE_K_vs_exact'],
-                               'dE_K_Eh_per_atom': out['config']['dE_K_vs_exact'] / cell.natm,
-                               'max_abs_dK': float(abs(vk - vk_ex).max()), 'exact_K_seconds_on_this_gpu': round(time.perf_counter() - ta, 1),
-                               'dE_J_Eh': 0.0, 'note': 'exact = the reference algorithm (N*nocc FFT pairs) on the same GPU and grid; J uses '
-                               'the reference formula itself; north-star tolerance 1e-6 Eh: see DESIGN.md section 2 for the c / selection scan'}
-            del vk_ex
+            note = ('exact = the reference algorithm (N*nocc FFT pairs) on the same GPU and grid; J uses the reference formula itself; '
+                    'north-star tolerance 1e-6 Eh: see DESIGN.md section 2 for the c / selection scan')
+            if ta - T_PROCESS_START <= args.accuracy_budget_s:
+                _, c_mo, occ_mo = workloads.make_dm(cell)
+                vk_ex = df.get_k_exact(mo_coeff=c_mo, mo_occ=occ_mo)
+                ek_ex = float(np.einsum('ij,ji', vk_ex, dm) / 4)
+                out['config']['dE_K_vs_exact'] = float(out['energies']['EK'] - ek_ex)
+                out['accuracy'] = {'E_K_exact': ek_ex, 'dE_K_Eh': out['config']['dE_K_vs_exact'],
+                                   'dE_K_Eh_per_atom': out['config']['dE_K_vs_exact'] / cell.natm,
+                                   'max_abs_dK': float(abs(vk - vk_ex).max()), 'source': 'measured in this run',
+                                   'exact_K_seconds_on_this_gpu': round(time.perf_counter() - ta, 1), 'dE_J_Eh': 0.0, 'note': note}
+                del vk_ex
+            else:
+                # a long run (many steps): do not add 48 s; E_K(exact) depends on the cell, the grid and the density only
+                try:
+                    with open(os.path.join(ROOT, 'profiles', 'r02_bench_cfg3.json')) as f:
+                        rec = json.load(f)
+                    same = (rec['config']['workload'] == workloads.WORKLOADS[args.workload][1] and rec['config']['nao'] == nao
+                            and rec['config']['ngrids'] == G and abs(rec['energies']['EJ'] - out['energies']['EJ']) < 1e-8)
+                    if same:
+                        ek_ex = float(rec['accuracy']['E_K_exact'])
+                        out['config']['dE_K_vs_exact'] = float(out['energies']['EK'] - ek_ex)
+                        out['accuracy'] = {'E_K_exact': ek_ex, 'dE_K_Eh': out['config']['dE_K_vs_exact'],
+                                           'dE_K_Eh_per_atom': out['config']['dE_K_vs_exact'] / cell.natm, 'max_abs_dK': None,
+                                           'source': 'E_K(exact) recorded in profiles/r02_bench_cfg3.json for this workload and density '
+                                                     '(same E_J to 1e-8); not re-evaluated: the process had run %.0f s > --accuracy-budget-s'
+                                                     % (ta - T_PROCESS_START), 'dE_J_Eh': 0.0, 'note': note}
+                except (OSError, KeyError, ValueError):
+                    pass
         if os.environ.get('ISDF_ONE_GPU'):
             out['data'] = 'synthetic; REHEARSAL: %d ranks on one GPU over gloo, not a benchmark' % world
         if world == 1 and not args.no_cpu_baseline and kpts is None:
