@@ -348,6 +348,7 @@ def main():
                     'north-star tolerance 1e-6 Eh: see DESIGN.md section 2 for the c / selection scan')
             if ta - T_PROCESS_START <= args.accuracy_budget_s:
                 _, c_mo, occ_mo = workloads.make_dm(cell)
+                df.release_fit_buffers()                # the fit's buffers fill HBM; the exact exchange needs phi and its own batches
                 vk_ex = df.get_k_exact(mo_coeff=c_mo, mo_occ=occ_mo)
                 ek_ex = float(np.einsum('ij,ji', vk_ex, dm) / 4)
                 out['config']['dE_K_vs_exact'] = float(out['energies']['EK'] - ek_ex)

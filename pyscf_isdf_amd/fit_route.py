@@ -52,15 +52,15 @@ class FitRouteMixin:
     # ---- paneled S3c/S4/S5: more fit rows than HBM holds at once -------------------------------------------------
     def _resident_rows(self, G, P):
         """(rows_single, rows_panel): how many (G-long) fit rows can stay resident next to what a build of P points still has
-        to allocate - W, the factor of A' and the block factors (3 x 8 P^2 bytes), FFT batches with their half spectra and
+        to allocate - W, the factor of A', the block factors and their inverses (4 x 8 P^2 bytes), FFT batches with their half spectra and
         work areas (24 G bytes per row of the batch), the GEMM's slab buffers.  rows_single assumes the smallest FFT batch
         the single-pass build would settle for (128 rows); rows_panel the paneled build's 512-row batches plus its
         recompute scratch.  ``max_resident_rows`` overrides both (tests, experiments)."""
         if self.max_resident_rows:
             return int(self.max_resident_rows), int(self.max_resident_rows)
         be = self.backend
-        have = be.free_bytes() + sum(int(b.numel()) * 8 for k, b in self._bufs.items() if k in ('theta', 'W', 'factor', 'Dblk', 'rows_scratch'))
-        fixed = 3 * 8 * P * P + (3 << 30)
+        have = be.free_bytes() + sum(int(b.numel()) * 8 for k, b in self._bufs.items() if k in ('theta', 'W', 'factor', 'Dblk', 'Dinv', 'rows_scratch'))
+        fixed = 4 * 8 * P * P + (3 << 30)
         single = (have - fixed - 24 * 128 * G) // (8 * G)
         panel = (have - fixed - 40 * 512 * G) // (8 * G)
         return max(0, int(single)), max(0, int(panel))

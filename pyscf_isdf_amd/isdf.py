@@ -141,6 +141,21 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         self._rsh_df = {}
         return self
 
+    def release_fit_buffers(self):
+        """Give back the big buffers of the fit (rows, recompute scratch, P x P matrices) and the library's workspaces, keeping
+        the collocation phi: what get_k_exact needs, and nothing else.  The object has to be rebuilt before the next get_jk."""
+        ao = self.ao
+        self._drop_build_state()
+        self.ao = ao
+        for name in ('theta', 'rows_scratch', 'W', 'factor', 'Dblk', 'Dinv', 'aoP'):
+            self._bufs.pop(name, None)
+        self._Dinv = None
+        self._Dinv_key = None
+        if self._backend is not None:
+            self._backend.release_workspace()
+            self._backend.empty_cache()
+        return self
+
     def _drop_build_state(self):
         """Forget everything a build produced (views of the persistent buffers included: the 214 GiB fit buffer must not
         stay referenced from a stale fit state when reset() lets the buffers go).  Called by reset() and at the top of
