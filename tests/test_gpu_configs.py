@@ -10,7 +10,7 @@ interpolation points c_isdf * nao and their selection (DESIGN.md section 2 has t
     than the headline's, 32000 against 13500 points: it needs c = 15 where the headline needs 12);
   * configs[2] (128 atoms, the headline): the configuration bench.py times (refined selection, c = 12, fit rows in two
     panels) is asserted at 1e-6 Eh PER ATOM (measured 2.8e-7 Eh/atom = 3.6e-5 Eh) and max|dK| <= 1e-4; the literal 1e-6 Eh
-    is NOT reached at this size inside 30 s (c = 15: 9.2e-6 Eh in 27.5 s) and no test pretends otherwise;
+    is NOT reached at this size inside 30 s (c = 15: 9.3e-6 Eh in 26.3 s) and no test pretends otherwise;
   * configs[4] (64 H2O) at the largest single-GPU mesh: 1e-5 Eh per atom class with the block-Jacobi clusters (see the test);
   * configs[0], configs[3]: see the tests below.
 """
