@@ -35,12 +35,14 @@ for sel in selects:
         t0 = time.perf_counter()
         vk = df.get_jk(dm, with_j=False)[1]
         t1 = time.perf_counter()
+        nip, route_used = len(df.ip), df.fit_route_used
         if ref is None:
+            df.release_fit_buffers()            # the fit's buffers fill HBM at large c; the exact exchange needs phi only
             ref = df.get_k_exact(mo_coeff=c, mo_occ=occ)
             df.backend.synchronize()
             print('exact K (N*nocc = %d FFT pairs) on the GPU: %.1f s' % (cell.nao_nr() * nocc, time.perf_counter() - t1), flush=True)
         ek, ek0 = np.einsum('ij,ji', vk, dm) / 4, np.einsum('ij,ji', ref, dm) / 4
         print('select=%-10s c=%2d P=%6d  build+K %.2f s   E_K(ISDF) %.8f  E_K(exact) %.8f  dE_K %.2e Eh (%.1e rel)  max|dK| %.2e  route %s  stages %s'
-              % (sel, cc, len(df.ip), t1 - t0, ek, ek0, ek - ek0, abs(ek - ek0) / ek0, abs(vk - ref).max(), df.fit_route_used, {k: round(v, 2) for k, v in df.timings.items()}), flush=True)
+              % (sel, cc, nip, t1 - t0, ek, ek0, ek - ek0, abs(ek - ek0) / ek0, abs(vk - ref).max(), route_used, {k: round(v, 2) for k, v in df.timings.items()}), flush=True)
         df.reset()
         del df

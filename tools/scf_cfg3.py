@@ -81,6 +81,7 @@ for it in range(30):
 cocc = c[:, :nocc]
 vk_first = df.get_jk(dm, with_j=False)[1]
 t1 = time.perf_counter()
+df.release_fit_buffers()
 vk_ex = df.get_k_exact(mo_coeff=cocc, mo_occ=np.full(nocc, 2.0))
 print('exact K at the converged orbitals: %.1f s' % (time.perf_counter() - t1), flush=True)
 if len(sys.argv) > 5 and sys.argv[5] == 'norobust':
