@@ -114,6 +114,12 @@ int isdf_eval_ao_k(isdf_handle h,
 int isdf_gather_cols(isdf_handle h, const double* d_src, int nrow, int64_t ld_src,
                      const int64_t* d_idx, int64_t n, double* d_dst, int64_t ld_dst);
 
+/* Voronoi partition of the grid for the per-atom selection blocks: d_owner[g] = index of the atom nearest to grid point g
+ * (d_coords (3, ngrids) SoA) under the minimum-image convention over the 27 neighbouring images; among atoms within tie_atol
+ * (Bohr) of the smallest distance the lowest index wins.  atom_coords (natm, 3) and the lattice a are host tables. */
+int isdf_partition_by_atom(isdf_handle h, const double* d_coords, int64_t ngrids, const double* atom_coords, int natm,
+                           const double a[9], double tie_atol, int32_t* d_owner);
+
 /* S2. Interpolation-point selection: pivoted Cholesky of the implicit pair-density Gram matrix
  * A(r,r') = (sum_mu ao[mu,r] ao[mu,r'])^2, independently for nblk column blocks
  * [blk_off[b], blk_off[b+1]) of d_ao, nip[b] pivots each (stops early when the largest residual

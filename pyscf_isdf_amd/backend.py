@@ -150,6 +150,19 @@ class HipBackend:
         self.handle.call('isdf_gather_cols', self._p(src), src.shape[0], src.stride(0), self._p(idx), idx.numel(),
                          self._p(dst), dst.stride(0))
 
+    def partition_by_atom(self, coords, atom_coords, a, tie_atol=1e-9):
+        """owner (G,) int32 on the host: nearest atom of every grid point (coords: host (G, 3)); the grid goes to the device
+        once, the partition runs there (isdf_partition_by_atom)."""
+        self._stream()
+        coords_soa = self.to_device(np.ascontiguousarray(np.asarray(coords, dtype=np.float64).T))
+        atoms = np.ascontiguousarray(atom_coords, dtype=np.float64)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        G = coords_soa.shape[1]
+        owner = self.empty((G,), dtype=torch.int32)
+        self.handle.call('isdf_partition_by_atom', self._p(coords_soa), G, _np_ptr(atoms), len(atoms), _np_ptr(a), float(tie_atol),
+                         self._p(owner))
+        return self.to_host(owner)
+
     def select_ip(self, ao, blk_off, nip, tol, tie_rtol, L, piv):
         """Returns rank (np.int32[nblk]); fills L (kmax, ldL) and piv (nblk, kmax) int64 (local indices)."""
         self._stream()

@@ -211,6 +211,68 @@ __global__ __launch_bounds__(TPB) void update_kernel(
 
 }  // namespace
 
+namespace {
+// owner[g] = the atom nearest to grid point g under the minimum-image convention (the 27 neighbouring images of every atom);
+// among atoms within tie_atol of the smallest distance the LOWEST index wins (symmetric crystals put many points exactly
+// between atoms).  Atom positions and the 27 lattice shifts sit in LDS; one grid point per lane, two sweeps over the atoms.
+__global__ __launch_bounds__(256) void partition_kernel(const double* __restrict__ coords, int64_t G, const double* __restrict__ atoms,
+                                                        int natm, const double* __restrict__ shifts, double tie_atol,
+                                                        int32_t* __restrict__ owner) {
+  extern __shared__ double sm[];            // atoms (3 natm) | shifts (81)
+  double* s_at = sm;
+  double* s_sh = sm + 3 * natm;
+  for (int t = threadIdx.x; t < 3 * natm; t += 256) s_at[t] = atoms[t];
+  for (int t = threadIdx.x; t < 81; t += 256) s_sh[t] = shifts[t];
+  __syncthreads();
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= G) return;
+  const double x = coords[g], y = coords[G + g], z = coords[2 * G + g];
+  double dmin = 1e300;
+  for (int a = 0; a < natm; ++a) {
+    const double ax = x - s_at[3 * a], ay = y - s_at[3 * a + 1], az = z - s_at[3 * a + 2];
+    double d2 = 1e300;
+    for (int t = 0; t < 27; ++t) {
+      const double dx = ax - s_sh[3 * t], dy = ay - s_sh[3 * t + 1], dz = az - s_sh[3 * t + 2];
+      d2 = fmin(d2, dx * dx + dy * dy + dz * dz);
+    }
+    dmin = fmin(dmin, sqrt(d2));
+  }
+  int own = natm;
+  for (int a = 0; a < natm && own == natm; ++a) {
+    const double ax = x - s_at[3 * a], ay = y - s_at[3 * a + 1], az = z - s_at[3 * a + 2];
+    double d2 = 1e300;
+    for (int t = 0; t < 27; ++t) {
+      const double dx = ax - s_sh[3 * t], dy = ay - s_sh[3 * t + 1], dz = az - s_sh[3 * t + 2];
+      d2 = fmin(d2, dx * dx + dy * dy + dz * dz);
+    }
+    if (sqrt(d2) <= dmin + tie_atol) own = a;
+  }
+  owner[g] = own;
+}
+}  // namespace
+
+extern "C" int isdf_partition_by_atom(isdf_handle h, const double* d_coords, int64_t ngrids, const double* atom_coords, int natm,
+                                      const double a[9], double tie_atol, int32_t* d_owner) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_coords && atom_coords && a && d_owner && ngrids > 0 && natm > 0 && natm <= 2000 && tie_atol >= 0.0);
+  std::vector<double> host(3 * (size_t)natm + 81);
+  for (int i = 0; i < 3 * natm; ++i) host[i] = atom_coords[i];
+  int t = 0;
+  for (int i = -1; i <= 1; ++i)
+    for (int j = -1; j <= 1; ++j)
+      for (int k = -1; k <= 1; ++k, ++t)
+        for (int c = 0; c < 3; ++c) host[3 * natm + 3 * t + c] = i * a[c] + j * a[3 + c] + k * a[6 + c];
+  double* d_tab = (double*)isdf_ws(h, "partition_tab", sizeof(double) * host.size());
+  if (!d_tab) return ISDF_ERR_HIP;
+  HIP_TRY(h, hipMemcpyAsync(d_tab, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  ProfScope ps(h, "partition_kernel[byte]", 28.0 * (double)ngrids);
+  hipLaunchKernelGGL(partition_kernel, dim3((unsigned)cdiv(ngrids, 256)), dim3(256), sizeof(double) * host.size(), h->stream,
+                     d_coords, ngrids, d_tab, natm, d_tab + 3 * natm, tie_atol, d_owner);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
 extern "C" int isdf_select_ip(isdf_handle h, const double* d_ao, int nao, int64_t ld, int nblk,
                               const int64_t* blk_off, const int32_t* nip, double tol,
                               double tie_rtol, double* d_L, int64_t ldL, int64_t* d_piv,

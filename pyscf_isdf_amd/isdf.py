@@ -285,7 +285,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             del tmp
             t0 = self._tick('S3_fit', t0)
         elif self.select in ('local', 'refined'):
-            owner = partition_grid_by_atom(coords, cell.atom_coords(), a)
+            owner = be.partition_by_atom(coords, cell.atom_coords(), a)
             perm = np.argsort(owner, kind='stable').astype(np.int64)
             counts = np.bincount(owner, minlength=cell.natm)
             blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)

@@ -61,7 +61,7 @@ class KPointMixin:
             ip_dev = piv[0, :int(rank[0])].contiguous()
             self.ip = be.to_host(ip_dev).astype(np.int64)
         else:
-            owner = partition_grid_by_atom(coords, cell.atom_coords(), a)
+            owner = be.partition_by_atom(coords, cell.atom_coords(), a)
             perm = np.argsort(owner, kind='stable').astype(np.int64)
             counts = np.bincount(owner, minlength=cell.natm)
             blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _lib = None
 
@@ -34,6 +34,7 @@ SIGNATURES = {
     'isdf_prof_get': (c_int, [c_vp, c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]),
     'isdf_eval_ao': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_i64]),
     'isdf_gather_cols': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_i64]),
+    'isdf_partition_by_atom': (c_int, [c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_dbl, c_vp]),
     'isdf_select_ip': (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_i64, c_vp, c_vp]),
     'isdf_select_ip_gram': (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_dbl, c_dbl, c_int, c_vp, ctypes.POINTER(ctypes.c_int32)]),
     'isdf_fit_from_chol': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp]),

@@ -71,7 +71,7 @@ class ShardedMixin:
         t0 = self._tick('S1_eval_ao', t0)
 
         # S2 selection on this rank's atom blocks
-        owner = partition_grid_by_atom(coords, cell.atom_coords(), a)
+        owner = be.partition_by_atom(coords, cell.atom_coords(), a)
         perm = np.argsort(owner, kind='stable').astype(np.int64)
         counts = np.bincount(owner, minlength=cell.natm)
         blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)

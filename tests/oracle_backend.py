@@ -79,6 +79,10 @@ class OracleBackend:
     def gather_cols(self, src, idx, dst):
         dst[:, :idx.numel()] = src[:, idx]
 
+    def partition_by_atom(self, coords, atom_coords, a, tie_atol=1e-9):
+        from pyscf_isdf_amd._common import partition_grid_by_atom
+        return partition_grid_by_atom(np.asarray(coords), np.asarray(atom_coords), np.asarray(a), tie_atol)
+
     def select_ip(self, ao, blk_off, nip, tol, tie_rtol, L, piv):
         rank = np.zeros(len(nip), dtype=np.int32)
         A = ao.numpy()

@@ -62,6 +62,19 @@ def test_gather_cols(be):
     assert np.array_equal(be.to_host(dst), src[:, idx])
 
 
+def test_partition_by_atom_matches_oracle(be):
+    """isdf_partition_by_atom (device Voronoi partition, minimum image, ties to the lowest atom index) == the oracle's brute
+    force on an fcc cell full of exact ties, on a triclinic cell, and on a supercell (bit-exact integer output)."""
+    from pyscf_isdf_amd._common import partition_grid_by_atom
+    for cell in (cells.cell_diamond_prim('gth-szv', (12, 12, 12)), cells.cell_he2_triclinic(), gto.diamond_supercell(2, 'gth-szv', (16, 16, 16))):
+        coords = cell.get_uniform_grids()
+        a = cell.lattice_vectors()
+        got = be.partition_by_atom(coords, cell.atom_coords(), a)
+        assert got.dtype == np.int32 and got.shape == (len(coords),)
+        assert np.array_equal(got, oisdf.partition_by_atom(coords, cell.atom_coords(), a))
+        assert np.array_equal(got, partition_grid_by_atom(coords, cell.atom_coords(), a))
+
+
 def _select_gpu(be, aoT, blk_off, nip, tie_rtol=1e-10, tol=-1.0):
     import torch
     kmax = int(max(nip))
