@@ -55,7 +55,9 @@ int isdf_release_workspace(isdf_handle h);
  * dtrsm, 1 through the substitution blocks of trsm.hip (plain forward/backward substitution on 64-row diagonal blocks +
  * dgemm updates: slower, no inverted diagonal blocks; an independent cross-check of rocBLAS's algorithm).  Unknown keys are
  * an error.  "own_fft": 1 (default) the Coulomb convolution runs through the hand-written five-pass FFT (fft_conv.hip) on
- * meshes whose dimensions factor into 2, 3, 5, 7, 11, 13; 0 forces hipFFT (D2Z, kernel multiply, Z2D) everywhere. */
+ * meshes whose dimensions factor into 2, 3, 5, 7, 11, 13; 0 forces hipFFT (D2Z, kernel multiply, Z2D) everywhere.
+ * "gemm_nn_own": 0 (default) the pair-density rows phi_P^T phi go through rocBLAS dgemm (74 TF/s on that shape), 1 through the
+ * hand-written MFMA NN kernel with the element-wise square in its epilogue (66-71 TF/s; profiles/r02_gemm_nn_vs_rocblas.log). */
 int isdf_set_option(isdf_handle h, const char* key, int value);
 /* Range separation of the Gamma-point Coulomb kernel used by isdf_coulomb_W / _rows / _potential / isdf_get_j, as
  * pyscf/pbc/tools/pbc.py:408-418: omega > 0 long range (erf(omega r)/r), omega < 0 short range, 0 (default) plain 1/r.
@@ -380,7 +382,9 @@ int isdf_pp_projector_overlaps(isdf_handle h, const int32_t* atm, int natm, cons
 /* Robust-fitting K (Dunlap's correction on top of the ISDF exchange).  With V_P = conv(Theta_P) kept
  * on the device, per batch of points:  F (nb, G) = (phi_P D)(nb, N) . phi (N, G)  [isdf_gemm_nn],  F .*= V rows
  * [isdf_hadamard_rows],  (F phi^T)(nb, N) [isdf_gemm_nt]  ->  K1 = w phi_P^T (F phi^T);  K = K1 + K1^T - K_isdf.
- *   isdf_gemm_nn:       C (M, ldc) = alpha A (M, K; lda) B (K, N; ldb) + beta C, row-major, N contiguous (rocBLAS dgemm)
+ *   isdf_gemm_nn:       C (M, ldc) = alpha A (M, K; lda) B (K, N; ldb) + beta C, row-major, N contiguous (rocBLAS dgemm; with
+ *                       option "gemm_nn_own" the own MFMA NN kernel for alpha = 1, beta = 0 on aligned operands with
+ *                       K % 32 == 0 and full 256-row tiles)
  *   isdf_hadamard_rows: X (rows, ldx) .*= Y (rows, ldy) on `cols` columns */
 int isdf_gemm_nn(isdf_handle h, int M, int64_t N, int K, double alpha, const double* d_A, int64_t lda, const double* d_B,
                  int64_t ldb, double beta, double* d_C, int64_t ldc);

@@ -31,6 +31,8 @@ class HipBackend:
             self.set_option('trsm_substitution', 1)
         if os.environ.get('ISDF_OWN_FFT') == '0':         # A/B runs: hipFFT instead of fft_conv.hip
             self.set_option('own_fft', 0)
+        if os.environ.get('ISDF_GEMM_NN') == '1':         # A/B runs: own MFMA NN kernel for the pair-density rows instead of rocBLAS
+            self.set_option('gemm_nn_own', 1)
 
     # ---- memory -------------------------------------------------------------------------------
     def empty(self, shape, dtype=torch.float64):

@@ -54,6 +54,9 @@ struct isdf_ctx {
   int trsm_substitution = 0;
   // Coulomb convolution: 1 = the hand-written five-pass FFT of fft_conv.hip where the mesh allows (default), 0 = hipFFT
   int own_fft = 1;
+  // pair-density rows aoP ao: 0 = rocBLAS dgemm (default: 74 TF/s on that shape), 1 = the own MFMA NN kernel of gemm_f64.hip with
+  // the square fused into its epilogue (66-71 TF/s; kept as the library-free route and for A/B runs)
+  int gemm_nn_own = 0;
   // range-separation parameter of the Gamma-point Coulomb kernel table (0 = plain 1/r); isdf_set_coulomb_omega
   double coul_omega = 0.0;
   // spherical truncation radius of the Coulomb kernel (exxdiv='vcut_sph', pbc.py:312-317); 0 = none.  isdf_set_coulomb_cutoff
@@ -145,6 +148,12 @@ int tri_left(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64
 int tri_right(isdf_handle h, bool trans, int m, int64_t n, const double* L, int64_t ldl, double* X, int64_t ldx);
 // Row-major wrappers over rocBLAS for the well-shaped products.
 // C (M x N, ldc) = alpha * op(A) * op(B) + beta * C, all row-major; opA/opB 'N' or 'T'.
+// C = A B (or its element-wise square), A (M x K) and B (K x N) row-major, on the own MFMA NN kernel (gemm_f64.hip); callers test
+// gemm_nn_f64_supported first and fall back to gemm_rm (+ a square pass)
+bool gemm_nn_f64_supported(isdf_handle h, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B,
+                           int64_t ldb);
+int gemm_nn_f64(isdf_handle h, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb,
+                double* C, int64_t ldc, bool square);
 int gemm_rm(isdf_handle h, char opA, char opB, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
             int64_t ldc);

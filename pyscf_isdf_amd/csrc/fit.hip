@@ -54,6 +54,20 @@ __global__ void transpose_gather_kernel(const double* __restrict__ ao, int64_t l
 
 }  // namespace
 
+// rows <- aoP ao (P x ng), element-wise squared when `square`: the own MFMA NN kernel with the square in its epilogue where the
+// operands fit it (gemm_f64.hip), else rocBLAS and a separate pass
+static int product_rows(isdf_handle h, int P, int64_t ng, int nao, const double* d_aoP, const double* d_ao, int64_t ld,
+                        double* d_B, int64_t ldb, bool square) {
+  if (gemm_nn_f64_supported(h, P, ng, nao, d_aoP, nao, d_ao, ld))
+    return gemm_nn_f64(h, P, ng, nao, d_aoP, nao, d_ao, ld, d_B, ldb, square);
+  int rc = gemm_rm(h, 'N', 'N', P, ng, nao, 1.0, d_aoP, nao, d_ao, ld, 0.0, d_B, ldb);
+  if (rc || !square) return rc;
+  hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(ng, 256), (unsigned)P), dim3(256), 0, h->stream, d_B, (int64_t)P, ng,
+                     ldb);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
 extern "C" int isdf_fit_from_chol(isdf_handle h, double* d_L, int k, int64_t m, int64_t ldL,
                                   const int64_t* d_piv) {
   if (!h) return ISDF_ERR_ARG;
@@ -168,7 +182,7 @@ extern "C" int isdf_fit_apply_cplx(isdf_handle h, const double* d_chol, const do
   ARG_CHECK(h, P <= 65535 && ldt < (int64_t)2147483647 && ng < (int64_t)2147483647);
   // B = (aoP ao)^2 (P x ng, row-major) written straight into theta; then in the column-major view
   // X = B_cm U^-1 U^-T  (A = U^T U).
-  int rc = gemm_rm(h, 'N', 'N', P, ng, nao, 1.0, d_aoP, nao, d_ao, ld, 0.0, d_theta, ldt);
+  int rc = product_rows(h, P, ng, nao, d_aoP, d_ao, ld, d_theta, ldt, nh == 0);
   if (rc) return rc;
   if (nh > 0) {
     // complex mode: B = (aoP X)^2 + (aoP_rot X)^2, the second product in column chunks
@@ -184,9 +198,6 @@ extern "C" int isdf_fit_apply_cplx(isdf_handle h, const double* d_chol, const do
       hipLaunchKernelGGL(square_add_kernel, dim3((unsigned)cdiv(nc, 256), (unsigned)P), dim3(256), 0, h->stream,
                          d_theta + c0, ldt, tmp, CH, nc);
     }
-  } else {
-    hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(ng, 256), (unsigned)P), dim3(256), 0, h->stream,
-                       d_theta, (int64_t)P, ng, ldt);
   }
   KERNEL_CHECK(h);
   // Theta = A^-1 B with A = Lr Lr^T (Lr = the factor read row-major, lower): forward solve Y = Lr^-1 B, then (unless the
@@ -281,7 +292,7 @@ extern "C" int isdf_pair_gram_rows(isdf_handle h, const double* d_aoP, int P, in
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_aoP && d_ao && d_B && P > 0 && P <= 65535 && nao > 0 && ng > 0 && ld >= ng && ldb >= ng);
   ARG_CHECK(h, nh == 0 || 2 * nh == nao);
-  int rc = gemm_rm(h, 'N', 'N', P, ng, nao, 1.0, d_aoP, nao, d_ao, ld, 0.0, d_B, ldb);
+  int rc = product_rows(h, P, ng, nao, d_aoP, d_ao, ld, d_B, ldb, nh == 0);
   if (rc) return rc;
   if (nh > 0) {
     const int64_t CH = 8192;
@@ -296,9 +307,6 @@ extern "C" int isdf_pair_gram_rows(isdf_handle h, const double* d_aoP, int P, in
       hipLaunchKernelGGL(square_add_kernel, dim3((unsigned)cdiv(nc, 256), (unsigned)P), dim3(256), 0, h->stream,
                          d_B + c0, ldb, tmp, CH, nc);
     }
-  } else {
-    hipLaunchKernelGGL(square_kernel, dim3((unsigned)cdiv(ng, 256), (unsigned)P), dim3(256), 0, h->stream, d_B,
-                       (int64_t)P, ng, ldb);
   }
   KERNEL_CHECK(h);
   return ISDF_OK;
@@ -450,14 +458,15 @@ extern "C" int isdf_pair_rows_block_apply(isdf_handle h, const double* d_aoP, in
                                           int64_t ld, const double* d_Dinv, int64_t ldd, int nblk, const int32_t* blk_off,
                                           double* d_B, int64_t ldb) {
   // B (P rows = the rows of the blocks, ng) <- Dinv_b (aoP ao)^2: the pair-gram rows and the block solves of the S3c route
-  // in two passes over B instead of three - the product aoP ao (rocBLAS), then the MFMA block apply, which squares its
-  // input while staging it
+  // in two passes over B instead of three - the product aoP ao (rocBLAS; the own NN kernel under option gemm_nn_own, which
+  // squares in its epilogue), then the MFMA block apply, which otherwise squares its input while staging it
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_aoP && d_ao && d_Dinv && d_B && blk_off && P > 0 && nao > 0 && ng > 0 && ld >= ng && ldb >= ng && nblk > 0);
   ARG_CHECK(h, blk_off[0] == 0 && blk_off[nblk] == P);
-  int rc = gemm_rm(h, 'N', 'N', P, ng, nao, 1.0, d_aoP, nao, d_ao, ld, 0.0, d_B, ldb);
+  const bool own = gemm_nn_f64_supported(h, P, ng, nao, d_aoP, nao, d_ao, ld);   // squares in its epilogue
+  int rc = product_rows(h, P, ng, nao, d_aoP, d_ao, ld, d_B, ldb, own);
   if (rc) return rc;
-  return block_apply_inverse(h, d_Dinv, ldd, nblk, blk_off, d_B, ldb, ng, true);
+  return block_apply_inverse(h, d_Dinv, ldd, nblk, blk_off, d_B, ldb, ng, !own);
 }
 
 extern "C" int isdf_shift_diag(isdf_handle h, double* d_A, int P, double shift_rel) {

@@ -517,6 +517,163 @@ __global__ __launch_bounds__(TPBD, 2) void gemm_nt_mfma_kernel_d(GemmArgs g) {
   }
 }
 
+// ---- NN form: C = A B (optionally squared element-wise), A (M x K) with K contiguous, B (K x N) with N contiguous, K short
+// (the AO count) and N long (the grid): the pair-density rows (phi_P^T phi)^2 of the fit.  Same 256x128 tile, 8 waves, register
+// double buffering and pinned issue order as variant B; what changes is the B operand: a chunk is 16 full 1-KB rows of the
+// K x N matrix (one row per wave and load: perfectly coalesced), written to LDS as it comes ([k][n], rows padded to 144 doubles
+// so that the four k-groups of a fragment read start 32 banks apart) and read back as fragments B[k = 4 kk + fk][n] - 16
+// contiguous doubles per k-group.  One unit = one output tile over the whole K (no slabs: K is ~1e3, M N is ~1e10); units are
+// dealt to the XCDs in super-tiles of stm x stn tiles (32 = the workgroups one XCD runs at a time) so that the co-running
+// workgroups share stm A panels and stn B panels in that XCD's L2.
+constexpr int LDN = 144;
+
+struct GemmNNArgs {
+  const double* A; int64_t lda;
+  const double* B; int64_t ldb;
+  double* C; int64_t ldc;
+  int M, N, K;                   // K % 32 == 0, N even
+  int ntm, ntn, stm, stn, ngm;   // tiles, super-tile shape, super-tiles along M
+  int64_t nunits, nunits_pad;
+};
+
+template <bool SQ>
+__global__ __launch_bounds__(TPB2, 2) void gemm_nn_mfma_kernel(GemmNNArgs g) {
+  extern __shared__ double smem[];                      // [2][BM2*LDT] A | [2][BK*LDN] B
+  double* sA = smem;
+  double* sB = smem + 2 * BM2 * LDT;
+  const int64_t bid = blockIdx.x;
+  const int64_t per_xcd = g.nunits_pad / 8;
+  const int64_t unit = (bid % 8) * per_xcd + bid / 8;
+  if (unit >= g.nunits) return;
+  const int per = g.stm * g.stn;
+  const int64_t grp = unit / per;
+  const int within = (int)(unit - grp * per);
+  const int tm = (int)(grp % g.ngm) * g.stm + within % g.stm;
+  const int tn = (int)(grp / g.ngm) * g.stn + within / g.stm;
+  if (tm >= g.ntm || tn >= g.ntn) return;
+  const int nchunks = g.K / BK;                         // even
+  const int last = nchunks - 1;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;              // 4 x 2 waves, 64x64 each
+  const int srow = tid >> 3, sseg = tid & 7;            // A staging: row srow + 64 i, k offset 2 sseg
+  const int krow = tid >> 6, nseg = tid & 63;           // B staging: k rows krow and krow + 8, columns 2 nseg, 2 nseg + 1
+  const int mlast = g.M - 1;
+  const double* pA0 = g.A + (int64_t)min(tm * BM2 + srow, mlast) * g.lda + sseg * 2;
+  const double* pA1 = g.A + (int64_t)min(tm * BM2 + srow + 64, mlast) * g.lda + sseg * 2;
+  const double* pA2 = g.A + (int64_t)min(tm * BM2 + srow + 128, mlast) * g.lda + sseg * 2;
+  const double* pA3 = g.A + (int64_t)min(tm * BM2 + srow + 192, mlast) * g.lda + sseg * 2;
+  // columns past the edge re-read the last pair (computed, never stored)
+  const double* pB0 = g.B + (int64_t)krow * g.ldb + min(tn * BN + 2 * nseg, g.N - 2);
+  const double* pB1 = pB0 + 8 * g.ldb;
+  const int64_t bstep = (int64_t)BK * g.ldb;
+
+  double2 xa0, xa1, xa2, xa3, xb0, xb1, ya0, ya1, ya2, ya3, yb0, yb1;
+#define ISDF_NN_LOAD(C, A0, A1, A2, A3, B0, B1)                                               \
+  {                                                                                           \
+    const int off = (C) * BK;                                                                 \
+    const int64_t offb = (C) * bstep;                                                         \
+    A0 = *reinterpret_cast<const double2*>(pA0 + off);                                        \
+    A1 = *reinterpret_cast<const double2*>(pA1 + off);                                        \
+    A2 = *reinterpret_cast<const double2*>(pA2 + off);                                        \
+    A3 = *reinterpret_cast<const double2*>(pA3 + off);                                        \
+    B0 = *reinterpret_cast<const double2*>(pB0 + offb);                                       \
+    B1 = *reinterpret_cast<const double2*>(pB1 + offb);                                       \
+  }
+#define ISDF_NN_ST1(P, R) { double* q_ = (P); q_[0] = R.x; q_[1] = R.y; }
+#define ISDF_NN_STORE(BUF, A0, A1, A2, A3, B0, B1)                                            \
+  {                                                                                           \
+    double* qa = sA + (BUF) * BM2 * LDT + srow * LDT + sseg * 2;                              \
+    double* qb = sB + (BUF) * BK * LDN + krow * LDN + 2 * nseg;                               \
+    ISDF_NN_ST1(qa, A0) ISDF_NN_ST1(qa + 64 * LDT, A1) ISDF_NN_ST1(qa + 128 * LDT, A2)        \
+    ISDF_NN_ST1(qa + 192 * LDT, A3)                                                           \
+    *reinterpret_cast<double2*>(qb) = B0;                                                     \
+    *reinterpret_cast<double2*>(qb + 8 * LDN) = B1;                                           \
+  }
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int frow = lane & 15, fk = lane >> 4;
+  const int aoff = (wm * 64 + frow) * LDT + fk, boff = fk * LDN + wn * 64 + frow;
+  double a0[4], b0[4], a1[4], b1[4];
+#define ISDF_NN_FRAG(BUF, KK, AF, BF)                                                         \
+  {                                                                                           \
+    const double* pa = sA + (BUF) * BM2 * LDT + aoff;                                         \
+    const double* pb = sB + (BUF) * BK * LDN + boff;                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+      AF[i] = pa[i * 16 * LDT + (KK) * 4];                                                    \
+      BF[i] = pb[(KK) * 4 * LDN + i * 16];                                                    \
+    }                                                                                         \
+  }
+#define ISDF_NN_MFMA(AF, BF)                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(AF[i], BF[j], acc[i][j], 0, 0, 0);
+  // same issue order as variant B (see there): LDS reads / writes / global loads trickle in after every second MFMA, one
+  // barrier per chunk after k-step 2, the next chunk's first fragments prefetched under k-step 3
+#define ISDF_NN_IL() _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#define ISDF_NN_IL_L() _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                \
+    if (q_ < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#define ISDF_NN_IL_RW() _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                \
+    if (q_ < 6) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#define ISDF_NN_CHUNK(BUF, LOAD_AHEAD, STORE_NEXT)                                            \
+  {                                                                                           \
+    ISDF_NN_FRAG(BUF, 1, a1, b1)                                                              \
+    LOAD_AHEAD                                                                                \
+    ISDF_NN_MFMA(a0, b0)                                                                      \
+    ISDF_NN_IL_L()                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    ISDF_NN_FRAG(BUF, 2, a0, b0)                                                              \
+    ISDF_NN_MFMA(a1, b1)                                                                      \
+    ISDF_NN_IL()                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    ISDF_NN_FRAG(BUF, 3, a1, b1)                                                              \
+    STORE_NEXT                                                                                \
+    ISDF_NN_MFMA(a0, b0)                                                                      \
+    ISDF_NN_IL_RW()                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    __syncthreads();                                                                          \
+    ISDF_NN_FRAG(1 - (BUF), 0, a0, b0)                                                        \
+    ISDF_NN_MFMA(a1, b1)                                                                      \
+    ISDF_NN_IL()                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  }
+
+  ISDF_NN_LOAD(0, xa0, xa1, xa2, xa3, xb0, xb1)
+  ISDF_NN_LOAD(1, ya0, ya1, ya2, ya3, yb0, yb1)
+  ISDF_NN_STORE(0, xa0, xa1, xa2, xa3, xb0, xb1)
+  __syncthreads();
+  ISDF_NN_FRAG(0, 0, a0, b0)
+  __builtin_amdgcn_sched_barrier(0);
+  for (int c = 0; c < nchunks; c += 2) {
+    ISDF_NN_CHUNK(0, ISDF_NN_LOAD(min(c + 2, last), xa0, xa1, xa2, xa3, xb0, xb1), ISDF_NN_STORE(1, ya0, ya1, ya2, ya3, yb0, yb1))
+    ISDF_NN_CHUNK(1, ISDF_NN_LOAD(min(c + 3, last), ya0, ya1, ya2, ya3, yb0, yb1), ISDF_NN_STORE(0, xa0, xa1, xa2, xa3, xb0, xb1))
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tm * BM2 + wm * 64 + i * 16 + (lane >> 4) + 4 * r;
+      if (row >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = tn * BN + wn * 64 + j * 16 + (lane & 15);
+        if (col >= g.N) continue;
+        const double v = acc[i][j][r];
+        g.C[(int64_t)row * g.ldc + col] = SQ ? v * v : v;
+      }
+    }
+  }
+}
+
 __global__ void reduce_slabs_kernel(const double* __restrict__ P, int nslab, int64_t slab_stride,
                                     int M, int N, double alpha, double beta, double* __restrict__ C,
                                     int64_t ldc) {
@@ -633,4 +790,41 @@ extern "C" int isdf_gemm_nt(isdf_handle h, int M, int N, int64_t K, double alpha
                             double beta, double* d_C, int64_t ldc) {
   if (!h) return ISDF_ERR_ARG;
   return gemm_nt_f64_scaled(h, M, N, K, alpha, d_A, lda, d_B, ldb, d_kscale, beta, d_C, ldc);
+}
+
+bool gemm_nn_f64_supported(isdf_handle h, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B,
+                           int64_t ldb) {
+  // opt-in (isdf_set_option "gemm_nn_own"): measured on the pair-row shapes of configs[2] the kernel reaches 69.5-71 TF/s
+  // alone and 66 TF/s inside the build, rocBLAS 74-75 and 74 (profiles/r02_gemm_nn_vs_rocblas.log) - the library keeps this
+  // product by default
+  return h->gemm_nn_own && M > BM && (double)(cdiv(M, BM2) * BM2) <= 1.15 * (double)M && N >= 2 && N % 2 == 0 && K >= 32 && K % 32 == 0 &&
+         lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)A) % 16 == 0 && ((uintptr_t)B) % 16 == 0 && M < 2147483647LL &&
+         N < 2147483647LL && K < 2147483647LL;
+}
+
+int gemm_nn_f64(isdf_handle h, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb,
+                double* C, int64_t ldc, bool square) {
+  ARG_CHECK(h, A && B && C && lda >= K && ldb >= N && ldc >= N && gemm_nn_f64_supported(h, M, N, K, A, lda, B, ldb));
+  GemmNNArgs g;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.ntm = (int)cdiv(M, BM2); g.ntn = (int)cdiv(N, BN);
+  g.stm = g.ntm >= 4 ? 4 : (g.ntm >= 2 ? 2 : 1);
+  g.stn = 32 / g.stm;
+  g.ngm = (int)cdiv(g.ntm, g.stm);
+  g.nunits = (int64_t)g.ngm * cdiv(g.ntn, g.stn) * 32;
+  g.nunits_pad = cdiv(g.nunits, 8) * 8;
+  ARG_CHECK(h, g.nunits_pad < 2147483647LL);
+  const size_t lds = sizeof(double) * 2 * (BM2 * LDT + BK * LDN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nn_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nn_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  ProfScope ps(h, square ? "gemm_nn_mfma_kernel<true>[flop]" : "gemm_nn_mfma_kernel<false>[flop]", 2.0 * M * N * (double)K);
+  if (square) hipLaunchKernelGGL(gemm_nn_mfma_kernel<true>, dim3((unsigned)g.nunits_pad), dim3(TPB2), lds, h->stream, g);
+  else hipLaunchKernelGGL(gemm_nn_mfma_kernel<false>, dim3((unsigned)g.nunits_pad), dim3(TPB2), lds, h->stream, g);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
 }

@@ -199,6 +199,9 @@ extern "C" int isdf_gemm_nn(isdf_handle h, int M, int64_t N, int K, double alpha
                             const double* d_B, int64_t ldb, double beta, double* d_C, int64_t ldc) {
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_A && d_B && d_C && M > 0 && N > 0 && K > 0 && lda >= K && ldb >= N && ldc >= N);
+  // the own MFMA NN kernel for the plain product on operands it fits (row panels of >= 222 rows, K % 32 == 0), rocBLAS otherwise
+  if (alpha == 1.0 && beta == 0.0 && gemm_nn_f64_supported(h, M, N, K, d_A, lda, d_B, ldb))
+    return gemm_nn_f64(h, M, N, K, d_A, lda, d_B, ldb, d_C, ldc, false);
   return gemm_rm(h, 'N', 'N', M, N, K, alpha, d_A, lda, d_B, ldb, beta, d_C, ldc);
 }
 

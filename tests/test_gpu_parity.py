@@ -412,6 +412,42 @@ def test_gemm_nt_mfma(be, M, N, K, scaled):
     assert abs(be.to_host(C) - ref).max() < 1e-12 * scale
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 128, 32), (512, 130, 64), (1000, 1002, 96), (1280, 4226, 32), (2304, 700, 416),
+                                   # outside the kernel's shape (row padding, odd K): the rocBLAS route of the same entry point
+                                   (300, 128, 64), (512, 200, 40)])
+def test_gemm_nn_mfma(be, M, N, K):
+    """The opt-in FP64 MFMA NN kernel for the pair-density rows (option gemm_nn_own): C = A B with A (M, K) and B (K, N) row-major, ragged column tiles,
+    super-tile padding (4 x 8 tiles per XCD round) and strided operands, against numpy; 1e-12 relative to |A||B|."""
+    rng = np.random.default_rng(M + 3 * N + K)
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((K, N + 6))
+    dB = be.to_device(B)[:, 2:2 + N]                     # a column window: ldb > N, 16-byte aligned start
+    C = be.to_device(np.full((M, N + 4), 7.0))
+    be.set_option('gemm_nn_own', 1)
+    try:
+        be.gemm_nn(be.to_device(A), dB, C[:, :N])
+    finally:
+        be.set_option('gemm_nn_own', 0)
+    out = be.to_host(C)
+    assert abs(out[:, :N] - A.dot(B[:, 2:2 + N])).max() < 1e-12 * np.sqrt(K) * 10
+    assert (out[:, N:] == 7.0).all()                     # nothing written past the last column
+
+
+def test_pair_gram_rows_squared_epilogue(be):
+    """isdf_pair_gram_rows on a shape the own NN kernel takes (512 points, 64 functions): the square is applied in the
+    kernel's epilogue; same numbers as the product-then-square of the reference formulation."""
+    rng = np.random.default_rng(11)
+    P, nao, ng = 512, 64, 3000
+    aoP = rng.standard_normal((P, nao)); ao = rng.standard_normal((nao, ng))
+    B = be.empty((P, ng))
+    be.set_option('gemm_nn_own', 1)
+    try:
+        be.pair_gram_rows(be.to_device(aoP), be.to_device(ao), ng, B)
+    finally:
+        be.set_option('gemm_nn_own', 0)
+    ref = aoP.dot(ao) ** 2
+    assert abs(be.to_host(B) - ref).max() < 1e-11 * abs(ref).max()
+
+
 def test_W_from_factor_both_kinds(be):
     """W without forming Theta: S^-1 [w conv(Y) Y^T] S^-T must give the same K as the explicit-Theta
     route (W itself may differ in directions K cannot see)."""
