@@ -390,6 +390,31 @@ int isdf_gemm_nn(isdf_handle h, int M, int64_t N, int K, double alpha, const dou
                  int64_t ldb, double beta, double* d_C, int64_t ldc);
 int isdf_hadamard_rows(isdf_handle h, double* d_X, int64_t ldx, const double* d_Y, int64_t ldy, int rows, int64_t cols);
 
+/* Multigrid J / LDA potential (replaces pyscf/pbc/dft/multigrid/multigrid.py:531-678 _eval_rhoG,
+ * :838-935 _get_j_pass2 and the LDA branch of :1046-1150 nr_rks; host orchestration in pyscf_isdf_amd/multigrid.py).
+ * Spectra are HALF spectra of real fields, (n0, n1, n2/2+1) complex128 per field, frequencies in numpy.fft.fftfreq order;
+ * a level mesh may not exceed the dense mesh in any dimension.
+ *   isdf_rho_pair:              rho[i, g] = sum_(mu<nA, nu<nB) aoA[mu, g] dm[i, mu, nu] aoB[nu, g]   (both AO blocks with leading
+ *                               dimension ld; the rectangular form of isdf_rho: dense x (dense + sparse) pairs of a level)
+ *   isdf_mg_embed_density:      spec[set] (+)= scale * fft(field[set] on mesh_sub) written at the matching frequencies of the
+ *                               dense mesh (multigrid.py:665-673: tools.fft, weight, _takebak_4d); accumulate = 0 overwrites
+ *                               the touched entries only - zero the spectrum first unless mesh_sub == mesh
+ *   isdf_mg_restrict_potential: field[set] = scale * sum_G spec[set][G restricted to mesh_sub] e^{iGr}   (multigrid.py:862-868:
+ *                               _take_4d, tools.ifft with scale = 1 / prod(mesh_sub), real part)
+ *   isdf_mg_coulomb_kernel:     spec[set] *= coulG of the handle's kernel state (multigrid.py:522-525)
+ *   isdf_lda_exchange:          Slater exchange of a spin-unpolarised density: exc per particle and vxc = d(rho exc)/d rho
+ *                               ('lda,' of multigrid.py:1104-1106; densities <= 1e-24 give zero)
+ *   isdf_dot:                   *result (host) = sum x_i y_i, d_y NULL: sum x_i; fixed summation order; synchronises */
+int isdf_rho_pair(isdf_handle h, const double* d_aoA, int nA, const double* d_aoB, int nB, int64_t ng, int64_t ld,
+                  const double* d_dm, int nset, double* d_rho, int64_t ldrho);
+int isdf_mg_embed_density(isdf_handle h, const double* d_field, int nset, const int32_t mesh_sub[3], double scale,
+                          double* d_spec, const int32_t mesh[3], int accumulate);
+int isdf_mg_restrict_potential(isdf_handle h, const double* d_spec, int nset, const int32_t mesh[3],
+                               const int32_t mesh_sub[3], double scale, double* d_field);
+int isdf_mg_coulomb_kernel(isdf_handle h, double* d_spec, int nset, const int32_t mesh[3], const double a[9]);
+int isdf_lda_exchange(isdf_handle h, const double* d_rho, int64_t n, double* d_exc, double* d_vxc);
+int isdf_dot(isdf_handle h, const double* d_x, const double* d_y, int64_t n, double* result);
+
 /* Dense helper behind S5/S6 (exposed for tests and micro-benchmarks):
  *   C (M, ldc) = alpha * A (M, lda) * (B (N, ldb) .* kscale[None, :])^T + beta * C,
  * K contiguous in both operands (the W = V Theta^T / vj = ao (v.ao)^T shape); d_kscale may be NULL.

@@ -1,0 +1,271 @@
+"""Oracle: multigrid J and LDA potential (numpy).  TEST INFRASTRUCTURE ONLY - never imported by the product.
+
+CPU restatement of pyscf/pbc/dft/multigrid/multigrid.py for the Gamma point:
+  * primitive cutoffs        multigrid.py:1825-1850 (_primitive_gto_cutoff), pyscf/pbc/gto/cell.py:436-448 (_estimate_ke_cutoff)
+  * task ladder              multigrid.py:1696-1822 (multi_grids_tasks_for_ke_cut: windows (ke0, ke1] growing by KE_RATIO = 1.3 from
+                             the cutoff of the 12^3 (orthogonal) / 32^3 mesh, odd meshes from pbc/tools/pbc.py:703-727, the last
+                             task takes every remaining shell on the FFT mesh; dense shells keep the primitives inside the
+                             window, sparse shells those below it)
+  * density pass             multigrid.py:531-678 (_eval_rhoG: level density, tools.fft, weight vol/ngrids, _takebak_4d at the
+                             numpy.fft.fftfreq indices of the dense mesh)
+  * potential pass           multigrid.py:838-935 (_get_j_pass2: _take_4d, tools.ifft, real part, level integrals scattered to
+                             [h,h], [h,l] and the transposed [l,h])
+  * J, rho, nr_rks (LDA)     multigrid.py:500-529, :1556-1570, :1046-1150
+with FULL complex spectra like the reference (the product uses half spectra).  A "task" here is a plain dict
+{mesh, bas, env, nH, idx_h, idx_l, Ls, rcut}: the same record the product's planner emits, so tests can run this oracle on
+the product's ladder (tight comparison, same arithmetic up to rounding) as well as on the reference's own ladder (both must
+then agree with the FFTDF J to the cell precision, which is the reference's own test: test_multigrid.py:112-131).
+
+The lattice-sum inputs of a task's collocation cell (Ls, rcut per shell) come from the caller through ``lattice_fn``: they
+are estimates the tests take from the same helpers as every other oracle AO evaluation.
+
+Parity: pinned through identities only - the reference's tests compare its multigrid J / veff with its own FFTDF J / numint
+veff at run time (no stored constants for 'lda,'); tests do the same against oracle/fftdf.py, which is pinned to the
+reference's constants (tests/test_oracle_pins.py).  The Slater exchange is the closed formula, libxc is absent: densities
+at or below 1e-24 give zero here and in the product; what libxc does below its own threshold is not pinned.
+"""
+import numpy as np
+from . import ao as oao, pbc_tools as tools
+
+ATOM_OF, ANG_OF, NPRIM_OF, NCTR_OF, PTR_EXP, PTR_COEFF, BAS_SLOTS = 0, 1, 2, 3, 5, 6, 8
+KE_RATIO = 1.3                      # multigrid.py:58
+INIT_MESH_ORTH = (12, 12, 12)       # multigrid.py:56
+INIT_MESH_NONORTH = (32, 32, 32)    # multigrid.py:57
+
+
+def _ctr_coeff(bas, env, ib):
+    nprim, nctr = bas[ib, NPRIM_OF], bas[ib, NCTR_OF]
+    p = bas[ib, PTR_COEFF]
+    return env[p:p + nprim * nctr].reshape(nctr, nprim).T
+
+
+def _exps(bas, env, ib):
+    return env[bas[ib, PTR_EXP]:bas[ib, PTR_EXP] + bas[ib, NPRIM_OF]]
+
+
+def estimate_ke_cutoff(alpha, l, c, precision):
+    """cell.py:436-448 with omega = 0."""
+    norm_ang = (2 * l + 1) / (4 * np.pi)
+    fac = 32 * np.pi ** 2 * (2 * np.pi) ** 1.5 * c ** 2 * norm_ang / (2 * alpha) ** (2 * l + .5) / precision
+    Ecut = 20.
+    Ecut = np.log(fac * (Ecut * 2) ** (l - .5) + 1.) * 4 * alpha
+    Ecut = np.log(fac * (Ecut * 2) ** (l - .5) + 1.) * 4 * alpha
+    return Ecut
+
+
+def primitive_ke_cutoff(bas, env, vol, precision):
+    """multigrid.py:1825-1850: per shell, per primitive."""
+    precision = precision / max(vol, 1)
+    out = []
+    for ib in range(len(bas)):
+        cs = abs(_ctr_coeff(bas, env, ib)).max(axis=1)
+        out.append(estimate_ke_cutoff(_exps(bas, env, ib), bas[ib, ANG_OF], cs, precision))
+    return out
+
+
+def cutoff_to_mesh(a, cutoff):
+    """pbc.py:703-727."""
+    b = 2 * np.pi * np.linalg.inv(a.T)
+    rx = np.linalg.qr(b[[1, 2, 0]].T)[1][2, 2]
+    ry = np.linalg.qr(b[[2, 0, 1]].T)[1][2, 2]
+    rz = np.linalg.qr(b.T)[1][2, 2]
+    Gmax = (2 * cutoff) ** .5 / np.abs([rx, ry, rz])
+    return np.ceil(Gmax).astype(int) * 2 + 1
+
+
+def mesh_to_cutoff(a, mesh):
+    """pbc.py:729-742."""
+    b = 2 * np.pi * np.linalg.inv(a.T)
+    rx = np.linalg.qr(b[[1, 2, 0]].T)[1][2, 2]
+    ry = np.linalg.qr(b[[2, 0, 1]].T)[1][2, 2]
+    rz = np.linalg.qr(b.T)[1][2, 2]
+    gs = (np.asarray(mesh) - 1) // 2
+    return (gs * np.array([rx, ry, rz])) ** 2 / 2
+
+
+def _sub_cell(bas, env, shells, keep_of):
+    """Shell rows ``shells`` with the primitives keep_of(ib) (multigrid.py:1706-1757: the contraction matrix keeps its kept
+    rows; shells keep all their contractions, as the reference does)."""
+    ao_loc = oao.ao_loc(bas)
+    env = list(env)
+    rows, idx = [], []
+    for ib in shells:
+        keep = keep_of(ib)
+        cs = _ctr_coeff(bas, np.asarray(env), ib)[keep]
+        es = _exps(bas, np.asarray(env), ib)[keep]
+        ptr = len(env)
+        env += list(es) + list(cs.T.ravel())
+        row = bas[ib].copy()
+        row[NPRIM_OF] = len(keep)
+        row[PTR_EXP] = ptr
+        row[PTR_COEFF] = ptr + len(keep)
+        rows.append(row)
+        idx.extend(range(ao_loc[ib], ao_loc[ib + 1]))
+    return np.asarray(rows, dtype=np.int32).reshape(-1, BAS_SLOTS), np.asarray(env, dtype=np.float64), idx
+
+
+def reference_tasks(bas, env, a, fft_mesh, precision, lattice_fn):
+    """The reference's ke-cut ladder (multigrid.py:1696-1822).  lattice_fn(bas_sub, env_sub) -> (Ls, rcut per shell)."""
+    bas = np.asarray(bas).reshape(-1, BAS_SLOTS)
+    env = np.asarray(env, dtype=np.float64)
+    a = np.asarray(a, dtype=float)
+    fft_mesh = np.asarray(fft_mesh)
+    vol = abs(np.linalg.det(a))
+    ke_prim = primitive_ke_cutoff(bas, env, vol, precision)
+    orth = abs(a - np.diag(a.diagonal())).max() < 1e-12
+    ke1 = mesh_to_cutoff(a, INIT_MESH_ORTH if orth else INIT_MESH_NONORTH).min()
+    ke_max = max(k.max() for k in ke_prim)
+    delim = [0, ke1]
+    while ke1 < ke_max:
+        ke1 *= KE_RATIO
+        delim.append(ke1)
+    tasks = []
+    for ke0, ke1 in zip(delim[:-1], delim[1:]):
+        shls_dense = [ib for ib, ke in enumerate(ke_prim) if np.any((ke0 < ke) & (ke <= ke1))]
+        if not shls_dense:
+            continue
+        mesh = cutoff_to_mesh(a, ke1)
+        last = bool(np.all(mesh >= fft_mesh))
+        if last:
+            shls_dense = [ib for ib, ke in enumerate(ke_prim) if np.any(ke0 < ke)]
+            top = ke_max + 1
+        else:
+            top = ke1
+        mesh = np.min([mesh, fft_mesh], axis=0)
+        bas_h, env_t, idx_h = _sub_cell(bas, env, shls_dense, lambda ib: np.where((ke0 < ke_prim[ib]) & (ke_prim[ib] <= top))[0])
+        shls_sparse = [ib for ib, ke in enumerate(ke_prim) if np.any(ke <= ke0)]
+        if shls_sparse:
+            bas_l, env_t, idx_l = _sub_cell(bas, env_t, shls_sparse, lambda ib: np.where(ke_prim[ib] <= ke0)[0])
+            bas_t = np.vstack([bas_h, bas_l])
+        else:
+            bas_t, idx_l = bas_h, []
+        Ls, rcut = lattice_fn(bas_t, env_t)
+        tasks.append(dict(mesh=mesh, bas=bas_t, env=env_t, nH=len(idx_h), idx_h=np.asarray(idx_h, dtype=np.int64),
+                          idx_l=np.asarray(idx_l, dtype=np.int64), Ls=Ls, rcut=rcut))
+        if last:
+            break
+    return tasks
+
+
+def uniform_grids(a, mesh):
+    """cell.py:874-898 with its default wrap_around=True: fractional coordinates numpy.fft.fftfreq(n) per axis, C order."""
+    fr = [np.fft.fftfreq(int(n)) for n in mesh]
+    f = np.stack(np.meshgrid(*fr, indexing='ij'), axis=-1).reshape(-1, 3)
+    return f.dot(a)
+
+
+def _task_ao(task, atm, a):
+    coords = uniform_grids(np.asarray(a, dtype=float), task['mesh'])
+    return oao.eval_ao(atm, task['bas'], task['env'], coords, task['Ls'], task['rcut'], rule='point')     # (G_t, nT)
+
+
+def _freq_index(mesh, fft_mesh):
+    # numpy.fft.fftfreq integers of the level mesh used as (possibly negative) indices of the dense mesh (multigrid.py:669-673)
+    return [np.fft.fftfreq(n, 1. / n).astype(np.int32) % N for n, N in zip(mesh, fft_mesh)]
+
+
+def eval_rhoG(tasks, atm, dms, a, fft_mesh):
+    """(nset, N0, N1, N2) complex density spectrum, integral-normalised (multigrid.py:531-678, hermi = 1, LDA)."""
+    a = np.asarray(a, dtype=float)
+    vol = abs(np.linalg.det(a))
+    dms = np.asarray(dms, dtype=float)
+    dms = 0.5 * (dms + dms.transpose(0, 2, 1))
+    nset = len(dms)
+    rhoG = np.zeros((nset,) + tuple(int(x) for x in fft_mesh), dtype=np.complex128)
+    for t in tasks:
+        ao = _task_ao(t, atm, a)
+        nH, idx_h, idx_l = t['nH'], t['idx_h'], t['idx_l']
+        idx_t = np.append(idx_h, idx_l)
+        mesh = tuple(int(x) for x in t['mesh'])
+        ngrids = int(np.prod(mesh))
+        rho = np.empty((nset, ngrids))
+        for i in range(nset):
+            d = dms[i][idx_h[:, None], idx_t].copy()
+            if len(idx_l):
+                d[:, nH:] += dms[i][idx_l[:, None], idx_h].T
+            rho[i] = np.einsum('gh,ht,gt->g', ao[:, :nH], d, ao, optimize=True)
+        rho_freq = tools.fft(rho, mesh) * (vol / ngrids)
+        gx, gy, gz = _freq_index(mesh, fft_mesh)
+        rhoG[:, gx[:, None, None], gy[:, None], gz] += rho_freq.reshape((nset,) + mesh)
+    return rhoG
+
+
+def integrate(tasks, atm, vG, a, fft_mesh, nao):
+    """Matrix of the potential with spectrum vG (nset, N0, N1, N2) (multigrid.py:838-935, hermi = 1)."""
+    nset = len(vG)
+    out = np.zeros((nset, nao, nao))
+    for t in tasks:
+        ao = _task_ao(t, atm, a)
+        nH, idx_h, idx_l = t['nH'], t['idx_h'], t['idx_l']
+        mesh = tuple(int(x) for x in t['mesh'])
+        gx, gy, gz = _freq_index(mesh, fft_mesh)
+        sub = vG[:, gx[:, None, None], gy[:, None], gz].reshape(nset, -1)
+        v = tools.ifft(sub, mesh).real
+        for i in range(nset):
+            vp = ao[:, :nH].T.dot(v[i][:, None] * ao)
+            out[i][idx_h[:, None], idx_h] += vp[:, :nH]
+            if len(idx_l):
+                out[i][idx_h[:, None], idx_l] += vp[:, nH:]
+                out[i][idx_l[:, None], idx_h] += vp[:, nH:].T
+    return out
+
+
+def get_j(tasks, atm, dms, a, fft_mesh):
+    """multigrid.py:500-529."""
+    dms = np.asarray(dms, dtype=float)
+    nao = dms.shape[-1]
+    rhoG = eval_rhoG(tasks, atm, dms.reshape(-1, nao, nao), a, fft_mesh)
+    coulG = tools.get_coulG(np.asarray(a, dtype=float), np.asarray(fft_mesh)).reshape(rhoG.shape[1:])
+    return integrate(tasks, atm, rhoG * coulG, a, fft_mesh, nao).reshape(dms.shape)
+
+
+def get_rho(tasks, atm, dm, a, fft_mesh):
+    """multigrid.py:1556-1570."""
+    nao = np.asarray(dm).shape[-1]
+    rhoG = eval_rhoG(tasks, atm, np.asarray(dm, dtype=float).reshape(-1, nao, nao), a, fft_mesh)
+    ngrids = int(np.prod(fft_mesh))
+    weight = abs(np.linalg.det(a)) / ngrids
+    return tools.ifft(rhoG.reshape(len(rhoG), ngrids), fft_mesh).real / weight
+
+
+def slater_exchange(rho):
+    """Spin-unpolarised LDA exchange: exc per particle = -(3/4) (3/pi)^(1/3) rho^(1/3), vxc = (4/3) exc; rho <= 1e-24 -> 0."""
+    e = np.zeros_like(rho)
+    m = rho > 1e-24
+    e[m] = -0.75 * (3.0 / np.pi) ** (1.0 / 3.0) * np.cbrt(rho[m])
+    return e, 4.0 / 3.0 * e
+
+
+def nr_rks_lda(tasks, atm, dm, a, fft_mesh, with_j=False):
+    """(nelec, exc, veff, ecoul) of one density matrix: multigrid.py:1046-1150 with xc = 'lda,' (Slater exchange)."""
+    a = np.asarray(a, dtype=float)
+    nao = np.asarray(dm).shape[-1]
+    fft_mesh = np.asarray(fft_mesh)
+    ngrids = int(np.prod(fft_mesh))
+    vol = abs(np.linalg.det(a))
+    weight = vol / ngrids
+    rhoG = eval_rhoG(tasks, atm, np.asarray(dm, dtype=float).reshape(1, nao, nao), a, fft_mesh)
+    coulG = tools.get_coulG(a, fft_mesh).reshape(rhoG.shape[1:])
+    vG = rhoG * coulG
+    ecoul = .5 * (rhoG.real * vG.real).sum() + .5 * (rhoG.imag * vG.imag).sum()
+    ecoul /= vol
+    rhoR = tools.ifft(rhoG.reshape(1, ngrids), fft_mesh).real / weight
+    nelec = rhoR[0].sum() * weight
+    exc, vxc = slater_exchange(rhoR[0])
+    excsum = (rhoR[0] * exc).sum() * weight
+    wv_freq = tools.fft((weight * vxc)[None], fft_mesh).reshape(rhoG.shape)
+    if with_j:
+        wv_freq = wv_freq + vG
+    veff = integrate(tasks, atm, wv_freq, a, fft_mesh, nao)[0]
+    return nelec, excsum, veff, ecoul
+
+
+def nr_rks_lda_dense(aoR, dm, a, fft_mesh):
+    """The same quantities on the dense grid alone (role of pyscf.pbc.dft.numint.nr_rks for 'lda,' on uniform grids, which the
+    reference's multigrid tests use as their answer: test_multigrid.py:133-142).  aoR (G, nao)."""
+    ngrids = len(aoR)
+    weight = abs(np.linalg.det(a)) / ngrids
+    rho = np.einsum('gi,ij,gj->g', aoR, 0.5 * (dm + dm.T), aoR, optimize=True)
+    exc, vxc = slater_exchange(rho)
+    veff = aoR.T.dot((weight * vxc)[:, None] * aoR)
+    return rho.sum() * weight, (rho * exc).sum() * weight, veff

@@ -399,6 +399,54 @@ class HipBackend:
         self.handle.call('isdf_gemm_nt', M, N, K, float(alpha), self._p(A), A.stride(0), self._p(B), B.stride(0), ks,
                          float(beta), self._p(C), C.stride(0))
 
+    # ---- multigrid ----------------------------------------------------------------------------
+    def rho_pair(self, aoA, aoB, ng, dm, rho):
+        """rho (nset, ng) = sum_(mu, nu) aoA[mu] dm[:, mu, nu] aoB[nu]; aoA / aoB row blocks of one AO buffer."""
+        self._stream()
+        assert aoA.stride(0) == aoB.stride(0) and aoA.stride(1) == 1 and aoB.stride(1) == 1 and dm.is_contiguous()
+        assert tuple(dm.shape[1:]) == (aoA.shape[0], aoB.shape[0])
+        self.handle.call('isdf_rho_pair', self._p(aoA), aoA.shape[0], self._p(aoB), aoB.shape[0], int(ng), aoA.stride(0),
+                         self._p(dm), dm.shape[0], self._p(rho), rho.stride(0))
+
+    def mg_embed_density(self, field, mesh_sub, scale, spec, mesh, accumulate=True):
+        """spec (nset, gc) complex128 (+)= scale * fft(field (nset, prod(mesh_sub))) at the matching frequencies of ``mesh``."""
+        self._stream()
+        mesh_sub = np.ascontiguousarray(mesh_sub, dtype=np.int32)
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        assert field.is_contiguous() and spec.is_contiguous() and spec.dtype == torch.complex128
+        assert field.shape[1] == int(np.prod(mesh_sub)) and spec.shape[1] == int(mesh[0]) * int(mesh[1]) * (int(mesh[2]) // 2 + 1)
+        self.handle.call('isdf_mg_embed_density', self._p(field), field.shape[0], _np_ptr(mesh_sub), float(scale), self._p(spec),
+                         _np_ptr(mesh), int(bool(accumulate)))
+
+    def mg_restrict_potential(self, spec, mesh, mesh_sub, scale, field):
+        """field (nset, prod(mesh_sub)) = scale * unnormalised inverse FFT of spec cut back to mesh_sub."""
+        self._stream()
+        mesh_sub = np.ascontiguousarray(mesh_sub, dtype=np.int32)
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        assert field.is_contiguous() and spec.is_contiguous() and spec.dtype == torch.complex128
+        assert field.shape[1] == int(np.prod(mesh_sub)) and spec.shape[1] == int(mesh[0]) * int(mesh[1]) * (int(mesh[2]) // 2 + 1)
+        self.handle.call('isdf_mg_restrict_potential', self._p(spec), spec.shape[0], _np_ptr(mesh), _np_ptr(mesh_sub), float(scale),
+                         self._p(field))
+
+    def mg_coulomb_kernel(self, spec, mesh, a):
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert spec.is_contiguous() and spec.dtype == torch.complex128
+        self.handle.call('isdf_mg_coulomb_kernel', self._p(spec), spec.shape[0], _np_ptr(mesh), _np_ptr(a))
+
+    def lda_exchange(self, rho, exc, vxc):
+        self._stream()
+        assert rho.is_contiguous() and exc.is_contiguous() and vxc.is_contiguous()
+        self.handle.call('isdf_lda_exchange', self._p(rho), rho.numel(), self._p(exc), self._p(vxc))
+
+    def dot(self, x, y=None):
+        self._stream()
+        assert x.is_contiguous() and (y is None or (y.is_contiguous() and y.numel() == x.numel()))
+        out = ctypes.c_double(0.0)
+        self.handle.call('isdf_dot', self._p(x), self._p(y) if y is not None else _vp(0), x.numel(), ctypes.byref(out))
+        return out.value
+
     # ---- k-points -----------------------------------------------------------------------------
     def eval_ao_k(self, atm, bas, env, Ls, rcut, kpt, periodic_part, coords_soa, out_re, out_im):
         self._stream()

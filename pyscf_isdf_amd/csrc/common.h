@@ -67,6 +67,9 @@ struct isdf_ctx {
 int isdf_fail(isdf_handle h, int code, const char* fmt, ...);
 void* isdf_ws(isdf_handle h, const char* name, size_t bytes);   // nullptr on failure (error set)
 int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out);
+// coulomb.hip: the symmetrised half-spectrum Coulomb table of the handle's kernel state for this mesh, times extra_scale / prod(mesh)
+// (workspace "coulG_half": valid until the next call)
+int get_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9], double extra_scale, double** out);
 // fft_conv.hip: d_out rows = ifft(cg * fft(d_in rows)) with the scaled half-spectrum table cg; zbuf nb * n0 n1 (n2/2+1) complex
 bool conv_rows_own_supported(const int32_t mesh[3]);
 int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, const int32_t mesh[3], const double* cg,

@@ -141,8 +141,7 @@ __global__ void mul_half_kernel(double2* __restrict__ z, const double* __restric
 }  // namespace
 
 // Build (or fetch) the scaled half-spectrum Coulomb table for this mesh/lattice.
-static int get_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9], double extra_scale,
-                          double** out) {
+int get_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9], double extra_scale, double** out) {
   const int64_t gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
   const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
   double* cg = (double*)isdf_ws(h, "coulG_half", sizeof(double) * gc);

@@ -1,0 +1,221 @@
+// Multigrid J / LDA potential (the role of pyscf/pbc/dft/multigrid/multigrid.py:500-680,838-935,
+// 1046-1150): the density of the sharp basis functions is collocated on the dense mesh, that of smoother ones on coarser
+// level meshes; the level spectra are added into the dense mesh's spectrum at the matching frequencies, the potential
+// spectrum is cut back to each level and integrated there.
+//
+// What lives here: the spectrum traffic between a level mesh and the dense mesh (half spectra of real fields throughout:
+// D2Z / Z2D, (n0, n1, n2/2+1) complex per field), the rectangular density contraction rho = sum_(mu in A, nu in B) aoA D aoB,
+// the Coulomb kernel on a spectrum, the LDA exchange kernel and a deterministic dot product.  The rectangular potential
+// integral V = aoA (v .* aoB)^T is isdf_gemm_nt with its per-k scale.
+//
+// Frequencies follow numpy.fft.fftfreq like the reference's index lists (multigrid.py:669-673): index i of an n-point axis
+// carries f = i for i < (n+1)/2, else i - n, and sits at index f (f >= 0) or N + f (f < 0) of the N-point dense axis.  Along
+// the halved axis only f >= 0 is stored on both meshes; an even level mesh's Nyquist plane (labelled -n/2 by fftfreq) goes
+// to +n/2 there, which gives the same real field after Z2D because a real field's Nyquist plane is Hermitian in-plane.
+#include "common.h"
+
+namespace {
+
+constexpr int64_t RCHUNK = 32768;   // grid columns per pass of the density contraction
+
+__device__ inline int dense_index(int i, int n, int N) {
+  const int f = (i < (n + 1) / 2) ? i : i - n;
+  return f >= 0 ? f : f + N;
+}
+
+// full[set][dense(ix,iy,iz)] (+)= scale * sub[set][ix,iy,iz]; the map is injective, so no two threads meet
+__global__ void spectrum_embed_kernel(const double2* __restrict__ sub, int n0, int n1, int n2h, int n2, double2* __restrict__ full,
+                                      int N0, int N1, int N2h, int N2, double scale, int accumulate) {
+  const int64_t gc = (int64_t)n0 * n1 * n2h;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= gc) return;
+  const int set = blockIdx.y;
+  const int iz = (int)(idx % n2h);
+  const int iy = (int)((idx / n2h) % n1);
+  const int ix = (int)(idx / ((int64_t)n2h * n1));
+  const int64_t j = ((int64_t)dense_index(ix, n0, N0) * N1 + dense_index(iy, n1, N1)) * N2h + iz;
+  const double2 v = sub[(int64_t)set * gc + idx];
+  double2* q = full + (int64_t)set * N0 * N1 * N2h + j;
+  if (accumulate) { q->x += scale * v.x; q->y += scale * v.y; }
+  else { q->x = scale * v.x; q->y = scale * v.y; }
+}
+
+__global__ void spectrum_restrict_kernel(const double2* __restrict__ full, int N0, int N1, int N2h, double2* __restrict__ sub,
+                                         int n0, int n1, int n2h, double scale) {
+  const int64_t gc = (int64_t)n0 * n1 * n2h;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= gc) return;
+  const int set = blockIdx.y;
+  const int iz = (int)(idx % n2h);
+  const int iy = (int)((idx / n2h) % n1);
+  const int ix = (int)(idx / ((int64_t)n2h * n1));
+  const int64_t j = ((int64_t)dense_index(ix, n0, N0) * N1 + dense_index(iy, n1, N1)) * N2h + iz;
+  const double2 v = full[(int64_t)set * N0 * N1 * N2h + j];
+  sub[(int64_t)set * gc + idx] = make_double2(scale * v.x, scale * v.y);
+}
+
+__global__ void spectrum_scale_kernel(double2* __restrict__ z, const double* __restrict__ table, int64_t gc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= gc) return;
+  double2* q = z + (int64_t)blockIdx.y * gc + idx;
+  const double c = table[idx];
+  q->x *= c; q->y *= c;
+}
+
+// rho[g] = sum_mu T[mu, g] * aoA[mu, g]
+__global__ void rho_pair_reduce_kernel(const double* __restrict__ T, int64_t ldT, const double* __restrict__ aoA, int64_t ld, int nA,
+                                       int64_t ng, double* __restrict__ rho) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  double s = 0.0;
+#pragma unroll 4
+  for (int mu = 0; mu < nA; ++mu) s = fma(T[(int64_t)mu * ldT + g], aoA[(int64_t)mu * ld + g], s);
+  rho[g] = s;
+}
+
+// Slater exchange of a spin-unpolarised density: exc = -(3/4) (3/pi)^(1/3) rho^(1/3) per particle, vxc = (4/3) exc.
+// Densities at or below 1e-24 (the noise floor of the collocation, negative ripples of the FFT) give zero.
+__global__ void lda_exchange_kernel(const double* __restrict__ rho, int64_t n, double* __restrict__ exc, double* __restrict__ vxc) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double r = rho[i];
+  double e = 0.0;
+  if (r > 1e-24) e = -0.75 * cbrt(3.0 / 3.14159265358979323846) * cbrt(r);
+  exc[i] = e;
+  vxc[i] = (4.0 / 3.0) * e;
+}
+
+// two-stage deterministic reduction: partial[b] = sum over block b's strided elements of x (* y)
+__global__ void dot_partial_kernel(const double* __restrict__ x, const double* __restrict__ y, int64_t n, double* __restrict__ partial) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += y ? x[i] * y[i] : x[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ void dot_final_kernel(const double* __restrict__ partial, int nb, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+bool mesh_fits(const int32_t sub[3], const int32_t full[3]) {
+  for (int d = 0; d < 3; ++d)
+    if (sub[d] <= 0 || sub[d] > full[d]) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int isdf_rho_pair(isdf_handle h, const double* d_aoA, int nA, const double* d_aoB, int nB, int64_t ng, int64_t ld,
+                             const double* d_dm, int nset, double* d_rho, int64_t ldrho) {
+  // rho[i, g] = sum_(mu < nA, nu < nB) aoA[mu, g] dm[i, mu, nu] aoB[nu, g]
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_aoA && d_aoB && d_dm && d_rho && nA > 0 && nB > 0 && ng > 0 && ld >= ng && nset > 0 && ldrho >= ng);
+  double* T = (double*)isdf_ws(h, "mg_T", sizeof(double) * (size_t)nA * RCHUNK);
+  if (!T) return ISDF_ERR_HIP;
+  for (int i = 0; i < nset; ++i) {
+    for (int64_t g0 = 0; g0 < ng; g0 += RCHUNK) {
+      const int64_t nc = std::min(RCHUNK, ng - g0);
+      int rc = gemm_rm(h, 'N', 'N', nA, nc, nB, 1.0, d_dm + (int64_t)i * nA * nB, nB, d_aoB + g0, ld, 0.0, T, RCHUNK);
+      if (rc) return rc;
+      ProfScope ps(h, "rho_pair_reduce_kernel[byte]", 16.0 * (double)nA * (double)nc);
+      hipLaunchKernelGGL(rho_pair_reduce_kernel, dim3((unsigned)cdiv(nc, 256)), dim3(256), 0, h->stream, T, RCHUNK, d_aoA + g0, ld,
+                         nA, nc, d_rho + (int64_t)i * ldrho + g0);
+      KERNEL_CHECK(h);
+    }
+  }
+  return ISDF_OK;
+}
+
+extern "C" int isdf_mg_embed_density(isdf_handle h, const double* d_field, int nset, const int32_t mesh_sub[3], double scale,
+                                     double* d_spec, const int32_t mesh[3], int accumulate) {
+  // spec[set] (+)= scale * embed(fft(field[set] on mesh_sub)) - half spectra, fields contiguous (nset, prod(mesh_sub))
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_field && d_spec && mesh_sub && mesh && nset > 0 && nset <= 65535 && mesh_fits(mesh_sub, mesh));
+  const int n2h = mesh_sub[2] / 2 + 1, N2h = mesh[2] / 2 + 1;
+  const int64_t gc = (int64_t)mesh_sub[0] * mesh_sub[1] * n2h;
+  double2* Z = (double2*)isdf_ws(h, "mg_Z", sizeof(double2) * (size_t)nset * gc);
+  if (!Z) return ISDF_ERR_HIP;
+  FftPlan* plan = nullptr;
+  int rc = isdf_get_plan(h, mesh_sub, nset, &plan);
+  if (rc) return rc;
+  const int64_t G = (int64_t)mesh_sub[0] * mesh_sub[1] * mesh_sub[2];
+  ProfScope ps(h, "mg_d2z_embed[byte]", (8.0 * G + 16.0 * gc * 3) * nset, 2);
+  FFT_TRY(h, hipfftExecD2Z(plan->fwd, (hipfftDoubleReal*)d_field, (hipfftDoubleComplex*)Z));
+  hipLaunchKernelGGL(spectrum_embed_kernel, dim3((unsigned)cdiv(gc, 256), (unsigned)nset), dim3(256), 0, h->stream, Z, mesh_sub[0],
+                     mesh_sub[1], n2h, mesh_sub[2], (double2*)d_spec, mesh[0], mesh[1], N2h, mesh[2], scale, accumulate);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_mg_restrict_potential(isdf_handle h, const double* d_spec, int nset, const int32_t mesh[3],
+                                          const int32_t mesh_sub[3], double scale, double* d_field) {
+  // field[set] = scale * ifft_unnormalised(restrict(spec[set]) to mesh_sub)   (Z2D; pass scale = 1 / prod(mesh_sub) for numpy's ifft)
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_field && d_spec && mesh_sub && mesh && nset > 0 && nset <= 65535 && mesh_fits(mesh_sub, mesh));
+  const int n2h = mesh_sub[2] / 2 + 1, N2h = mesh[2] / 2 + 1;
+  const int64_t gc = (int64_t)mesh_sub[0] * mesh_sub[1] * n2h;
+  double2* Z = (double2*)isdf_ws(h, "mg_Z", sizeof(double2) * (size_t)nset * gc);
+  if (!Z) return ISDF_ERR_HIP;
+  FftPlan* plan = nullptr;
+  int rc = isdf_get_plan(h, mesh_sub, nset, &plan);
+  if (rc) return rc;
+  const int64_t G = (int64_t)mesh_sub[0] * mesh_sub[1] * mesh_sub[2];
+  ProfScope ps(h, "mg_restrict_z2d[byte]", (8.0 * G + 16.0 * gc * 3) * nset, 2);
+  hipLaunchKernelGGL(spectrum_restrict_kernel, dim3((unsigned)cdiv(gc, 256), (unsigned)nset), dim3(256), 0, h->stream,
+                     (const double2*)d_spec, mesh[0], mesh[1], N2h, Z, mesh_sub[0], mesh_sub[1], n2h, scale);
+  KERNEL_CHECK(h);
+  FFT_TRY(h, hipfftExecZ2D(plan->bwd, (hipfftDoubleComplex*)Z, (hipfftDoubleReal*)d_field));
+  return ISDF_OK;
+}
+
+extern "C" int isdf_mg_coulomb_kernel(isdf_handle h, double* d_spec, int nset, const int32_t mesh[3], const double a[9]) {
+  // spec[set] *= coulG (the handle's kernel: 4 pi / G^2 with its range-separation / truncation state, G = 0 -> 0)
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_spec && mesh && a && nset > 0 && nset <= 65535 && mesh[0] > 0 && mesh[1] > 0 && mesh[2] > 0);
+  const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  const int64_t gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
+  double* cg = nullptr;
+  int rc = get_coulG_half(h, mesh, a, (double)G, &cg);   // the table carries 1/G by default; undo it
+  if (rc) return rc;
+  hipLaunchKernelGGL(spectrum_scale_kernel, dim3((unsigned)cdiv(gc, 256), (unsigned)nset), dim3(256), 0, h->stream, (double2*)d_spec,
+                     cg, gc);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_lda_exchange(isdf_handle h, const double* d_rho, int64_t n, double* d_exc, double* d_vxc) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_rho && d_exc && d_vxc && n > 0);
+  hipLaunchKernelGGL(lda_exchange_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, d_rho, n, d_exc, d_vxc);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_dot(isdf_handle h, const double* d_x, const double* d_y, int64_t n, double* result) {
+  // *result = sum_i x_i y_i (d_y NULL: sum_i x_i); fixed reduction order; synchronises the work stream
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_x && result && n > 0);
+  const int nb = (int)std::min<int64_t>(cdiv(n, 256), 1024);
+  double* part = (double*)isdf_ws(h, "dot_partial", sizeof(double) * 1025);
+  if (!part) return ISDF_ERR_HIP;
+  hipLaunchKernelGGL(dot_partial_kernel, dim3((unsigned)nb), dim3(256), 0, h->stream, d_x, d_y, n, part);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, h->stream, part, nb, part + 1024);
+  KERNEL_CHECK(h);
+  HIP_TRY(h, hipMemcpyAsync(result, part + 1024, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return ISDF_OK;
+}

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lib = None
 
@@ -80,6 +80,12 @@ SIGNATURES = {
     'isdf_pp_projector_overlaps': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     'isdf_gemm_nn': (c_int, [c_vp, c_int, c_i64, c_int, c_dbl, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp, c_i64]),
     'isdf_hadamard_rows': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_i64]),
+    'isdf_rho_pair': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_i64]),
+    'isdf_mg_embed_density': (c_int, [c_vp, c_vp, c_int, c_vp, c_dbl, c_vp, c_vp, c_int]),
+    'isdf_mg_restrict_potential': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_dbl, c_vp]),
+    'isdf_mg_coulomb_kernel': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp]),
+    'isdf_lda_exchange': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    'isdf_dot': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     'isdf_gemm_nt': (c_int, [c_vp, c_int, c_int, c_i64, c_dbl, c_vp, c_i64, c_vp, c_i64, c_vp, c_dbl, c_vp, c_i64]),
     'isdf_get_k_exact': (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'isdf_get_k': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]),

@@ -76,6 +76,52 @@ class OracleBackend:
         v = oao.eval_ao(atm, bas, env, coords_soa.numpy().T, Ls, rcut, rule='point')
         ao[:, :v.shape[0]] = torch.from_numpy(np.ascontiguousarray(v.T))
 
+    # ---- multigrid (half spectra, numpy rfftn / irfftn) ----
+    @staticmethod
+    def _dense_index(n, N):
+        f = np.fft.fftfreq(n, 1. / n).astype(np.int64)
+        return np.where(f >= 0, f, f + N)
+
+    def rho_pair(self, aoA, aoB, ng, dm, rho):
+        A, B = aoA.numpy()[:, :ng], aoB.numpy()[:, :ng]
+        for i in range(dm.shape[0]):
+            rho[i, :ng] = torch.from_numpy(np.einsum('hg,hg->g', A, dm[i].numpy().dot(B)))
+
+    def mg_embed_density(self, field, mesh_sub, scale, spec, mesh, accumulate=True):
+        n, N = [int(x) for x in mesh_sub], [int(x) for x in mesh]
+        sub = np.fft.rfftn(field.numpy().reshape(-1, *n), axes=(1, 2, 3)) * scale
+        full = spec.numpy().reshape(-1, N[0], N[1], N[2] // 2 + 1)
+        jx, jy = self._dense_index(n[0], N[0]), self._dense_index(n[1], N[1])
+        if accumulate:
+            full[:, jx[:, None, None], jy[:, None], np.arange(n[2] // 2 + 1)] += sub
+        else:
+            full[:, jx[:, None, None], jy[:, None], np.arange(n[2] // 2 + 1)] = sub
+
+    def mg_restrict_potential(self, spec, mesh, mesh_sub, scale, field):
+        n, N = [int(x) for x in mesh_sub], [int(x) for x in mesh]
+        full = spec.numpy().reshape(-1, N[0], N[1], N[2] // 2 + 1)
+        jx, jy = self._dense_index(n[0], N[0]), self._dense_index(n[1], N[1])
+        sub = full[:, jx[:, None, None], jy[:, None], np.arange(n[2] // 2 + 1)]
+        out = np.fft.irfftn(sub, s=n, axes=(1, 2, 3)) * (np.prod(n) * scale)
+        field.copy_(torch.from_numpy(np.ascontiguousarray(out.reshape(field.shape))))
+
+    def mg_coulomb_kernel(self, spec, mesh, a):
+        N = [int(x) for x in mesh]
+        c = tools.get_coulG(np.asarray(a, dtype=float), np.asarray(N), omega=self.omega, rc=self.rc).reshape(N)
+        mirror = c[np.ix_((-np.arange(N[0])) % N[0], (-np.arange(N[1])) % N[1], (-np.arange(N[2])) % N[2])]
+        half = (0.5 * (c + mirror))[:, :, :N[2] // 2 + 1]
+        full = spec.numpy().reshape(-1, N[0], N[1], N[2] // 2 + 1)
+        full *= half
+
+    def lda_exchange(self, rho, exc, vxc):
+        from oracle import multigrid as omg
+        e, v = omg.slater_exchange(rho.numpy())
+        exc.copy_(torch.from_numpy(e))
+        vxc.copy_(torch.from_numpy(v))
+
+    def dot(self, x, y=None):
+        return float(x.numpy().sum() if y is None else x.numpy().dot(y.numpy()))
+
     def gather_cols(self, src, idx, dst):
         dst[:, :idx.numel()] = src[:, idx]
 

@@ -1,0 +1,195 @@
+"""Multigrid J / LDA potential.
+
+CPU half (-m "not gpu"): the oracle restatement of pyscf/pbc/dft/multigrid/multigrid.py on the reference's own task ladder
+against the oracle FFTDF J (the reference's acceptance test, test_multigrid.py:112-131: |ref - out| < 1e-8) on the
+reference's two test cells (test_multigrid.py:32-50; gth-dzvp instead of gth-dzv, which is not bundled), the product's planner,
+and the product's orchestration on the CPU checker backend.  GPU half: the device path against the oracle on the same ladder
+(1e-9) and against the FFTDF J of the device (1e-8)."""
+import copy
+import numpy as np
+import pytest
+from pyscf_isdf_amd import gto
+from pyscf_isdf_amd import multigrid as pmg
+from oracle import multigrid as omg, fftdf as offt, ao as oao
+
+
+def cell_c2_orth():
+    return gto.Cell(a=np.eye(3) * 3.5668, atom='C 0 0 0; C 1.8 1.8 1.8', basis='gth-dzvp', pseudo='gth-pade', precision=1e-9,
+                    mesh=[48] * 3)
+
+
+def cell_c2_nonorth():
+    rng = np.random.default_rng(5)
+    return gto.Cell(a=np.eye(3) * 3.5668 + rng.random((3, 3)), atom='C 0 0 0; C 0.8917 0.8917 0.8917', basis='gth-dzvp',
+                    pseudo='gth-pade', precision=1e-9, mesh=[44, 43, 42])
+
+
+def cell_he():
+    # test_multigrid.py:52-58: shells that split between levels inside one contraction
+    return gto.Cell(atom='He 0 0 0', basis=[[0, (1, 1, .1), (.5, .1, 1)], [1, (.8, 1)]], unit='B', precision=1e-9, mesh=[18] * 3,
+                    a=np.eye(3) * 5)
+
+
+def cell_he_split():
+    # a sharp and a smooth primitive inside the same two contractions: the contracted functions themselves split between levels
+    return gto.Cell(atom='He 0 0 0; He 2.2 2.4 2.1', basis=[[0, (6., 1, .1), (.4, .1, 1)], [1, (.8, 1)], [2, (1.1, 1)]], unit='B',
+                    precision=1e-9, mesh=[30, 32, 30], a=np.eye(3) * 5 + np.array([[0, .3, 0], [0, 0, 0], [.2, 0, 0]]))
+
+
+def lattice_fn_for(cell):
+    def fn(bas, env):
+        sub = copy.copy(cell)
+        sub._bas, sub._env = bas, env
+        sub._rcut = gto.estimate_rcut(sub, cell.precision)
+        rcut = gto.estimate_rcut_per_shell(sub)
+        return gto.get_lattice_Ls(sub, rcut=rcut.max()), rcut
+    return fn
+
+
+def dense_ao(cell):
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    return oao.eval_ao(cell._atm, cell._bas, cell._env, cell.get_uniform_grids(), Ls, rcut, rule='point')
+
+
+def make_dm(cell, seed=2):
+    nao = cell.nao_nr()
+    dm = np.random.default_rng(seed).random((nao, nao)) * .2 + np.eye(nao)
+    return dm + dm.T
+
+
+def as_tasks(levels):
+    return [dict(mesh=l.mesh, bas=l.bas, env=l.env, nH=l.nH, idx_h=l.idx_h, idx_l=l.idx_l, Ls=l.Ls, rcut=l.rcut) for l in levels]
+
+
+@pytest.mark.parametrize('mk', [cell_c2_orth, cell_c2_nonorth, cell_he, cell_he_split])
+def test_oracle_reference_ladder_reproduces_fftdf_j(mk):
+    """The reference's own criterion on its own ladder (ratio 1.3, odd meshes from 12^3 / 32^3): 1e-8."""
+    cell = mk()
+    dm = make_dm(cell)
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    tasks = omg.reference_tasks(cell._bas, cell._env, a, mesh, cell.precision, lattice_fn_for(cell))
+    assert (np.asarray(tasks[-1]['mesh']) == mesh).all()
+    ref = offt.get_j(dense_ao(cell), dm, a, mesh)
+    assert abs(omg.get_j(tasks, cell._atm, dm, a, mesh) - ref).max() < 1e-8
+
+
+def test_planner_levels_partition_the_primitives():
+    """Every primitive is dense in exactly one level and sparse in every level above it; meshes descend from the dense mesh,
+    factor into 2, 3, 5, 7 and never drop below the floor; contractions without a primitive in a window are dropped."""
+    cell = cell_c2_orth()
+    levels = pmg.multi_grids_tasks(cell, cell.mesh, split='all')
+    assert (levels[0].mesh == cell.mesh).all() and len(levels) >= 2
+    for hi, lo in zip(levels[:-1], levels[1:]):
+        assert (lo.mesh <= hi.mesh).all() and (lo.mesh < hi.mesh).any() and hi.ke_window[0] == lo.ke_window[1]
+    nprim_total = sum(cell.bas_nprim(i) for i in range(cell.nbas))
+    NPRIM_OF, ANG_OF, NCTR_OF = 2, 1, 3
+    dense = 0
+    for lv in levels:
+        assert lv.mesh.min() >= pmg.MIN_LEVEL_MESH and all(pmg._fft_friendly(int(n)) == n for n in lv.mesh[lv.mesh < cell.mesh])
+        nsh_h = 0
+        nfun = 0
+        for row in lv.bas:                                   # dense rows come first: count rows until nH functions are covered
+            if nfun >= lv.nH:
+                break
+            nfun += (2 * row[ANG_OF] + 1) * row[NCTR_OF]
+            dense += row[NPRIM_OF]
+            nsh_h += 1
+        assert nfun == lv.nH and len(lv.idx_h) == lv.nH and len(set(lv.idx_h)) == lv.nH
+        assert len(lv.rcut) == len(lv.bas)
+    assert dense == nprim_total
+    assert len(levels[-1].idx_l) == 0
+    # gth-dzvp carbon: the second s / p contraction is one diffuse primitive - absent from the sharp levels
+    assert levels[0].nH < cell.nao_nr()
+    # the default cost model keeps a cell this small on one mesh and splits the headline cell (planning only)
+    assert len(pmg.multi_grids_tasks(cell, cell.mesh)) == 1
+    big = gto.diamond_supercell(4, mesh=(120,) * 3)
+    lv = pmg.multi_grids_tasks(big, big.mesh)
+    assert len(lv) >= 2 and sum(pmg._level_cost(l.ngrids, l.nH, l.nT) for l in lv) < pmg._level_cost(120 ** 3, big.nao_nr(), big.nao_nr())
+    assert len(pmg.multi_grids_tasks(big, big.mesh, max_levels=2)) <= 2
+
+
+@pytest.mark.parametrize('mk', [cell_c2_orth, cell_c2_nonorth, cell_he, cell_he_split])
+def test_oracle_on_product_ladder_reproduces_fftdf_j_and_lda(mk):
+    """The product's coarse ladder (ratio 3, FFT-friendly even/odd meshes) through the oracle: J to 1e-8 of the FFTDF J, the
+    LDA energy / potential to 1e-7 of the dense-grid numbers (test_multigrid.py:133-142)."""
+    cell = mk()
+    dm = make_dm(cell)
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    tasks = as_tasks(pmg.multi_grids_tasks(cell, mesh, split='all'))
+    aoR = dense_ao(cell)
+    assert abs(omg.get_j(tasks, cell._atm, dm, a, mesh) - offt.get_j(aoR, dm, a, mesh)).max() < 1e-8
+    n, e, v, ecoul = omg.nr_rks_lda(tasks, cell._atm, dm, a, mesh)
+    n0, e0, v0 = omg.nr_rks_lda_dense(aoR, dm, a, mesh)
+    assert abs(n - n0) < 1e-7 and abs(e - e0) < 1e-7 and abs(v - v0).max() < 1e-7
+    vj = offt.get_j(aoR, dm, a, mesh)
+    assert abs(ecoul - 0.5 * np.einsum('ij,ji', vj, 0.5 * (dm + dm.T))) < 1e-7
+
+
+def _check_product_against_oracle(df, cell, tol):
+    dm = make_dm(cell)
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    dms = np.stack([dm, make_dm(cell, seed=7)[::-1, ::-1].copy()])
+    vj = df.get_jk(dms, with_k=False)[0]
+    assert vj.shape == dms.shape
+    tasks = as_tasks(df.tasks)
+    ref = omg.get_j(tasks, cell._atm, dms, a, mesh)
+    assert abs(vj - ref).max() < tol
+    assert abs(df.get_jk(dm, with_k=False)[0] - ref[0]).max() < tol
+    rho = df.get_rho(dm)
+    assert abs(rho - omg.get_rho(tasks, cell._atm, dm, a, mesh)[0]).max() < tol * 10
+    n, e, veff = pmg.nr_rks(df, 'lda,', dm, with_j=True)
+    n0, e0, v0, ec0 = omg.nr_rks_lda(tasks, cell._atm, dm, a, mesh, with_j=True)
+    assert abs(n - n0) < tol * 100 and abs(e - e0) < tol * 100 and abs(veff - v0).max() < tol * 10
+    assert abs(veff.ecoul - ec0) < 1e-7 and veff.exc == e and veff.vj is None
+    n, e, veff = pmg.nr_rks(df, 'LDA,', dm, return_j=True)
+    assert abs(veff - omg.nr_rks_lda(tasks, cell._atm, dm, a, mesh)[2]).max() < tol * 10
+    assert abs(veff.vj - ref[0]).max() < tol
+    with pytest.raises(NotImplementedError):
+        pmg.nr_rks(df, 'pbe,pbe', dm)
+    return vj, dms
+
+
+@pytest.mark.parametrize('mk', [cell_he_split, cell_c2_nonorth])
+def test_product_orchestration_on_checker_backend(mk):
+    """pyscf_isdf_amd.multigrid end to end on tests/oracle_backend.py (half spectra by numpy rfftn) against the full-spectrum
+    oracle on the same ladder, and the FFTDF J."""
+    from oracle_backend import OracleBackend
+    cell = mk()
+    df = pmg.MultiGridFFTDF(cell, backend=OracleBackend())
+    df.split = 'all'                                         # one level per distinct mesh: small cells get several levels
+    vj, dms = _check_product_against_oracle(df, cell, 1e-10)
+    assert abs(vj[0] - offt.get_j(dense_ao(cell), dms[0], cell.lattice_vectors(), cell.mesh)).max() < 1e-8
+    assert not df._built                                     # J never triggered the ISDF fit
+    df.reset()
+    assert df.tasks is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mk', [cell_c2_orth, cell_c2_nonorth, cell_he, cell_he_split])
+def test_gpu_multigrid_j_rho_lda_match_oracle_and_fftdf(mk):
+    """The device path (multigrid.hip + eval_ao.hip + gemm_f64.hip through the C ABI) against the oracle on the same ladder
+    (1e-9) and against the device's own FFTDF-formula J (1e-8, the reference's criterion)."""
+    from pyscf_isdf_amd import ISDF
+    cell = mk()
+    df = pmg.MultiGridFFTDF(cell)
+    df.split = 'all'
+    vj, dms = _check_product_against_oracle(df, cell, 1e-9)
+    assert not df._built
+    plain = ISDF(cell, c_isdf=4, select='global')
+    ref = plain.get_jk(dms, with_k=False)[0]
+    assert abs(vj - ref).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_gpu_multigrid_pairs_with_isdf_k():
+    """get_jk(with_k=True): J from the ladder, K from the parent's interpolation - the same K as the plain ISDF object."""
+    from pyscf_isdf_amd import ISDF
+    cell = cell_c2_orth()
+    dm = make_dm(cell)
+    df = pmg.MultiGridFFTDF(cell, c_isdf=8, select='global')
+    df.split = 'all'
+    vj, vk = df.get_jk(dm)
+    plain = ISDF(cell, c_isdf=8, select='global')
+    vj0, vk0 = plain.get_jk(dm)
+    assert abs(vj - vj0).max() < 1e-8 and abs(vk - vk0).max() < 1e-9
