@@ -394,6 +394,8 @@ int isdf_hadamard_rows(isdf_handle h, double* d_X, int64_t ldx, const double* d_
  * :838-935 _get_j_pass2 and the LDA branch of :1046-1150 nr_rks; host orchestration in pyscf_isdf_amd/multigrid.py).
  * Spectra are HALF spectra of real fields, (n0, n1, n2/2+1) complex128 per field, frequencies in numpy.fft.fftfreq order;
  * a level mesh may not exceed the dense mesh in any dimension.
+ *   isdf_uniform_grid:          coords (3, G) of the uniform grid of ``mesh`` in cell.get_uniform_grids' order and folding
+ *                               (pyscf/pbc/gto/cell.py:874-898, wrap_around = True), structure of arrays, on the device
  *   isdf_rho_pair:              rho[i, g] = sum_(mu<nA, nu<nB) aoA[mu, g] dm[i, mu, nu] aoB[nu, g]   (both AO blocks with leading
  *                               dimension ld; the rectangular form of isdf_rho: dense x (dense + sparse) pairs of a level)
  *   isdf_mg_embed_density:      spec[set] (+)= scale * fft(field[set] on mesh_sub) written at the matching frequencies of the
@@ -405,6 +407,7 @@ int isdf_hadamard_rows(isdf_handle h, double* d_X, int64_t ldx, const double* d_
  *   isdf_lda_exchange:          Slater exchange of a spin-unpolarised density: exc per particle and vxc = d(rho exc)/d rho
  *                               ('lda,' of multigrid.py:1104-1106; densities <= 1e-24 give zero)
  *   isdf_dot:                   *result (host) = sum x_i y_i, d_y NULL: sum x_i; fixed summation order; synchronises */
+int isdf_uniform_grid(isdf_handle h, const int32_t mesh[3], const double a[9], double* d_coords_soa);
 int isdf_rho_pair(isdf_handle h, const double* d_aoA, int nA, const double* d_aoB, int nB, int64_t ng, int64_t ld,
                   const double* d_dm, int nset, double* d_rho, int64_t ldrho);
 int isdf_mg_embed_density(isdf_handle h, const double* d_field, int nset, const int32_t mesh_sub[3], double scale,

@@ -10,4 +10,7 @@ def __getattr__(name):
     if name == 'ISDF':
         from .isdf import ISDF
         return ISDF
+    if name == 'MultiGridFFTDF':
+        from .multigrid import MultiGridFFTDF
+        return MultiGridFFTDF
     raise AttributeError(name)

@@ -400,6 +400,15 @@ class HipBackend:
                          float(beta), self._p(C), C.stride(0))
 
     # ---- multigrid ----------------------------------------------------------------------------
+    def uniform_grid(self, mesh, a):
+        """(3, G) device coordinates of the uniform grid, cell.get_uniform_grids' order and folding."""
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out = self.empty((3, int(np.prod(mesh))))
+        self.handle.call('isdf_uniform_grid', _np_ptr(mesh), _np_ptr(a), self._p(out))
+        return out
+
     def rho_pair(self, aoA, aoB, ng, dm, rho):
         """rho (nset, ng) = sum_(mu, nu) aoA[mu] dm[:, mu, nu] aoB[nu]; aoA / aoB row blocks of one AO buffer."""
         self._stream()

@@ -111,6 +111,23 @@ __global__ void dot_final_kernel(const double* __restrict__ partial, int nb, dou
   if (threadIdx.x == 0) out[0] = sh[0];
 }
 
+// coords[d][g] = sum_i f_i a[i][d], f_i = numpy.fft.fftfreq(n_i)[index_i]: the uniform grid in the order and with the folding of
+// cell.get_uniform_grids (cell.py:874-898, wrap_around = True), structure of arrays
+__global__ void uniform_grid_kernel(double* __restrict__ coords, int n0, int n1, int n2, const double a0, const double a1,
+                                    const double a2, const double a3, const double a4, const double a5, const double a6,
+                                    const double a7, const double a8) {
+  const int64_t G = (int64_t)n0 * n1 * n2;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const int iz = (int)(g % n2), iy = (int)((g / n2) % n1), ix = (int)(g / ((int64_t)n2 * n1));
+  const double fx = (double)((ix < (n0 + 1) / 2) ? ix : ix - n0) / (double)n0;
+  const double fy = (double)((iy < (n1 + 1) / 2) ? iy : iy - n1) / (double)n1;
+  const double fz = (double)((iz < (n2 + 1) / 2) ? iz : iz - n2) / (double)n2;
+  coords[g] = fx * a0 + fy * a3 + fz * a6;
+  coords[G + g] = fx * a1 + fy * a4 + fz * a7;
+  coords[2 * G + g] = fx * a2 + fy * a5 + fz * a8;
+}
+
 bool mesh_fits(const int32_t sub[3], const int32_t full[3]) {
   for (int d = 0; d < 3; ++d)
     if (sub[d] <= 0 || sub[d] > full[d]) return false;
@@ -118,6 +135,16 @@ bool mesh_fits(const int32_t sub[3], const int32_t full[3]) {
 }
 
 }  // namespace
+
+extern "C" int isdf_uniform_grid(isdf_handle h, const int32_t mesh[3], const double a[9], double* d_coords_soa) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, mesh && a && d_coords_soa && mesh[0] > 0 && mesh[1] > 0 && mesh[2] > 0);
+  const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  hipLaunchKernelGGL(uniform_grid_kernel, dim3((unsigned)cdiv(G, 256)), dim3(256), 0, h->stream, d_coords_soa, mesh[0], mesh[1],
+                     mesh[2], a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
 
 extern "C" int isdf_rho_pair(isdf_handle h, const double* d_aoA, int nA, const double* d_aoB, int nB, int64_t ng, int64_t ld,
                              const double* d_dm, int nset, double* d_rho, int64_t ldrho) {

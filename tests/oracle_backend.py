@@ -82,6 +82,10 @@ class OracleBackend:
         f = np.fft.fftfreq(n, 1. / n).astype(np.int64)
         return np.where(f >= 0, f, f + N)
 
+    def uniform_grid(self, mesh, a):
+        from oracle import multigrid as omg
+        return torch.from_numpy(np.ascontiguousarray(omg.uniform_grids(np.asarray(a, dtype=float), mesh).T))
+
     def rho_pair(self, aoA, aoB, ng, dm, rho):
         A, B = aoA.numpy()[:, :ng], aoB.numpy()[:, :ng]
         for i in range(dm.shape[0]):

@@ -182,6 +182,18 @@ def test_gpu_multigrid_j_rho_lda_match_oracle_and_fftdf(mk):
 
 
 @pytest.mark.gpu
+def test_gpu_uniform_grid_matches_cell_grid():
+    """isdf_uniform_grid: order and folding of cell.get_uniform_grids (cell.py:874-898), even / odd and unequal meshes."""
+    from pyscf_isdf_amd.backend import HipBackend
+    be = HipBackend(0)
+    cell = cell_c2_nonorth()
+    for mesh in ([44, 43, 42], [5, 8, 3], [1, 2, 7]):
+        got = be.to_host(be.uniform_grid(mesh, cell.lattice_vectors()))
+        ref = cell.get_uniform_grids(mesh)
+        assert got.shape == (3, len(ref)) and abs(got.T - ref).max() < 1e-14
+
+
+@pytest.mark.gpu
 def test_gpu_multigrid_pairs_with_isdf_k():
     """get_jk(with_k=True): J from the ladder, K from the parent's interpolation - the same K as the plain ISDF object."""
     from pyscf_isdf_amd import ISDF

@@ -55,6 +55,10 @@ torch.cuda.empty_cache()
 for frac, label in ((0.0, 'multigrid J, levels collocated in both passes'), (0.25, 'multigrid J, level AOs resident')):
     df.ao_cache_fraction = frac
     df._level_cache = {}
-    be.prof_enable(True) if hasattr(be, 'prof_enable') else None
     vj, t_mg = timed(lambda: df.get_jk(dm, with_k=False)[0], label)
+    be.prof_enable(True); be.prof_reset()
+    df.get_jk(dm, with_k=False); be.synchronize()
+    for k, v in sorted(be.prof_results().items(), key=lambda kv: -kv[1]['ms']):
+        print('      %-40s launches %4d  %8.2f ms' % (k, v['launches'], v['ms']))
+    be.prof_enable(False)
     print('   max |J_multigrid - J_plain| = %.3e   (|J|max %.3f)' % (abs(vj - ref).max(), abs(ref).max()), flush=True)
