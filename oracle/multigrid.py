@@ -269,3 +269,89 @@ def nr_rks_lda_dense(aoR, dm, a, fft_mesh):
     exc, vxc = slater_exchange(rho)
     veff = aoR.T.dot((weight * vxc)[:, None] * aoR)
     return rho.sum() * weight, (rho * exc).sum() * weight, veff
+
+
+# ---- k-points (multigrid.py:531-678 with nkpts > 1, :838-935 with complex AOs) ----------------------------------------------
+def _task_ao_kpts(task, atm, a, kpts):
+    coords = uniform_grids(np.asarray(a, dtype=float), task['mesh'])
+    return [np.asarray(x, dtype=np.complex128)
+            for x in oao.eval_ao(atm, task['bas'], task['env'], coords, task['Ls'], task['rcut'], kpts=np.reshape(kpts, (-1, 3)),
+                                 rule='point')]
+
+
+def eval_rhoG_kpts(tasks, atm, dms, a, fft_mesh, kpts):
+    """(nset, N0, N1, N2) spectrum of rho = 1/nk sum_k sum_ij ao_i D_ij conj(ao_j) (multigrid.py:590-598), full Bloch functions;
+    dms (nset, nk, nao, nao), Hermitian or not (the density is then complex, as in the reference's hermi = 0 branch)."""
+    a = np.asarray(a, dtype=float)
+    vol = abs(np.linalg.det(a))
+    dms = np.asarray(dms, dtype=np.complex128)
+    nset, nk = dms.shape[:2]
+    rhoG = np.zeros((nset,) + tuple(int(x) for x in fft_mesh), dtype=np.complex128)
+    for t in tasks:
+        aos = _task_ao_kpts(t, atm, a, kpts)
+        nH, idx_h, idx_l = t['nH'], t['idx_h'], t['idx_l']
+        idx_t = np.append(idx_h, idx_l)
+        mesh = tuple(int(x) for x in t['mesh'])
+        ngrids = int(np.prod(mesh))
+        rho = np.zeros((nset, ngrids), dtype=np.complex128)
+        for i in range(nset):
+            for k in range(nk):
+                ao = aos[k]
+                rho[i] += np.einsum('gh,ht,gt->g', ao[:, :nH], dms[i, k][idx_h[:, None], idx_t], ao.conj(), optimize=True)
+                if len(idx_l):
+                    rho[i] += np.einsum('gl,lh,gh->g', ao[:, nH:], dms[i, k][idx_l[:, None], idx_h], ao[:, :nH].conj(), optimize=True)
+        rho_freq = tools.fft(rho, mesh) * (vol / ngrids / nk)
+        gx, gy, gz = _freq_index(mesh, fft_mesh)
+        rhoG[:, gx[:, None, None], gy[:, None], gz] += rho_freq.reshape((nset,) + mesh)
+    return rhoG
+
+
+def integrate_kpts(tasks, atm, vG, a, fft_mesh, nao, kpts_band):
+    """(nset, nband, nao, nao): conj(ao_i) v ao_j per band k-point for the potential with spectrum vG (complex in general)."""
+    nset = len(vG)
+    kpts_band = np.reshape(kpts_band, (-1, 3))
+    out = np.zeros((nset, len(kpts_band), nao, nao), dtype=np.complex128)
+    for t in tasks:
+        aos = _task_ao_kpts(t, atm, a, kpts_band)
+        nH, idx_h, idx_l = t['nH'], t['idx_h'], t['idx_l']
+        mesh = tuple(int(x) for x in t['mesh'])
+        gx, gy, gz = _freq_index(mesh, fft_mesh)
+        sub = vG[:, gx[:, None, None], gy[:, None], gz].reshape(nset, -1)
+        v = tools.ifft(sub, mesh)
+        for i in range(nset):
+            for ib, ao in enumerate(aos):
+                vw = v[i][:, None] * ao
+                out[i, ib][idx_h[:, None], idx_h] += ao[:, :nH].conj().T.dot(vw[:, :nH])
+                if len(idx_l):
+                    out[i, ib][idx_h[:, None], idx_l] += ao[:, :nH].conj().T.dot(vw[:, nH:])
+                    out[i, ib][idx_l[:, None], idx_h] += ao[:, nH:].conj().T.dot(vw[:, :nH])
+    return out
+
+
+def get_j_kpts(tasks, atm, dms, a, fft_mesh, kpts, kpts_band=None):
+    """multigrid.py:500-529 at k-points; dms (nk, nao, nao) -> (nband, nao, nao)."""
+    dms = np.asarray(dms, dtype=np.complex128)
+    nao = dms.shape[-1]
+    rhoG = eval_rhoG_kpts(tasks, atm, dms[None], a, fft_mesh, kpts)
+    coulG = tools.get_coulG(np.asarray(a, dtype=float), np.asarray(fft_mesh)).reshape(rhoG.shape[1:])
+    return integrate_kpts(tasks, atm, rhoG * coulG, a, fft_mesh, nao, kpts if kpts_band is None else kpts_band)[0]
+
+
+def nr_rks_lda_kpts(tasks, atm, dms, a, fft_mesh, kpts, with_j=False):
+    """(nelec, exc, veff (nk, nao, nao)) at k-points, 'lda,' (multigrid.py:1046-1150; the functional sees Re rho)."""
+    a = np.asarray(a, dtype=float)
+    dms = np.asarray(dms, dtype=np.complex128)
+    nao = dms.shape[-1]
+    fft_mesh = np.asarray(fft_mesh)
+    ngrids = int(np.prod(fft_mesh))
+    vol = abs(np.linalg.det(a))
+    weight = vol / ngrids
+    rhoG = eval_rhoG_kpts(tasks, atm, dms[None], a, fft_mesh, kpts)
+    coulG = tools.get_coulG(a, fft_mesh).reshape(rhoG.shape[1:])
+    rhoR = tools.ifft(rhoG.reshape(1, ngrids), fft_mesh).real / weight
+    exc, vxc = slater_exchange(rhoR[0])
+    wv_freq = tools.fft((weight * vxc)[None], fft_mesh).reshape(rhoG.shape)
+    if with_j:
+        wv_freq = wv_freq + rhoG * coulG
+    veff = integrate_kpts(tasks, atm, wv_freq, a, fft_mesh, nao, kpts)[0]
+    return rhoR[0].sum() * weight, (rhoR[0] * exc).sum() * weight, veff

@@ -27,10 +27,10 @@ scatters the small level matrices into J on the host.
 
 K is the ISDF exchange of the parent class (``MultiGridFFTDF(ISDF)``): hybrid functionals get J/XC from here and K from the
 interpolation, which is the pairing SURVEY section 8 f-3 names.  XC: only the Slater exchange ('lda,') - libxc is not part of
-this tree.  k-points: J falls through to the parent's FFTDF-formula J on the device (same numbers, no level savings).
+this tree.  k-points: the same two passes on the periodic parts u_k, real and imaginary planes stacked so that the complex
+contractions are the Gamma point's real rectangular ones (get_j_kpts, nr_rks with kpts).
 """
 import copy
-import warnings
 import numpy as np
 import torch
 from . import gto
@@ -387,6 +387,109 @@ class MultiGridFFTDF(ISDF):
             del v, V, vpad, aoT
         return out
 
+    # ---- k-points: periodic parts u_k (the Bloch phases cancel in the density and in the potential matrix) ----------
+    def _level_ao_k(self, it, kpt):
+        """(2 nT, G_t) periodic parts of level ``it`` at ``kpt``: rows (Re dense | Im dense | Re sparse | Im sparse), so that the
+        first 2 nH rows are the dense functions' real and imaginary planes and the whole buffer is the level's function set -
+        the complex contractions then ARE the real rectangular ones of the Gamma point on stacked planes."""
+        lv, be, cell = self.tasks[it], self.backend, self.cell
+        nH, nL, nb = lv.nH, lv.nT - lv.nH, lv.nbas_h
+        buf = be.zeros((2 * lv.nT, -(-lv.ngrids // 32) * 32))
+        coords_soa = be.uniform_grid(lv.mesh, cell.lattice_vectors())
+        atm = np.asarray(cell._atm)
+        be.eval_ao_k(atm, lv.bas[:nb], lv.env, lv.Ls, lv.rcut[:nb], kpt, True, coords_soa, buf[:nH], buf[nH:2 * nH])
+        if nL:
+            be.eval_ao_k(atm, lv.bas[nb:], lv.env, lv.Ls, lv.rcut[nb:], kpt, True, coords_soa, buf[2 * nH:2 * nH + nL],
+                         buf[2 * nH + nL:])
+        return buf
+
+    def _eval_rhoG_k(self, dms, kpts):
+        """Half spectrum (nset, gc) of rho = 1/nk sum_k sum_ij D^k_ij u^k_i conj(u^k_j) for HERMITIAN ``dms`` (nset, nk, nao, nao):
+        rho_t = Re sum_h u_h sum_t D'_ht conj(u_t) with D' = [D_hh | 2 D_hl] (the (l,h) products are the conjugates of (h,l))
+        = A (M B) on the stacked planes A = (Re u_H; Im u_H), B = the level buffer, M = [[Re D', Im D'], [-Im D', Re D']]."""
+        be, cell = self.backend, self.cell
+        self.build_tasks()
+        nset, nk = dms.shape[:2]
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        spec = be.zeros((nset, self._spectrum_size()), dtype=torch.complex128)
+        for it, lv in enumerate(self.tasks):
+            nH, nL = lv.nH, lv.nT - lv.nH
+            idx_t = np.append(lv.idx_h, lv.idx_l)
+            rho = be.empty((nset, lv.ngrids))
+            for k in range(nk):
+                buf = self._level_ao_k(it, kpts[k])
+                D = dms[:, k][:, lv.idx_h[:, None], idx_t]                        # (nset, nH, nT) complex
+                D[:, :, nH:] *= 2.0
+                M = np.empty((nset, 2 * nH, 2 * lv.nT))
+                for r0, (P, Q) in ((0, (D.real, D.imag)), (nH, (-D.imag, D.real))):   # rows Re u_h: [p, q]; rows Im u_h: [-q, p]
+                    M[:, r0:r0 + nH, 0:nH] = P[:, :, :nH]
+                    M[:, r0:r0 + nH, nH:2 * nH] = Q[:, :, :nH]
+                    M[:, r0:r0 + nH, 2 * nH:2 * nH + nL] = P[:, :, nH:]
+                    M[:, r0:r0 + nH, 2 * nH + nL:] = Q[:, :, nH:]
+                be.rho_pair(buf[:2 * nH], buf, lv.ngrids, be.to_device(M), rho)
+                be.mg_embed_density(rho, lv.mesh, cell.vol / lv.ngrids / nk, spec, mesh, accumulate=True)
+                del buf
+        return spec
+
+    def _integrate_k(self, vspec, kpts_band):
+        """(nset, nband, nao, nao) complex matrices conj(u_i) v u_j of a real potential given by its half spectrum."""
+        be, cell = self.backend, self.cell
+        nao = cell.nao_nr()
+        nset = vspec.shape[0]
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        out = np.zeros((nset, len(kpts_band), nao, nao), dtype=np.complex128)
+        for it, lv in enumerate(self.tasks):
+            nH, nL = lv.nH, lv.nT - lv.nH
+            v = be.empty((nset, lv.ngrids))
+            be.mg_restrict_potential(vspec, mesh, lv.mesh, 1.0 / lv.ngrids, v)
+            cre = np.r_[0:nH, 2 * nH:2 * nH + nL]
+            cim = np.r_[nH:2 * nH, 2 * nH + nL:2 * lv.nT]
+            for ib, kb in enumerate(kpts_band):
+                buf = self._level_ao_k(it, kb)
+                R = be.empty((2 * nH, 2 * lv.nT))
+                vpad = be.zeros((buf.shape[1],))
+                for i in range(nset):
+                    vpad[:lv.ngrids].copy_(v[i])
+                    be.gemm_nt(buf[:2 * nH], buf, R, kscale=vpad)
+                    Rh = be.to_host(R)
+                    # conj(a + ib) v (c + id) = (a v c + b v d) + i (a v d - b v c)
+                    V = (Rh[:nH][:, cre] + Rh[nH:][:, cim]) + 1j * (Rh[:nH][:, cim] - Rh[nH:][:, cre])
+                    out[i, ib][lv.idx_h[:, None], lv.idx_h] += V[:, :nH]
+                    if nL:
+                        out[i, ib][lv.idx_h[:, None], lv.idx_l] += V[:, nH:]
+                        out[i, ib][lv.idx_l[:, None], lv.idx_h] += V[:, nH:].conj().T
+                del buf, R, vpad
+            del v
+        return out
+
+    def _hermitian_parts(self, dms):
+        """D = H + i A with H, A Hermitian: the density of D is rho(H) + i rho(A), both real (fft_jk.py:63-72 builds a complex
+        density for hermi = 0; J is linear, so the two real densities go through the ladder one after the other)."""
+        H = 0.5 * (dms + dms.conj().transpose(0, 1, 3, 2))
+        A = -0.5j * (dms - dms.conj().transpose(0, 1, 3, 2))
+        parts = [(1.0, H)]
+        if abs(A).max() > 1e-10:
+            parts.append((1j, A))
+        return parts
+
+    def get_j_kpts(self, dm_kpts, hermi=1, kpts=None, kpts_band=None):
+        """k-point J through the level ladder (multigrid.py:500-529); shapes as df_jk._format_jks (df_jk.py:1426-1444)."""
+        kpts = np.asarray(self.kpts if kpts is None else kpts, dtype=float).reshape(-1, 3)
+        nk, nao = len(kpts), self.cell.nao_nr()
+        dm_in = np.asarray(dm_kpts)
+        dms = np.asarray(dm_in, dtype=np.complex128).reshape(-1, nk, nao, nao)
+        band_in = None if kpts_band is None else np.asarray(kpts_band, dtype=float)
+        band = kpts if band_in is None else band_in.reshape(-1, 3)
+        out_shape = dm_in.shape if band_in is None else \
+            (dm_in.shape[:-3] + ((len(band),) if band_in.ndim > 1 else ()) + (nao, nao))
+        be = self.backend
+        vj = np.zeros((dms.shape[0], len(band), nao, nao), dtype=np.complex128)
+        for fac, part in self._hermitian_parts(dms):
+            spec = self._eval_rhoG_k(part, kpts)
+            be.mg_coulomb_kernel(spec, np.asarray(self.mesh, dtype=np.int32), self.cell.lattice_vectors())
+            vj += fac * self._integrate_k(spec, band)
+        return vj.reshape(out_shape)
+
     def _real_dms(self, dm):
         dm_in = np.asarray(dm)
         nao = self.cell.nao_nr()
@@ -419,12 +522,18 @@ class MultiGridFFTDF(ISDF):
         if kpts is None:
             kpts = self.kpts
         gamma = self._is_gamma(kpts) and self._is_gamma(self.kpts) and self._is_gamma(kpts_band)
-        if not gamma or (omega is not None and abs(omega) > 0):
-            # k-points / range separation: the parent's FFTDF-formula J (same numbers, no level savings) and ISDF K
-            if with_j and not gamma:
-                warnings.warn('MultiGridFFTDF: k-point J goes through the FFTDF formula on the dense mesh')
-            self._k_requested = True          # the parent's k-point / range-separated paths live in its own build
+        if omega is not None and abs(omega) > 0:
+            # range separation: the parent's J with the attenuated kernel (dense mesh) and its own W; not a multigrid case
+            self._k_requested = True
             return ISDF.get_jk(self, dm, hermi, kpts, kpts_band, with_j, with_k, omega, exxdiv)
+        if not gamma:
+            vj = vk = None
+            if with_j:
+                vj = self.get_j_kpts(dm, hermi, kpts, kpts_band)
+            if with_k:
+                self._k_requested = True      # the k-point fit lives in the parent's build
+                vk = ISDF.get_jk(self, dm, hermi, kpts, kpts_band, False, True, omega, exxdiv)[1]
+            return vj, vk
         vj = vk = None
         if with_j:
             vj = self.get_j(dm)
@@ -436,26 +545,46 @@ class MultiGridFFTDF(ISDF):
 
 def get_j_kpts(mydf, dm_kpts, hermi=1, kpts=np.zeros((1, 3)), kpts_band=None):
     """Module-level form of the reference (multigrid.py:500-529)."""
-    return mydf.get_jk(dm_kpts, hermi, kpts, kpts_band, with_j=True, with_k=False)[0]
+    kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
+    if mydf._is_gamma(kpts) and mydf._is_gamma(kpts_band):
+        return mydf.get_jk(dm_kpts, hermi, kpts, kpts_band, with_j=True, with_k=False)[0]
+    return mydf.get_j_kpts(dm_kpts, hermi, kpts, kpts_band)
 
 
 def nr_rks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=False, return_j=False, verbose=None):
-    """XC energy and potential matrix of a closed-shell density through the level ladder (multigrid.py:1046-1150), Gamma point,
-    Slater exchange.  Returns (nelec, exc, veff) with veff tagged ecoul / exc / vj / vk like the reference's; with_j adds the
-    Coulomb potential to veff before the integration pass (one pass for J + XC)."""
+    """XC energy and potential matrix of a closed-shell density through the level ladder (multigrid.py:1046-1150), Slater
+    exchange; Gamma point (real matrices) or k-points (dm (nk, nao, nao) or (nset, nk, nao, nao), complex result on the
+    k-points or on kpts_band).  Returns (nelec, exc, veff) with veff tagged ecoul / exc / vj / vk like the reference's; with_j
+    adds the Coulomb potential to veff before the integration pass (one pass for J + XC)."""
     if not _is_slater(xc_code):
         raise NotImplementedError("xc=%r: only the Slater exchange ('lda,') is implemented (no libxc in this tree)" % (xc_code,))
     if kpts is None:
         kpts = mydf.kpts
-    if not mydf._is_gamma(kpts) or not mydf._is_gamma(kpts_band):
-        raise NotImplementedError('multigrid nr_rks is implemented at the Gamma point')
     be, cell = mydf.backend, mydf.cell
-    shape, dms = mydf._real_dms(dm_kpts)
+    gamma = mydf._is_gamma(kpts) and mydf._is_gamma(kpts_band)
+    nao = cell.nao_nr()
+    if gamma:
+        shape, dms = mydf._real_dms(dm_kpts)
+        spec = mydf._eval_rhoG(dms)
+
+        def integrate(sp):
+            return mydf._integrate(sp).reshape(shape)
+    else:
+        kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
+        dm_in = np.asarray(dm_kpts)
+        dms = np.asarray(dm_in, dtype=np.complex128).reshape(-1, len(kpts), nao, nao)
+        band_in = None if kpts_band is None else np.asarray(kpts_band, dtype=float)
+        band = kpts if band_in is None else band_in.reshape(-1, 3)
+        shape = dm_in.shape if band_in is None else (dm_in.shape[:-3] + ((len(band),) if band_in.ndim > 1 else ()) + (nao, nao))
+        # the XC functional sees the real density: the Hermitian part of D (the reference takes the real part of rho)
+        spec = mydf._eval_rhoG_k(0.5 * (dms + dms.conj().transpose(0, 1, 3, 2)), kpts)
+
+        def integrate(sp):
+            return mydf._integrate_k(sp, band).reshape(shape)
     nset = dms.shape[0]
     mesh = np.asarray(mydf.mesh, dtype=np.int32)
     G = int(np.prod(mesh))
     weight = cell.vol / G
-    spec = mydf._eval_rhoG(dms)
     rho = be.empty((nset, G))
     be.mg_restrict_potential(spec, mesh, mesh, 1.0 / cell.vol, rho)
     be.mg_coulomb_kernel(spec, mesh, cell.lattice_vectors())                 # spec now holds the Hartree potential
@@ -470,11 +599,11 @@ def nr_rks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
         excsum[i] = be.dot(rho[i], exc[i]) * weight
         ecoul[i] = 0.5 * be.dot(rho[i], vH[i]) * weight
     del exc, vH
-    vj = mydf._integrate(spec).reshape(shape) if return_j else None
+    vj = integrate(spec) if return_j else None
     if not with_j:
         spec.zero_()
     be.mg_embed_density(vxc, mesh, weight, spec, mesh, accumulate=True)      # + spectrum of the XC potential
-    veff = mydf._integrate(spec).reshape(shape)
+    veff = integrate(spec)
     if nset == 1:
         nelec, excsum, ecoul = nelec[0], excsum[0], ecoul[0]
     return nelec, excsum, TaggedArray(veff, ecoul=ecoul, exc=excsum, vj=vj, vk=None)

@@ -165,6 +165,75 @@ def test_product_orchestration_on_checker_backend(mk):
     assert df.tasks is None
 
 
+def make_kpts_dms(cell, hermitian=True, seed=3):
+    """Two k-points k, -k as in the reference's tests (test_multigrid.py:60-67) and complex density matrices on them."""
+    rng = np.random.default_rng(seed)
+    k0 = rng.random(3) * 0.4
+    kpts = np.array([k0, -k0])
+    nao = cell.nao_nr()
+    dms = rng.random((2, nao, nao)) * .2 + 1j * (rng.random((2, nao, nao)) - .5) * .1
+    if hermitian:
+        dms = dms + dms.conj().transpose(0, 2, 1) + np.eye(nao)
+    return kpts, dms
+
+
+def dense_ao_kpts(cell, kpts):
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    return oao.eval_ao(cell._atm, cell._bas, cell._env, cell.get_uniform_grids(), Ls, rcut, kpts=kpts, rule='point')
+
+
+def _check_kpts_against_oracle(df, cell, tol):
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    kpts, dms = make_kpts_dms(cell)
+    vj = df.get_jk(dms, kpts=kpts, with_k=False)[0]
+    assert vj.shape == dms.shape and np.iscomplexobj(vj)
+    tasks = as_tasks(df.tasks)
+    ref = omg.get_j_kpts(tasks, cell._atm, dms, a, mesh, kpts)
+    assert abs(vj - ref).max() < tol
+    assert abs(vj - vj.conj().transpose(0, 2, 1)).max() < tol           # Hermitian density -> Hermitian J
+    # the reference's criterion: the FFTDF J at the same k-points (test_multigrid.py:112-125), 1e-8
+    fft_ref = offt.get_jk_kpts(dense_ao_kpts(cell, kpts), dms, a, mesh, cell.get_uniform_grids(), kpts)[0]
+    assert abs(vj - fft_ref).max() < 1e-8
+    # band k-points, one (3,) vector and a list; a non-Hermitian density matrix (complex density, two real passes)
+    band = np.array([[0.1, -0.05, 0.2], [0., 0., 0.]])
+    vb = pmg.get_j_kpts(df, dms, kpts=kpts, kpts_band=band)
+    assert vb.shape == (2,) + dms.shape[1:]
+    assert abs(vb - omg.get_j_kpts(tasks, cell._atm, dms, a, mesh, kpts, band)).max() < tol
+    assert abs(df.get_jk(dms, kpts=kpts, kpts_band=band[0], with_k=False)[0] - vb[0]).max() < 1e-12
+    kpts2, dms_nh = make_kpts_dms(cell, hermitian=False)
+    vnh = df.get_jk(np.stack([dms, dms_nh]), kpts=kpts, with_k=False)[0]
+    assert vnh.shape == (2,) + dms.shape and abs(vnh[0] - vj).max() < 1e-12
+    assert abs(vnh[1] - omg.get_j_kpts(tasks, cell._atm, dms_nh, a, mesh, kpts)).max() < tol * 10
+    # LDA at k-points
+    n, e, veff = pmg.nr_rks(df, 'lda,', dms, kpts=kpts, with_j=True)
+    n0, e0, v0 = omg.nr_rks_lda_kpts(tasks, cell._atm, dms, a, mesh, kpts, with_j=True)
+    assert abs(n - n0) < tol * 100 and abs(e - e0) < tol * 100 and abs(veff - v0).max() < tol * 10 and veff.shape == dms.shape
+
+
+def test_product_kpts_on_checker_backend():
+    """k-point J / LDA of pyscf_isdf_amd.multigrid on the CPU checker backend: stacked real / imaginary planes against the
+    oracle's complex arithmetic on the same ladder, and the oracle's FFTDF J at the k-points."""
+    from oracle_backend import OracleBackend
+    cell = cell_he_split()
+    df = pmg.MultiGridFFTDF(cell, backend=OracleBackend())
+    df.split = 'all'
+    _check_kpts_against_oracle(df, cell, 1e-10)
+    assert not df._built
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mk', [cell_he_split, cell_c2_nonorth])
+def test_gpu_multigrid_kpts_match_oracle_and_fftdf(mk):
+    """The device's k-point J / LDA through the ladder (eval_ao_k on the level cells, isdf_rho_pair and isdf_gemm_nt on stacked
+    planes) against the oracle on the same ladder (1e-9) and the oracle's FFTDF J (1e-8)."""
+    cell = mk()
+    df = pmg.MultiGridFFTDF(cell)
+    df.split = 'all'
+    _check_kpts_against_oracle(df, cell, 1e-9)
+    assert not df._built
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('mk', [cell_c2_orth, cell_c2_nonorth, cell_he, cell_he_split])
 def test_gpu_multigrid_j_rho_lda_match_oracle_and_fftdf(mk):
