@@ -355,3 +355,35 @@ def nr_rks_lda_kpts(tasks, atm, dms, a, fft_mesh, kpts, with_j=False):
         wv_freq = wv_freq + rhoG * coulG
     veff = integrate_kpts(tasks, atm, wv_freq, a, fft_mesh, nao, kpts)[0]
     return rhoR[0].sum() * weight, (rhoR[0] * exc).sum() * weight, veff
+
+
+def nr_uks_lda(tasks, atm, dms, a, fft_mesh, with_j=False, kpts=None):
+    """(nelec, exc, veff (2, ...), ecoul) of an (alpha, beta) pair: multigrid.py:1152-1257 with 'lda,'.  Spin-polarised Slater
+    exchange in closed form: e = -(3/4)(3/pi)^(1/3) 2^(1/3) (rho_a^(4/3) + rho_b^(4/3)), v_s = -(3/pi)^(1/3) 2^(1/3) rho_s^(1/3)."""
+    a = np.asarray(a, dtype=float)
+    fft_mesh = np.asarray(fft_mesh)
+    ngrids = int(np.prod(fft_mesh))
+    vol = abs(np.linalg.det(a))
+    weight = vol / ngrids
+    nao = np.asarray(dms).shape[-1]
+    if kpts is None:
+        rhoG = eval_rhoG(tasks, atm, np.asarray(dms, dtype=float), a, fft_mesh)
+    else:
+        rhoG = eval_rhoG_kpts(tasks, atm, np.asarray(dms), a, fft_mesh, kpts)
+    coulG = tools.get_coulG(a, fft_mesh).reshape(rhoG.shape[1:])
+    vG = (rhoG[0] + rhoG[1]) * coulG
+    tot = rhoG[0] + rhoG[1]
+    ecoul = (.5 * (tot.real * vG.real).sum() + .5 * (tot.imag * vG.imag).sum()) / vol
+    rhoR = tools.ifft(rhoG.reshape(2, ngrids), fft_mesh).real / weight
+    c = -(3.0 / np.pi) ** (1.0 / 3.0) * 2.0 ** (1.0 / 3.0)
+    pos = np.where(2 * rhoR > 1e-24, rhoR, 0.0)
+    vxc = c * np.cbrt(pos)
+    edens = 0.75 * c * (pos[0] ** (4.0 / 3.0) + pos[1] ** (4.0 / 3.0))
+    wv_freq = tools.fft(weight * vxc, fft_mesh).reshape(rhoG.shape)
+    if with_j:
+        wv_freq = wv_freq + vG
+    if kpts is None:
+        veff = integrate(tasks, atm, wv_freq, a, fft_mesh, nao)
+    else:
+        veff = integrate_kpts(tasks, atm, wv_freq, a, fft_mesh, nao, kpts)
+    return rhoR.sum() * weight, edens.sum() * weight, veff, ecoul

@@ -609,6 +609,70 @@ def nr_rks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
     return nelec, excsum, TaggedArray(veff, ecoul=ecoul, exc=excsum, vj=vj, vk=None)
 
 
+def nr_uks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=False, return_j=False, verbose=None):
+    """Open-shell form (multigrid.py:1152-1257): dm = (alpha, beta), each (nao, nao) at the Gamma point or (nk, nao, nao) at
+    k-points.  Returns (nelec [both spins together], exc, veff (2, ...)); Slater exchange by spin scaling,
+    E_x[rho_a, rho_b] = (E_x[2 rho_a] + E_x[2 rho_b]) / 2, v_a = v_x[2 rho_a]; the Coulomb potential of with_j is that of the
+    total density."""
+    if not _is_slater(xc_code):
+        raise NotImplementedError("xc=%r: only the Slater exchange ('lda,') is implemented (no libxc in this tree)" % (xc_code,))
+    if kpts is None:
+        kpts = mydf.kpts
+    be, cell = mydf.backend, mydf.cell
+    gamma = mydf._is_gamma(kpts) and mydf._is_gamma(kpts_band)
+    nao = cell.nao_nr()
+    dm_in = np.asarray(dm_kpts)
+    if dm_in.shape[0] != 2 or dm_in.ndim != (3 if gamma else 4):
+        raise ValueError('nr_uks takes one pair (alpha, beta) of density matrices')
+    if gamma:
+        shape, dms = mydf._real_dms(dm_in)
+        spec = mydf._eval_rhoG(dms)
+
+        def integrate(sp):
+            return mydf._integrate(sp).reshape(shape)
+    else:
+        kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
+        dms = np.asarray(dm_in, dtype=np.complex128)
+        band_in = None if kpts_band is None else np.asarray(kpts_band, dtype=float)
+        band = kpts if band_in is None else band_in.reshape(-1, 3)
+        shape = dm_in.shape if band_in is None else ((2,) + ((len(band),) if band_in.ndim > 1 else ()) + (nao, nao))
+        spec = mydf._eval_rhoG_k(0.5 * (dms + dms.conj().transpose(0, 1, 3, 2)), kpts)
+
+        def integrate(sp):
+            return mydf._integrate_k(sp, band).reshape(shape)
+    mesh = np.asarray(mydf.mesh, dtype=np.int32)
+    G = int(np.prod(mesh))
+    weight = cell.vol / G
+    rho2 = be.empty((2, G))                                                  # 2 rho_sigma: what the spin-scaled functional sees
+    be.mg_restrict_potential(spec, mesh, mesh, 2.0 / cell.vol, rho2)
+    be.mg_coulomb_kernel(spec, mesh, cell.lattice_vectors())                 # spec rows: Hartree potentials of alpha and of beta
+    vH = be.empty((2, G))
+    be.mg_restrict_potential(spec, mesh, mesh, 1.0 / cell.vol, vH)
+    exc = be.empty((2, G))
+    vxc = be.empty((2, G))
+    nelec = excsum = ecoul = 0.0
+    for sp in range(2):
+        be.lda_exchange(rho2[sp], exc[sp], vxc[sp])
+        nelec += 0.5 * be.dot(rho2[sp]) * weight
+        excsum += 0.5 * be.dot(rho2[sp], exc[sp]) * weight
+        ecoul += 0.25 * (be.dot(rho2[sp], vH[0]) + be.dot(rho2[sp], vH[1])) * weight
+    vj = None
+    if return_j:
+        vj2 = integrate(spec)
+        vj = vj2[0] + vj2[1]
+    # veff_sigma = v_x[2 rho_sigma] (+ the Hartree potential of the total density): three real fields into each spin's spectrum
+    spec.zero_()
+    be.mg_embed_density(vxc, mesh, weight, spec, mesh, accumulate=True)
+    if with_j:
+        vtot = be.empty((2, G))
+        for sp in range(2):
+            vtot[sp].copy_(vH[1 - sp])
+        be.mg_embed_density(vH, mesh, weight, spec, mesh, accumulate=True)
+        be.mg_embed_density(vtot, mesh, weight, spec, mesh, accumulate=True)
+    veff = integrate(spec)
+    return nelec, excsum, TaggedArray(veff, ecoul=ecoul, exc=excsum, vj=vj, vk=None)
+
+
 def multigrid_fftdf(mf):
     """Swap a mean-field object's density-fitting object for a MultiGridFFTDF on the same cell (multigrid.py:1904-1910)."""
     old = mf.with_df

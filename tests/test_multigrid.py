@@ -147,6 +147,15 @@ def _check_product_against_oracle(df, cell, tol):
     assert abs(veff.vj - ref[0]).max() < tol
     with pytest.raises(NotImplementedError):
         pmg.nr_rks(df, 'pbe,pbe', dm)
+    # open shell: (alpha, beta) pair, spin-scaled Slater exchange, Coulomb potential of the total density
+    n, e, veff = pmg.nr_uks(df, 'lda,', dms, with_j=True, return_j=True)
+    n0, e0, v0, ec0 = omg.nr_uks_lda(tasks, cell._atm, dms, a, mesh, with_j=True)
+    assert abs(n - n0) < tol * 100 and abs(e - e0) < tol * 100 and abs(veff - v0).max() < tol * 10 and veff.shape == dms.shape
+    assert abs(veff.ecoul - ec0) < 1e-7 and abs(veff.vj - ref.sum(axis=0)).max() < tol * 2
+    # a closed shell split into equal halves gives the restricted numbers
+    nr, er, vr = pmg.nr_rks(df, 'lda,', dm)
+    nu, eu, vu = pmg.nr_uks(df, 'lda,', np.stack([dm, dm]) * .5)
+    assert abs(nr - nu) < 1e-9 and abs(er - eu) < 1e-9 and abs(vu[0] - vr).max() < 1e-9 and abs(vu[1] - vr).max() < 1e-9
     return vj, dms
 
 
@@ -209,6 +218,11 @@ def _check_kpts_against_oracle(df, cell, tol):
     n, e, veff = pmg.nr_rks(df, 'lda,', dms, kpts=kpts, with_j=True)
     n0, e0, v0 = omg.nr_rks_lda_kpts(tasks, cell._atm, dms, a, mesh, kpts, with_j=True)
     assert abs(n - n0) < tol * 100 and abs(e - e0) < tol * 100 and abs(veff - v0).max() < tol * 10 and veff.shape == dms.shape
+    pair = np.stack([dms, dms[::-1] * .5])
+    n, e, veff = pmg.nr_uks(df, 'lda,', pair, kpts=kpts, with_j=True)
+    n0, e0, v0, ec0 = omg.nr_uks_lda(tasks, cell._atm, pair, a, mesh, with_j=True, kpts=kpts)
+    assert abs(n - n0) < tol * 100 and abs(e - e0) < tol * 100 and abs(veff - v0).max() < tol * 10 and veff.shape == pair.shape
+    assert abs(veff.ecoul - ec0) < 1e-7
 
 
 def test_product_kpts_on_checker_backend():
