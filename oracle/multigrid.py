@@ -387,3 +387,63 @@ def nr_uks_lda(tasks, atm, dms, a, fft_mesh, with_j=False, kpts=None):
     else:
         veff = integrate_kpts(tasks, atm, wv_freq, a, fft_mesh, nao, kpts)
     return rhoR.sum() * weight, edens.sum() * weight, veff, ecoul
+
+
+# ---- LDA response (multigrid.py:1259-1452), 'lda,' --------------------------------------------------------------------
+def slater_exchange_fxc(rho):
+    """d2(rho exc)/d rho2 = -(1/3)(3/pi)^(1/3) rho^(-2/3); rho <= 1e-24 -> 0."""
+    f = np.zeros_like(rho)
+    m = rho > 1e-24
+    f[m] = -(1.0 / 3.0) * (3.0 / np.pi) ** (1.0 / 3.0) * np.cbrt(rho[m]) ** -2
+    return f
+
+
+def _rho_real_space(tasks, atm, dms, a, fft_mesh, kpts):
+    """(nset, G) density of a stack of matrices, complex for non-Hermitian k-point matrices; and its spectrum."""
+    fft_mesh = np.asarray(fft_mesh)
+    ngrids = int(np.prod(fft_mesh))
+    weight = abs(np.linalg.det(a)) / ngrids
+    if kpts is None:
+        rhoG = eval_rhoG(tasks, atm, dms, a, fft_mesh)
+        return tools.ifft(rhoG.reshape(len(rhoG), ngrids), fft_mesh).real / weight, rhoG
+    rhoG = eval_rhoG_kpts(tasks, atm, dms, a, fft_mesh, kpts)
+    return tools.ifft(rhoG.reshape(len(rhoG), ngrids), fft_mesh) / weight, rhoG
+
+
+def nr_fxc_lda(tasks, atm, dm0, dms, a, fft_mesh, kind='rks', with_j=False, kpts=None):
+    """Response matrices of ``dms`` around ``dm0``: kind 'rks' (multigrid.py:1259-1318), 'st' (:1321-1386; singlet = triplet
+    for exchange alone), 'uks' (:1389-1452; dm0 = (a, b), dms = (a responses..., b responses...)).  Closed forms of the
+    spin-resolved kernel: f_aa(rho_a, rho_b) = -(1/3)(3/pi)^(1/3) 2^(1/3)... = (4/9) C 2^(1/3) rho_a^(-2/3), f_ab = 0."""
+    a = np.asarray(a, dtype=float)
+    fft_mesh = np.asarray(fft_mesh)
+    ngrids = int(np.prod(fft_mesh))
+    weight = abs(np.linalg.det(a)) / ngrids
+    nao = np.asarray(dms).shape[-1]
+    dm0 = np.asarray(dm0)
+    dms = np.asarray(dms)
+    nk = 0 if kpts is None else len(kpts)
+    stack0 = dm0.reshape((-1, nao, nao) if kpts is None else (-1, nk, nao, nao))
+    stack1 = dms.reshape((-1, nao, nao) if kpts is None else (-1, nk, nao, nao))
+    rho0 = _rho_real_space(tasks, atm, stack0, a, fft_mesh, kpts)[0].real
+    rho1, rhoG1 = _rho_real_space(tasks, atm, stack1, a, fft_mesh, kpts)
+    c = (4.0 / 9.0) * (-0.75 * (3.0 / np.pi) ** (1.0 / 3.0))
+    if kind == 'rks':
+        f = slater_exchange_fxc(rho0[0])[None]
+    elif kind == 'st':
+        ra = 0.5 * rho0[0]
+        f = np.where(2 * ra > 1e-24, c * 2.0 ** (1.0 / 3.0) * np.cbrt(np.where(ra > 0, ra, 1.0)) ** -2, 0.0)[None]
+    else:
+        f = np.where(2 * rho0 > 1e-24, c * 2.0 ** (1.0 / 3.0) * np.cbrt(np.where(rho0 > 0, rho0, 1.0)) ** -2, 0.0)
+        f = np.repeat(f, len(stack1) // 2, axis=0)
+    wv = tools.fft(weight * f * rho1, fft_mesh).reshape(rhoG1.shape)
+    if with_j:
+        coulG = tools.get_coulG(a, fft_mesh).reshape(rhoG1.shape[1:])
+        if kind == 'uks':
+            half = len(stack1) // 2
+            tot = rhoG1[:half] + rhoG1[half:]
+            wv = wv + np.concatenate([tot, tot]) * coulG
+        else:
+            wv = wv + rhoG1 * coulG
+    if kpts is None:
+        return integrate(tasks, atm, wv, a, fft_mesh, nao).reshape(dms.shape)
+    return integrate_kpts(tasks, atm, wv, a, fft_mesh, nao, kpts).reshape(dms.shape)

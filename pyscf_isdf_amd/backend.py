@@ -449,6 +449,11 @@ class HipBackend:
         assert rho.is_contiguous() and exc.is_contiguous() and vxc.is_contiguous()
         self.handle.call('isdf_lda_exchange', self._p(rho), rho.numel(), self._p(exc), self._p(vxc))
 
+    def lda_exchange_fxc(self, rho, fxc):
+        self._stream()
+        assert rho.is_contiguous() and fxc.is_contiguous() and rho.numel() == fxc.numel()
+        self.handle.call('isdf_lda_exchange_fxc', self._p(rho), rho.numel(), self._p(fxc))
+
     def dot(self, x, y=None):
         self._stream()
         assert x.is_contiguous() and (y is None or (y.is_contiguous() and y.numel() == x.numel()))

@@ -85,6 +85,19 @@ __global__ void lda_exchange_kernel(const double* __restrict__ rho, int64_t n, d
   vxc[i] = (4.0 / 3.0) * e;
 }
 
+// second derivative of the Slater exchange energy density: f = d2(rho exc)/d rho2 = (4/9) C rho^(-2/3), C = -(3/4)(3/pi)^(1/3)
+__global__ void lda_exchange_fxc_kernel(const double* __restrict__ rho, int64_t n, double* __restrict__ fxc) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double r = rho[i];
+  double f = 0.0;
+  if (r > 1e-24) {
+    const double c = cbrt(r);
+    f = -(1.0 / 3.0) * cbrt(3.0 / 3.14159265358979323846) / (c * c);
+  }
+  fxc[i] = f;
+}
+
 // two-stage deterministic reduction: partial[b] = sum over block b's strided elements of x (* y)
 __global__ void dot_partial_kernel(const double* __restrict__ x, const double* __restrict__ y, int64_t n, double* __restrict__ partial) {
   __shared__ double sh[256];
@@ -228,6 +241,14 @@ extern "C" int isdf_lda_exchange(isdf_handle h, const double* d_rho, int64_t n, 
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_rho && d_exc && d_vxc && n > 0);
   hipLaunchKernelGGL(lda_exchange_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, d_rho, n, d_exc, d_vxc);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_lda_exchange_fxc(isdf_handle h, const double* d_rho, int64_t n, double* d_fxc) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_rho && d_fxc && n > 0);
+  hipLaunchKernelGGL(lda_exchange_fxc_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, d_rho, n, d_fxc);
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

@@ -25,6 +25,9 @@ What differs from the reference, by design for the GPU:
 Everything numerical runs in libmi355_isdf.so (multigrid.hip, eval_ao.hip, gemm_f64.hip); this file plans the levels and
 scatters the small level matrices into J on the host.
 
+Surface: MultiGridFFTDF (get_jk, get_j_kpts, get_rho, tasks), nr_rks, nr_uks, nr_rks_fxc, nr_rks_fxc_st, nr_uks_fxc,
+cache_xc_kernel1, multi_grids_tasks, multigrid_fftdf - the names of pyscf/pbc/dft/multigrid/__init__.py.
+
 K is the ISDF exchange of the parent class (``MultiGridFFTDF(ISDF)``): hybrid functionals get J/XC from here and K from the
 interpolation, which is the pairing SURVEY section 8 f-3 names.  XC: only the Slater exchange ('lda,') - libxc is not part of
 this tree.  k-points: the same two passes on the periodic parts u_k, real and imaginary planes stacked so that the complex
@@ -671,6 +674,154 @@ def nr_uks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
         be.mg_embed_density(vtot, mesh, weight, spec, mesh, accumulate=True)
     veff = integrate(spec)
     return nelec, excsum, TaggedArray(veff, ecoul=ecoul, exc=excsum, vj=vj, vk=None)
+
+
+# ---- linear response of the LDA potential (TDDFT / stability / Hessians), multigrid.py:1259-1500 ---------------------------
+def _density_passes(mydf, dm_in, kpts):
+    """What the response functions share: the spectra of the (real) densities a stack of matrices stands for, each with its
+    factor (Gamma: one pass; k-points: Hermitian and, if present, anti-Hermitian part), an integrator and the result shape."""
+    nao = mydf.cell.nao_nr()
+    dm_in = np.asarray(dm_in)
+    if kpts is None or mydf._is_gamma(kpts):
+        shape, dms = mydf._real_dms(dm_in)
+        return [(1.0, mydf._eval_rhoG(dms))], (lambda sp: mydf._integrate(sp).reshape(shape)), dms.shape[0]
+    kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
+    dms = np.asarray(dm_in, dtype=np.complex128).reshape(-1, len(kpts), nao, nao)
+    passes = [(fac, mydf._eval_rhoG_k(part, kpts)) for fac, part in mydf._hermitian_parts(dms)]
+    return passes, (lambda sp: mydf._integrate_k(sp, kpts).reshape(dm_in.shape)), dms.shape[0]
+
+
+def _real_space(mydf, spec, scale):
+    mesh = np.asarray(mydf.mesh, dtype=np.int32)
+    out = mydf.backend.empty((spec.shape[0], int(np.prod(mesh))))
+    mydf.backend.mg_restrict_potential(spec, mesh, mesh, scale, out)
+    return out
+
+
+def _ground_density(mydf, dm0, kpts, scale=1.0):
+    """scale * rho of the ground-state matrix (or (alpha, beta) pair) on the dense mesh, device (nset, G)."""
+    passes, _, _ = _density_passes(mydf, dm0, kpts)
+    return _real_space(mydf, passes[0][1], scale / mydf.cell.vol)
+
+
+def _response(mydf, dms, kpts, kernel_rows, with_j, total_j=False, w_scale=1.0):
+    """veff[n] = matrix of  w_scale * kernel_rows[n] * rho1[n]  (+ Hartree potential of rho1[n], or of the pair's sum with total_j)."""
+    be, cell = mydf.backend, mydf.cell
+    mesh = np.asarray(mydf.mesh, dtype=np.int32)
+    weight = cell.vol / int(np.prod(mesh))
+    passes, integrate, nset = _density_passes(mydf, dms, kpts)
+    veff = 0.0
+    for fac, spec in passes:
+        w = _real_space(mydf, spec, 1.0 / cell.vol)                          # rho1 (nset, G)
+        for n in range(nset):
+            be.hadamard_rows(w[n:n + 1], kernel_rows[n:n + 1])
+        if with_j:
+            be.mg_coulomb_kernel(spec, mesh, cell.lattice_vectors())
+            if total_j:                                                      # both spins feel the Hartree potential of the sum
+                vH = _real_space(mydf, spec, 1.0 / cell.vol)
+                swapped = be.empty(tuple(vH.shape))
+                half = nset // 2
+                swapped[:half].copy_(vH[half:])
+                swapped[half:].copy_(vH[:half])
+                be.mg_embed_density(swapped, mesh, weight, spec, mesh, accumulate=True)
+        else:
+            spec.zero_()
+        be.mg_embed_density(w, mesh, weight * w_scale, spec, mesh, accumulate=True)
+        veff = veff + fac * integrate(spec)
+    return np.asarray(veff)
+
+
+def _check_lda(xc_code):
+    if not _is_slater(xc_code):
+        raise NotImplementedError("xc=%r: only the Slater exchange ('lda,') is implemented (no libxc in this tree)" % (xc_code,))
+
+
+def _kernel_rows(mydf, rho0_dev, fxc, nrows):
+    """Device rows f[n] = f_x(density row) (or the caller's fxc), one per response density (ground-state rows repeated)."""
+    be = mydf.backend
+    if fxc is not None:
+        f = be.to_device(np.ascontiguousarray(np.asarray(fxc, dtype=np.float64).reshape(-1, rho0_dev.shape[1])))
+    else:
+        f = be.empty(tuple(rho0_dev.shape))
+        for i in range(rho0_dev.shape[0]):
+            be.lda_exchange_fxc(rho0_dev[i], f[i])
+    reps = nrows // f.shape[0]
+    if reps <= 1:
+        return f
+    out = be.empty((nrows, f.shape[1]))
+    for n in range(nrows):
+        out[n].copy_(f[n // reps])
+    return out
+
+
+def nr_rks_fxc(mydf, xc_code, dm0, dms, hermi=0, with_j=False, rho0=None, vxc=None, fxc=None, kpts=None, verbose=None):
+    """Closed-shell response matrix f_xc[rho0] rho1 (+ J[rho1]) of the matrices ``dms`` (multigrid.py:1259-1318), 'lda,'."""
+    _check_lda(xc_code)
+    be = mydf.backend
+    r0 = be.to_device(np.asarray(rho0, dtype=np.float64).reshape(1, -1)) if rho0 is not None else _ground_density(mydf, dm0, kpts)
+    nset = int(np.asarray(dms).size // (np.asarray(dm0).size))
+    return _response(mydf, dms, kpts, _kernel_rows(mydf, r0, fxc, nset), with_j)
+
+
+def nr_rks_fxc_st(mydf, xc_code, dm0, dms_alpha, singlet=True, rho0=None, vxc=None, fxc=None, kpts=None, verbose=None):
+    """Singlet / triplet response of the alpha-spin response matrices (multigrid.py:1321-1386): f_aa +- f_ab at rho_a = rho0/2.
+    For exchange alone f_ab = 0 and f_aa(rho0/2) = 2 f(rho0): singlet and triplet coincide."""
+    _check_lda(xc_code)
+    be = mydf.backend
+    if fxc is not None:
+        f = np.asarray(fxc, dtype=np.float64)
+        fxc = f[0, :, 0] + f[0, :, 1] if singlet else f[0, :, 0] - f[0, :, 1]
+        r0 = be.empty((1, fxc.size))
+    elif rho0 is not None:
+        r0 = be.to_device(2.0 * np.asarray(rho0, dtype=np.float64).reshape(2, -1)[:1])      # (rho_a, rho_b) in, total density out
+    else:
+        r0 = _ground_density(mydf, dm0, kpts)
+    nset = int(np.asarray(dms_alpha).size // (np.asarray(dm0).size))
+    return _response(mydf, dms_alpha, kpts, _kernel_rows(mydf, r0, fxc, nset), False, w_scale=1.0 if fxc is not None else 2.0)
+
+
+def nr_uks_fxc(mydf, xc_code, dm0, dms, hermi=0, with_j=False, rho0=None, vxc=None, fxc=None, kpts=None, verbose=None):
+    """Open-shell response (multigrid.py:1389-1452): dm0 = (alpha, beta), dms = (alpha responses..., beta responses...);
+    w_s = f_ss(rho0_s) rho1_s with f_ss(rho_s) = 2 f(2 rho_s) by spin scaling, the Coulomb term of with_j from rho1_a + rho1_b."""
+    _check_lda(xc_code)
+    if fxc is not None:
+        raise NotImplementedError('nr_uks_fxc with a caller-supplied kernel')
+    be = mydf.backend
+    r0 = be.to_device(2.0 * np.asarray(rho0, dtype=np.float64).reshape(2, -1)) if rho0 is not None \
+        else _ground_density(mydf, dm0, kpts, scale=2.0)
+    nset = int(np.asarray(dms).size // (np.asarray(dm0).size // 2))
+    return _response(mydf, dms, kpts, _kernel_rows(mydf, r0, None, nset), with_j, total_j=True, w_scale=2.0)
+
+
+def cache_xc_kernel1(mydf, xc_code, dm, spin=0, kpts=None):
+    """(rho, vxc, fxc) of the ground state for the response functions (multigrid.py:1457-1500), array shapes of eval_xc_eff for
+    an LDA: spin 0 -> rho (G,), vxc (1, G), fxc (1, 1, G); spin 1 -> rho (2, G), vxc (2, 1, G), fxc (2, 1, 2, 1, G)."""
+    _check_lda(xc_code)
+    be = mydf.backend
+    rho = _ground_density(mydf, dm, kpts)
+    if spin == 0:
+        if rho.shape[0] != 1:
+            raise ValueError('spin = 0 takes one density matrix')
+        e, v, f = be.empty(tuple(rho.shape)), be.empty(tuple(rho.shape)), be.empty(tuple(rho.shape))
+        be.lda_exchange(rho[0], e[0], v[0])
+        be.lda_exchange_fxc(rho[0], f[0])
+        return be.to_host(rho)[0], be.to_host(v), be.to_host(f)[None]
+    r = be.to_host(rho)
+    if r.shape[0] == 1:
+        r = np.repeat(r, 2, axis=0) * .5
+    r2 = be.to_device(2.0 * r)
+    e, v, f = be.empty((2, r.shape[1])), be.empty((2, r.shape[1])), be.empty((2, r.shape[1]))
+    fx = np.zeros((2, 1, 2, 1, r.shape[1]))
+    for sp in range(2):
+        be.lda_exchange(r2[sp], e[sp], v[sp])
+        be.lda_exchange_fxc(r2[sp], f[sp])
+    fh = be.to_host(f)
+    fx[0, 0, 0, 0], fx[1, 0, 1, 0] = 2.0 * fh[0], 2.0 * fh[1]
+    return r, be.to_host(v)[:, None], fx
+
+
+def cache_xc_kernel(mydf, xc_code, mo_coeff, mo_occ, spin=0, kpts=None):
+    raise NotImplementedError          # as the reference (multigrid.py:1454-1455)
 
 
 def multigrid_fftdf(mf):

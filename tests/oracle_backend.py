@@ -123,6 +123,10 @@ class OracleBackend:
         exc.copy_(torch.from_numpy(e))
         vxc.copy_(torch.from_numpy(v))
 
+    def lda_exchange_fxc(self, rho, fxc):
+        from oracle import multigrid as omg
+        fxc.copy_(torch.from_numpy(omg.slater_exchange_fxc(rho.numpy())))
+
     def dot(self, x, y=None):
         return float(x.numpy().sum() if y is None else x.numpy().dot(y.numpy()))
 

@@ -225,6 +225,66 @@ def _check_kpts_against_oracle(df, cell, tol):
     assert abs(veff.ecoul - ec0) < 1e-7
 
 
+def _check_response(df, cell, tol):
+    """nr_rks_fxc / nr_rks_fxc_st / nr_uks_fxc / cache_xc_kernel1 against the oracle, and against what they are by definition:
+    the derivative of nr_rks's (nr_uks's) potential matrix along the response density (central difference)."""
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    dm0 = make_dm(cell)
+    rng = np.random.default_rng(9)
+    nao = cell.nao_nr()
+    dm1 = rng.standard_normal((2, nao, nao)) * 0.05                      # not symmetric: hermi = 0 input
+    tasks = as_tasks(df.tasks) if df.tasks is not None else as_tasks(df.build_tasks())
+    v = pmg.nr_rks_fxc(df, 'lda,', dm0, dm1, with_j=True)
+    assert v.shape == dm1.shape
+    assert abs(v - omg.nr_fxc_lda(tasks, cell._atm, dm0, dm1, a, mesh, 'rks', with_j=True)).max() < tol
+    eps = 1e-4
+    sym = 0.5 * (dm1[0] + dm1[0].T)
+    fd = (pmg.nr_rks(df, 'lda,', dm0 + eps * sym, with_j=True)[2] - pmg.nr_rks(df, 'lda,', dm0 - eps * sym, with_j=True)[2]) / (2 * eps)
+    assert abs(v[0] - fd).max() < 1e-6 * max(1.0, abs(v[0]).max())
+    rho, vxc, fxc = pmg.cache_xc_kernel1(df, 'lda,', dm0)
+    assert rho.shape == (int(np.prod(mesh)),) and vxc.shape == (1, rho.size) and fxc.shape == (1, 1, rho.size)
+    assert abs(pmg.nr_rks_fxc(df, 'lda,', dm0, dm1, with_j=True, rho0=rho, fxc=fxc) - v).max() < 1e-12
+    vs = pmg.nr_rks_fxc_st(df, 'lda,', dm0, dm1, singlet=True)
+    assert abs(vs - omg.nr_fxc_lda(tasks, cell._atm, dm0, dm1, a, mesh, 'st')).max() < tol
+    assert abs(vs - pmg.nr_rks_fxc_st(df, 'lda,', dm0, dm1, singlet=False)).max() < 1e-12
+    assert abs(vs - 2 * pmg.nr_rks_fxc(df, 'lda,', dm0, dm1)).max() < 1e-10
+    pair0 = np.stack([dm0 * .6, dm0 * .4])
+    pair1 = np.stack([dm1[0], dm1[1], dm1[1] * .5, dm1[0] * -.3])       # (alpha responses 1, 2, beta responses 1, 2)
+    vu = pmg.nr_uks_fxc(df, 'lda,', pair0, pair1, with_j=True)
+    assert vu.shape == pair1.shape
+    assert abs(vu - omg.nr_fxc_lda(tasks, cell._atm, pair0, pair1, a, mesh, 'uks', with_j=True)).max() < tol
+    d = np.stack([0.5 * (pair1[0] + pair1[0].T), 0.5 * (pair1[2] + pair1[2].T)])
+    fdu = (pmg.nr_uks(df, 'lda,', pair0 + eps * d, with_j=True)[2] - pmg.nr_uks(df, 'lda,', pair0 - eps * d, with_j=True)[2]) / (2 * eps)
+    assert abs(vu[[0, 2]] - fdu).max() < 1e-6 * max(1.0, abs(vu).max())
+    r2, v2, f2 = pmg.cache_xc_kernel1(df, 'lda,', pair0, spin=1)
+    assert r2.shape == (2, rho.size) and v2.shape == (2, 1, rho.size) and f2.shape == (2, 1, 2, 1, rho.size)
+    assert abs(f2[0, 0, 1, 0]).max() == 0 and abs(r2.sum(axis=0) - rho).max() < 1e-10
+
+
+def test_product_response_on_checker_backend():
+    from oracle_backend import OracleBackend
+    cell = cell_he_split()
+    df = pmg.MultiGridFFTDF(cell, backend=OracleBackend())
+    df.split = 'all'
+    _check_response(df, cell, 1e-10)
+    # k-points: Hermitian and non-Hermitian response matrices
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    kpts, dm0 = make_kpts_dms(cell)
+    _, dm1 = make_kpts_dms(cell, hermitian=False, seed=11)
+    tasks = as_tasks(df.tasks)
+    v = pmg.nr_rks_fxc(df, 'lda,', dm0, dm1[None], with_j=True, kpts=kpts)
+    assert v.shape == (1,) + dm1.shape
+    assert abs(v - omg.nr_fxc_lda(tasks, cell._atm, dm0, dm1[None], a, mesh, 'rks', with_j=True, kpts=kpts)).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_gpu_multigrid_response_functions():
+    cell = cell_he_split()
+    df = pmg.MultiGridFFTDF(cell)
+    df.split = 'all'
+    _check_response(df, cell, 1e-9)
+
+
 def test_product_kpts_on_checker_backend():
     """k-point J / LDA of pyscf_isdf_amd.multigrid on the CPU checker backend: stacked real / imaginary planes against the
     oracle's complex arithmetic on the same ladder, and the oracle's FFTDF J at the k-points."""
