@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument('--workload', default=os.environ.get('ISDF_BENCH_WORKLOAD', 'diamond-444-dzvp-120'))
     ap.add_argument('--select', default='refined', choices=['local', 'refined', 'global'])
     ap.add_argument('--refine-over', type=float, default=2.0)
+    ap.add_argument('--cand-ao-cutoff', type=float, default=None,
+                    help="Bohr: the candidate stage of the refined selection sees only the AOs of atoms this close to a block's atom (default: all)")
     ap.add_argument('--no-accuracy', action='store_true',
                     help="skip the exact-exchange comparison (config.dE_K_vs_exact; 48 s at configs[2], after the timed region)")
     ap.add_argument('--c-isdf', type=int, default=None,
@@ -215,6 +217,7 @@ def main():
         dm = np.array(dm)
         df = ISDF(cell, kpts=kpts, c_isdf=args.c_isdf, select=args.select, comm=comm)
     df.refine_over = args.refine_over
+    df.cand_ao_cutoff = args.cand_ao_cutoff
     if args.fit_route:
         df.fit_route = args.fit_route
     if args.robust_k:
@@ -338,6 +341,7 @@ def main():
         }
         out['cold_first_step_s'] = None if cold_first_step is None else round(cold_first_step, 3)
         out['config']['refine_over'] = args.refine_over if args.select == 'refined' else None
+        out['config']['cand_ao_cutoff'] = args.cand_ao_cutoff if args.select == 'refined' else None
         out['config']['fit_row_panels'] = int(getattr(df, 'n_panels', 1))
         # accuracy of the timed configuration against the reference's exact exchange (fft_jk.py:177-302 on the GPU,
         # isdf_get_k_exact; outside the timed region).  J is the reference's own formula (fft_jk.py:33-109): no fit error.
