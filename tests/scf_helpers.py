@@ -78,3 +78,52 @@ def rhf(hcore, S, get_jk, nocc, e_nuc, max_cycle=50, conv=1e-10):
         e, c = scipy.linalg.eigh(f, S)
         dm = 2 * c[:, :nocc].dot(c[:, :nocc].conj().T)
     return e_tot, dm
+
+
+def overlap_kinetic_from_ft(cell, gmax_factor=1.0):
+    """Gamma-point S and T of any shells (s, p, d) by Poisson summation over the ANALYTIC AO Fourier transforms
+    (oracle.pp.ft_ao: no grid, no aliasing): S = 1/vol sum_G conj(ft_mu(G)) ft_nu(G), T = 1/(2 vol) sum_G |G|^2 (...), the G sum
+    carried to where the sharpest primitive's exp(-G^2/4a) is below 1e-16.  The reference takes both from libcint lattice
+    sums (pyscf/pbc/scf/hf.py:76-95)."""
+    from oracle import pp as opp
+    a = cell.lattice_vectors()
+    b = 2 * np.pi * np.linalg.inv(a.T)
+    amax = max(cell.bas_exp(i).max() for i in range(cell.nbas))
+    gmax = np.sqrt(4 * amax * 37.0) * gmax_factor                       # e^-37 = 1e-16
+    n = np.ceil(gmax * np.linalg.norm(a, axis=1) / (2 * np.pi)).astype(int) + 1
+    Gv = gto.cartesian_prod([np.arange(-k, k + 1) for k in n]).dot(b)
+    F = opp.ft_ao(cell._atm, cell._bas, cell._env, Gv)
+    g2 = np.einsum('gx,gx->g', Gv, Gv)
+    S = (F.conj().T.dot(F)).real / cell.vol
+    T = 0.5 * (F.conj().T.dot(g2[:, None] * F)).real / cell.vol
+    return S, T
+
+
+def rks(hcore, S, veff_fn, nocc, e_nuc, max_cycle=60, conv=1e-10):
+    """Closed-shell Kohn-Sham iterations with Pulay DIIS.  veff_fn(dm) -> (veff incl. J, e_coul, e_xc).  Returns (e_tot, dm)."""
+    e, c = scipy.linalg.eigh(hcore, S)
+    dm = 2 * c[:, :nocc].dot(c[:, :nocc].T)
+    focks, errs, e_last = [], [], 0.0
+    for it in range(max_cycle):
+        veff, ecoul, exc = veff_fn(dm)
+        f = hcore + veff
+        e_tot = np.einsum('ij,ji', hcore, dm) + ecoul + exc + e_nuc
+        err = f.dot(dm).dot(S) - S.dot(dm).dot(f)
+        if abs(e_tot - e_last) < conv and abs(err).max() < 1e-7:
+            break
+        e_last = e_tot
+        focks, errs = (focks + [f])[-8:], (errs + [err])[-8:]
+        n = len(focks)
+        if n > 1:
+            B = -np.ones((n + 1, n + 1))
+            B[n, n] = 0
+            for i in range(n):
+                for j in range(n):
+                    B[i, j] = np.vdot(errs[i], errs[j])
+            rhs = np.zeros(n + 1)
+            rhs[n] = -1
+            coef = np.linalg.lstsq(B, rhs, rcond=None)[0][:n]
+            f = sum(ci * fi for ci, fi in zip(coef, focks))
+        e, c = scipy.linalg.eigh(f, S)
+        dm = 2 * c[:, :nocc].dot(c[:, :nocc].T)
+    return e_tot, dm
