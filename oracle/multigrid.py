@@ -19,9 +19,11 @@ then agree with the FFTDF J to the cell precision, which is the reference's own 
 The lattice-sum inputs of a task's collocation cell (Ls, rcut per shell) come from the caller through ``lattice_fn``: they
 are estimates the tests take from the same helpers as every other oracle AO evaluation.
 
-Parity: pinned through identities only - the reference's tests compare its multigrid J / veff with its own FFTDF J / numint
-veff at run time (no stored constants for 'lda,'); tests do the same against oracle/fftdf.py, which is pinned to the
-reference's constants (tests/test_oracle_pins.py).  The Slater exchange is the closed formula, libxc is absent: densities
+Parity: the reference's multigrid tests compare its J / veff with its own FFTDF J / numint veff at run time (no stored constants
+for 'lda,'); tests do the same against oracle/fftdf.py, which is pinned to the reference's constants (tests/test_oracle_pins.py).
+The LDA path as a whole is pinned by a reference constant one level up: the RKS 'lda,' total energy of
+pyscf/pbc/scf/test/test_newton.py:84-90 (-9.7670882971475663) is reproduced to 5e-9 Eh by an SCF whose J + XC come from the
+product's ladder (tests/test_gpu_scf.py, profiles/r02_scf_pins_diamond_prim.log).  The Slater exchange is the closed formula, libxc is absent: densities
 at or below 1e-24 give zero here and in the product; what libxc does below its own threshold is not pinned.
 """
 import numpy as np
