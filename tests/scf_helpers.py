@@ -127,3 +127,59 @@ def rks(hcore, S, veff_fn, nocc, e_nuc, max_cycle=60, conv=1e-10):
         e, c = scipy.linalg.eigh(f, S)
         dm = 2 * c[:, :nocc].dot(c[:, :nocc].T)
     return e_tot, dm
+
+
+def overlap_kinetic_from_ft_kpts(cell, kpts):
+    """k-point S^k, T^k from the analytic AO transforms at k + G (Bloch sums by Poisson summation): (nk, nao, nao) complex."""
+    from oracle import pp as opp
+    a = cell.lattice_vectors()
+    b = 2 * np.pi * np.linalg.inv(a.T)
+    amax = max(cell.bas_exp(i).max() for i in range(cell.nbas))
+    gmax = np.sqrt(4 * amax * 37.0) + np.linalg.norm(kpts, axis=1).max()
+    n = np.ceil(gmax * np.linalg.norm(a, axis=1) / (2 * np.pi)).astype(int) + 1
+    Gv = gto.cartesian_prod([np.arange(-k, k + 1) for k in n]).dot(b)
+    S, T = [], []
+    for k in np.reshape(kpts, (-1, 3)):
+        q = Gv + k
+        F = opp.ft_ao(cell._atm, cell._bas, cell._env, q)
+        q2 = np.einsum('gx,gx->g', q, q)
+        S.append(F.conj().T.dot(F) / cell.vol)
+        T.append(0.5 * F.conj().T.dot(q2[:, None] * F) / cell.vol)
+    return np.array(S), np.array(T)
+
+
+def krks(hcore, S, veff_fn, nocc, e_nuc, max_cycle=60, conv=1e-10):
+    """Closed-shell k-point Kohn-Sham iterations (insulator, nocc bands per k), DIIS over the stacked k blocks.
+    veff_fn(dms (nk, nao, nao)) -> (veff (nk, nao, nao), e_coul, e_xc)."""
+    nk = len(hcore)
+
+    def density(focks):
+        out = []
+        for k in range(nk):
+            e, c = scipy.linalg.eigh(focks[k], S[k])
+            out.append(2 * c[:, :nocc].dot(c[:, :nocc].conj().T))
+        return np.array(out)
+    dms = density(hcore)
+    focks, errs, e_last = [], [], 0.0
+    for it in range(max_cycle):
+        veff, ecoul, exc = veff_fn(dms)
+        f = hcore + veff
+        e_tot = np.einsum('kij,kji', hcore, dms).real / nk + ecoul + exc + e_nuc
+        err = np.array([f[k].dot(dms[k]).dot(S[k]) - S[k].dot(dms[k]).dot(f[k]) for k in range(nk)])
+        if abs(e_tot - e_last) < conv and abs(err).max() < 1e-7:
+            break
+        e_last = e_tot
+        focks, errs = (focks + [f])[-8:], (errs + [err])[-8:]
+        n = len(focks)
+        if n > 1:
+            B = -np.ones((n + 1, n + 1), dtype=complex)
+            B[n, n] = 0
+            for i in range(n):
+                for j in range(n):
+                    B[i, j] = np.vdot(errs[i], errs[j])
+            rhs = np.zeros(n + 1, dtype=complex)
+            rhs[n] = -1
+            coef = np.linalg.lstsq(B, rhs, rcond=None)[0][:n]
+            f = sum(ci * fi for ci, fi in zip(coef, focks))
+        dms = density(f)
+    return e_tot, dms

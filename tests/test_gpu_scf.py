@@ -86,3 +86,49 @@ def test_diamond_rhf_and_lda_rks_total_energies_match_reference():
     assert abs(e_lda - (-9.7670882971475663)) < 5e-8            # measured: 5.1e-9 (profiles/r02_scf_pins_diamond_prim.log)
     e_hf, dm = scf_helpers.rhf(hcore, S, lambda d: df.get_jk(d, exxdiv='ewald'), 4, e_nuc)
     assert abs(e_hf - (-10.137043711032916)) < 5e-8             # measured: 6.0e-9
+
+
+def test_diamond_krks_lda_total_energy_matches_reference():
+    """KRKS 'lda,' on the same cell with a [2,1,1] k-mesh (pyscf/pbc/scf/test/test_newton.py:135-142): e_tot =
+    -10.307756038726733 (places=8).  J + v_xc from the k-point form of the multigrid ladder (periodic parts on stacked planes),
+    get_pp at the k-points from the device."""
+    from pyscf_isdf_amd import multigrid as pmg
+    cell = _diamond_newton_cell()
+    kpts = cell.make_kpts([2, 1, 1])
+    S, T = scf_helpers.overlap_kinetic_from_ft_kpts(cell, kpts)
+    df = pmg.MultiGridFFTDF(cell, kpts=kpts)
+    df.split = 'all'
+    hcore = T + np.asarray(df.get_pp(kpts))
+    assert abs(hcore - hcore.conj().transpose(0, 2, 1)).max() < 1e-9
+    e_nuc = scf_helpers.ewald_energy(cell)
+
+    def veff_lda(dms):
+        n, exc, veff = pmg.nr_rks(df, 'lda,', dms, kpts=kpts, with_j=True)
+        assert abs(n - 8.0) < 1e-6
+        return np.asarray(veff), float(veff.ecoul), float(exc)
+    e_lda, dms = scf_helpers.krks(hcore, S, veff_lda, 4, e_nuc)
+    assert abs(e_lda - (-10.307756038726733)) < 5e-8
+    assert not df._built                                  # no ISDF fit was needed
+
+
+def test_diamond_krhf_total_energy_matches_reference():
+    """KRHF on the same cell and [2,1,1] k-mesh (pyscf/pbc/scf/test/test_newton.py:102-108, exxdiv='ewald'):
+    e_tot = -10.5309059210831 (places=8) with the k-point ISDF exchange at (numerically) full rank of the pair space."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = _diamond_newton_cell()
+    kpts = cell.make_kpts([2, 1, 1])
+    S, T = scf_helpers.overlap_kinetic_from_ft_kpts(cell, kpts)
+    df = ISDF(cell, kpts=kpts, c_isdf=40, select='global')
+    df.k_ip_factor = 1
+    df.select_tol = 0.0
+    df.reg_rel = 0.0
+    hcore = T + np.asarray(df.get_pp(kpts))
+    e_nuc = scf_helpers.ewald_energy(cell)
+
+    def veff_hf(dms):
+        vj, vk = df.get_jk(dms, kpts=kpts, exxdiv='ewald')
+        v = vj - .5 * vk
+        e2 = .5 * np.einsum('kij,kji', v, dms).real / len(kpts)
+        return v, e2, 0.0
+    e_hf, dms = scf_helpers.krks(hcore, S, veff_hf, 4, e_nuc)
+    assert abs(e_hf - (-10.5309059210831)) < 5e-8               # measured: 2.9e-9 at P = 225 (the selection stops at the pair space's rank)
