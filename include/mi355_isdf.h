@@ -99,6 +99,13 @@ int isdf_eval_ao(isdf_handle h,
                  const double* d_coords, int64_t ngrids,
                  double* d_ao, int64_t ld);
 
+/* Values and Cartesian first derivatives of the Gamma-point AOs (numint.eval_ao(deriv=1), pyscf/pbc/dft/numint.py:33-93;
+ * pyscf/lib/gto/deriv1.c:60-69,166-330): four planes (value, d/dx, d/dy, d/dz) at d_ao + comp * plane_stride, each laid out
+ * like isdf_eval_ao's output; same arguments and truncation rule otherwise.  For GGA densities and potentials. */
+int isdf_eval_ao_deriv1(isdf_handle h, const int32_t* atm, int natm, const int32_t* bas, int nbas, const double* env,
+                        int nenv, const double* Ls, int nimgs, const double* rcut, const double* d_coords,
+                        int64_t ngrids, double* d_ao, int64_t ld, int64_t plane_stride);
+
 /* k-point collocation: real and imaginary planes (nao rows each, leading dimension ld) of
  *   periodic_part = 0:  phi^k_m(r) = sum_T exp(i k.T) phi_m(r - T)       (eval_gto.py:137, grid_ao.c:421-422)
  *   periodic_part = 1:  u^k_m(r) = exp(-i k.r) phi^k_m(r)                 (lattice periodic)

@@ -119,3 +119,65 @@ def eval_ao(atm, bas, env, coords, Ls, rcut, kpts=None, rule='point'):
     if gamma_only or np.shape(kpts) == (3,):
         return res[0]
     return res
+
+
+def _angular_grad(l, dx, dy, dz):
+    """Gradients of the real-spherical angular polynomials of _angular: list over m of (d/dx, d/dy, d/dz) arrays."""
+    z = np.zeros_like(dx)
+    o = np.ones_like(dx)
+    if l == 0:
+        return [(z, z, z)]
+    if l == 1:
+        return [(o, z, z), (z, o, z), (z, z, o)]
+    if l == 2:
+        return [(D_XY * dy, D_XY * dx, z), (z, D_XY * dz, D_XY * dy),
+                (-2 * D_Z2_XXYY * dx, -2 * D_Z2_XXYY * dy, 2 * D_Z2_ZZ * dz),
+                (D_XY * dz, z, D_XY * dx), (2 * D_X2Y2 * dx, -2 * D_X2Y2 * dy, z)]
+    raise NotImplementedError('l > 2')
+
+
+def eval_ao_deriv1(atm, bas, env, coords, Ls, rcut):
+    """AO values and Cartesian first derivatives at the Gamma point: (4, G, nao) = (value, d/dx, d/dy, d/dz), the layout of
+    numint.eval_ao(deriv=1) (pyscf/pbc/dft/numint.py:33-93).  Per-point truncation rule (see eval_ao); the derivative of
+    fac * ang(d) * sum_p c_p exp(-a_p r^2) is  grad(ang) * R + ang * (-2 d) * sum_p c_p a_p exp(-a_p r^2)
+    (pyscf/lib/gto/deriv1.c:60-69 for the radial part, :166-330 for the Cartesian factors)."""
+    atm = np.asarray(atm).reshape(-1, ATM_SLOTS)
+    bas = np.asarray(bas).reshape(-1, BAS_SLOTS)
+    coords = np.asarray(coords, dtype=float)
+    G = coords.shape[0]
+    loc = ao_loc(bas)
+    out = np.zeros((4, loc[-1], G))
+    rcut = np.asarray(rcut, dtype=float)
+    for ia in range(len(atm)):
+        shl = np.where(bas[:, ATOM_OF] == ia)[0]
+        if len(shl) == 0:
+            continue
+        ri = env[atm[ia, PTR_COORD]:atm[ia, PTR_COORD] + 3]
+        rc_max = rcut[shl].max()
+        for L in Ls:
+            d = coords - (ri + L)
+            rr = np.einsum('gx,gx->g', d, d)
+            if not (rr < rc_max * rc_max).any():
+                continue
+            for ib in shl:
+                l, npr, nc = bas[ib, ANG_OF], bas[ib, NPRIM_OF], bas[ib, NCTR_OF]
+                idx = np.nonzero(rr < rcut[ib] * rcut[ib])[0]
+                if idx.size == 0:
+                    continue
+                es = env[bas[ib, PTR_EXP]:bas[ib, PTR_EXP] + npr]
+                cs = env[bas[ib, PTR_COEFF]:bas[ib, PTR_COEFF] + npr * nc].reshape(nc, npr)
+                fac = FAC_S if l == 0 else (FAC_P if l == 1 else 1.0)
+                e = np.exp(-np.outer(es, rr[idx])) * fac
+                rad = cs.dot(e)
+                rad1 = (cs * es).dot(e)
+                dd = [d[idx, 0], d[idx, 1], d[idx, 2]]
+                ang = _angular(l, *dd)
+                gang = _angular_grad(l, *dd)
+                deg = 2 * l + 1
+                for k in range(nc):
+                    for mm in range(deg):
+                        row = loc[ib] + k * deg + mm
+                        out[0, row, idx] += rad[k] * ang[mm]
+                        for x in range(3):
+                            out[1 + x, row, idx] += gang[mm][x] * rad[k] - 2.0 * dd[x] * ang[mm] * rad1[k]
+    return np.ascontiguousarray(out.transpose(0, 2, 1))

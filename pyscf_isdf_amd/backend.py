@@ -146,6 +146,19 @@ class HipBackend:
         self.handle.call('isdf_eval_ao', _np_ptr(atm), len(atm), _np_ptr(bas), len(bas), _np_ptr(env), len(env),
                          _np_ptr(Ls), len(Ls), _np_ptr(rcut), self._p(coords_soa), G, self._p(ao), ao.stride(0))
 
+    def eval_ao_deriv1(self, atm, bas, env, Ls, rcut, coords_soa, ao4):
+        """ao4 (4, nao, ld) <- values and x, y, z derivatives on coords_soa (3, G)."""
+        self._stream()
+        atm = np.ascontiguousarray(atm, dtype=np.int32)
+        bas = np.ascontiguousarray(bas, dtype=np.int32)
+        env = np.ascontiguousarray(env, dtype=np.float64)
+        Ls = np.ascontiguousarray(Ls, dtype=np.float64)
+        rcut = np.ascontiguousarray(rcut, dtype=np.float64)
+        G = coords_soa.shape[1]
+        assert coords_soa.is_contiguous() and ao4.dim() == 3 and ao4.shape[0] == 4 and ao4.stride(2) == 1 and ao4.shape[2] >= G
+        self.handle.call('isdf_eval_ao_deriv1', _np_ptr(atm), len(atm), _np_ptr(bas), len(bas), _np_ptr(env), len(env),
+                         _np_ptr(Ls), len(Ls), _np_ptr(rcut), self._p(coords_soa), G, self._p(ao4), ao4.stride(1), ao4.stride(0))
+
     def gather_cols(self, src, idx, dst):
         self._stream()
         assert idx.dtype == torch.int64 and src.stride(1) == 1 and dst.stride(1) == 1

@@ -305,6 +305,154 @@ __global__ __launch_bounds__(TPB) void eval_ao_k_kernel(
   }
 }
 
+// Values and Cartesian first derivatives (GGA densities and potentials; numint.eval_ao(deriv=1), pyscf/lib/gto/deriv1.c:60-69 for
+// the radial part): phi = fac ang(d) R(r^2), R = sum_p c_p exp(-a_p r^2)  ->  grad phi = grad(ang) R - 2 d ang R1,
+// R1 = sum_p c_p a_p exp(-a_p r^2).  Four output planes (value, d/dx, d/dy, d/dz), each AO-major like eval_ao_kernel's.
+template <int L>
+__device__ inline void shell_eval_d1(const ShellDev sh, const double* __restrict__ env, const double* __restrict__ Ls,
+                                     const int* __restrict__ img_list, int nlist, double px, double py, double pz, double ax,
+                                     double ay, double az, bool valid, double* __restrict__ ao, int64_t ld, int64_t plane,
+                                     int64_t g) {
+  constexpr int DEG = 2 * L + 1;
+  double acc[4][NCMAX][DEG];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c)
+#pragma unroll
+      for (int m = 0; m < DEG; ++m) acc[x][c][m] = 0.0;
+  const double fac = (L == 0) ? FAC_S : (L == 1 ? FAC_P : 1.0);
+  const double* __restrict__ es = env + sh.pexp;
+  const double* __restrict__ cs = env + sh.pcoef;
+  for (int i = 0; i < nlist; ++i) {
+    const int iL = img_list[i];
+    const double d[3] = {px - (ax + Ls[3 * iL + 0]), py - (ay + Ls[3 * iL + 1]), pz - (az + Ls[3 * iL + 2])};
+    const double rr = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    if (rr < sh.rcut2) {
+      double rad[NCMAX], rad1[NCMAX];
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c) { rad[c] = 0.0; rad1[c] = 0.0; }
+      for (int p = 0; p < sh.nprim; ++p) {
+        const double e = exp(-es[p] * rr) * fac;
+#pragma unroll
+        for (int c = 0; c < NCMAX; ++c)
+          if (c < sh.nctr) {
+            rad[c] += cs[c * sh.nprim + p] * e;
+            rad1[c] += cs[c * sh.nprim + p] * es[p] * e;
+          }
+      }
+      double ang[DEG], gang[DEG][3];
+      if (L == 0) {
+        ang[0] = 1.0;
+        gang[0][0] = gang[0][1] = gang[0][2] = 0.0;
+      } else if (L == 1) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          ang[m] = d[m];
+#pragma unroll
+          for (int x = 0; x < 3; ++x) gang[m][x] = (m == x) ? 1.0 : 0.0;
+        }
+      } else {
+        const double dx = d[0], dy = d[1], dz = d[2];
+        ang[0] = D_XY * dx * dy;  gang[0][0] = D_XY * dy;  gang[0][1] = D_XY * dx;  gang[0][2] = 0.0;
+        ang[1] = D_XY * dy * dz;  gang[1][0] = 0.0;        gang[1][1] = D_XY * dz;  gang[1][2] = D_XY * dy;
+        ang[2] = D_Z2_ZZ * dz * dz - D_Z2_XXYY * (dx * dx + dy * dy);
+        gang[2][0] = -2.0 * D_Z2_XXYY * dx;  gang[2][1] = -2.0 * D_Z2_XXYY * dy;  gang[2][2] = 2.0 * D_Z2_ZZ * dz;
+        ang[3] = D_XY * dx * dz;  gang[3][0] = D_XY * dz;  gang[3][1] = 0.0;        gang[3][2] = D_XY * dx;
+        ang[4] = D_X2Y2 * (dx * dx - dy * dy);
+        gang[4][0] = 2.0 * D_X2Y2 * dx;  gang[4][1] = -2.0 * D_X2Y2 * dy;  gang[4][2] = 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c)
+#pragma unroll
+        for (int m = 0; m < DEG; ++m) {
+          acc[0][c][m] += rad[c] * ang[m];
+#pragma unroll
+          for (int x = 0; x < 3; ++x) acc[1 + x][c][m] += gang[m][x] * rad[c] - 2.0 * d[x] * ang[m] * rad1[c];
+        }
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c)
+        if (c < sh.nctr) {
+#pragma unroll
+          for (int m = 0; m < DEG; ++m) ao[x * plane + (int64_t)(sh.ao0 + c * DEG + m) * ld + g] = acc[x][c][m];
+        }
+  }
+}
+
+// the workgroup's image list (see eval_ao_kernel): ordered compaction of the translations whose atom image can reach the
+// bounding box of the workgroup's points; returns the list length
+__device__ inline int cull_images(const AtomDev at, const double* __restrict__ Ls, int nimgs, double px, double py, double pz,
+                                  int* __restrict__ img_list, double (*red)[TPB / 64], int* __restrict__ wcnt) {
+  const int tid = threadIdx.x;
+  double lo[3] = {wave_min(px), wave_min(py), wave_min(pz)};
+  double hi[3] = {wave_max(px), wave_max(py), wave_max(pz)};
+  const int w = tid >> 6;
+  if ((tid & 63) == 0) {
+    for (int k = 0; k < 3; ++k) { red[k][w] = lo[k]; red[3 + k][w] = hi[k]; }
+  }
+  __syncthreads();
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = red[k][0]; hi[k] = red[3 + k][0];
+    for (int ww = 1; ww < TPB / 64; ++ww) {
+      lo[k] = fmin(lo[k], red[k][ww]);
+      hi[k] = fmax(hi[k], red[3 + k][ww]);
+    }
+  }
+  const double rc2 = at.rcut_max * at.rcut_max;
+  const int lane = tid & 63;
+  int nlist = 0;
+  for (int base = 0; base < nimgs; base += TPB) {
+    const int i = base + tid;
+    bool keep = false;
+    if (i < nimgs) {
+      const double c[3] = {at.x + Ls[3 * i], at.y + Ls[3 * i + 1], at.z + Ls[3 * i + 2]};
+      double d2 = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        const double dd = fmax(fmax(lo[k] - c[k], c[k] - hi[k]), 0.0);
+        d2 += dd * dd;
+      }
+      keep = d2 < rc2;
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) wcnt[w] = __popcll(mask);
+    __syncthreads();
+    int off = nlist;
+    for (int ww = 0; ww < w; ++ww) off += wcnt[ww];
+    if (keep) img_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    for (int ww = 0; ww < TPB / 64; ++ww) nlist += wcnt[ww];
+    __syncthreads();
+  }
+  return nlist;
+}
+
+__global__ __launch_bounds__(TPB) void eval_ao_deriv1_kernel(
+    const AtomDev* __restrict__ atoms, const ShellDev* __restrict__ shells, const double* __restrict__ env,
+    const double* __restrict__ Ls, int nimgs, const double* __restrict__ coords, int64_t ngrids, double* __restrict__ ao,
+    int64_t ld, int64_t plane) {
+  extern __shared__ int img_list[];
+  __shared__ double red[6][TPB / 64];
+  __shared__ int wcnt[TPB / 64];
+  const int64_t g = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  const bool valid = g < ngrids;
+  const int64_t gc = valid ? g : (int64_t)blockIdx.x * TPB;
+  const double px = coords[gc], py = coords[ngrids + gc], pz = coords[2 * ngrids + gc];
+  const AtomDev at = atoms[blockIdx.y];
+  const int nlist = cull_images(at, Ls, nimgs, px, py, pz, img_list, red, wcnt);
+  for (int s = at.sh0; s < at.sh1; ++s) {
+    const ShellDev sh = shells[s];
+    switch (sh.l) {
+      case 0: shell_eval_d1<0>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, plane, g); break;
+      case 1: shell_eval_d1<1>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, plane, g); break;
+      default: shell_eval_d1<2>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, plane, g); break;
+    }
+  }
+}
+
 __global__ void gather_cols_kernel(const double* __restrict__ src, int64_t ld_src,
                                    const int64_t* __restrict__ idx, int64_t n,
                                    double* __restrict__ dst, int64_t ld_dst) {
@@ -392,6 +540,23 @@ extern "C" int isdf_eval_ao(isdf_handle h, const int32_t* atm, int natm, const i
   ProfScope ps(h, "eval_ao_kernel[byte]", 8.0 * (double)ngrids * t.nao);
   hipLaunchKernelGGL(eval_ao_kernel, grid, dim3(TPB), (size_t)nimgs * sizeof(int), h->stream,
                      t.d_atoms, t.d_shells, t.d_env, t.d_Ls, nimgs, d_coords, ngrids, d_ao, ld);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_eval_ao_deriv1(isdf_handle h, const int32_t* atm, int natm, const int32_t* bas, int nbas, const double* env,
+                                   int nenv, const double* Ls, int nimgs, const double* rcut, const double* d_coords,
+                                   int64_t ngrids, double* d_ao, int64_t ld, int64_t plane_stride) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_coords && d_ao && ngrids > 0 && ld >= ngrids);
+  AoTables t;
+  int rc = upload_ao_tables(h, atm, natm, bas, nbas, env, nenv, Ls, nimgs, rcut, nullptr, &t);
+  if (rc) return rc;
+  ARG_CHECK(h, plane_stride >= (int64_t)t.nao * ld);
+  dim3 grid((unsigned)cdiv(ngrids, TPB), (unsigned)natm);
+  ProfScope ps(h, "eval_ao_deriv1_kernel[byte]", 32.0 * (double)ngrids * t.nao);
+  hipLaunchKernelGGL(eval_ao_deriv1_kernel, grid, dim3(TPB), (size_t)nimgs * sizeof(int), h->stream, t.d_atoms, t.d_shells,
+                     t.d_env, t.d_Ls, nimgs, d_coords, ngrids, d_ao, ld, plane_stride);
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

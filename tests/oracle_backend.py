@@ -130,6 +130,10 @@ class OracleBackend:
     def dot(self, x, y=None):
         return float(x.numpy().sum() if y is None else x.numpy().dot(y.numpy()))
 
+    def eval_ao_deriv1(self, atm, bas, env, Ls, rcut, coords_soa, ao4):
+        v = oao.eval_ao_deriv1(atm, bas, env, coords_soa.numpy().T, Ls, rcut)           # (4, G, nao)
+        ao4[:, :, :v.shape[1]] = torch.from_numpy(np.ascontiguousarray(v.transpose(0, 2, 1)))
+
     def gather_cols(self, src, idx, dst):
         dst[:, :idx.numel()] = src[:, idx]
 

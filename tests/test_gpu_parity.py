@@ -62,6 +62,30 @@ def test_gather_cols(be):
     assert np.array_equal(be.to_host(dst), src[:, idx])
 
 
+@pytest.mark.parametrize('mk', [cells.cell_he_c, cells.cell_he2_triclinic, cells.cell_c2_ccpvdz])
+def test_eval_ao_deriv1(be, mk):
+    """isdf_eval_ao_deriv1 (values + Cartesian gradients, s / p / d shells) against the oracle (1e-12 of the largest entry) and,
+    on the reference's own cell, against its constant fp(ao, deriv=1) = 8.8004405892746433 (test_numint.py:98-100)."""
+    import torch
+    cell = mk()
+    coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    ref = oao.eval_ao_deriv1(cell._atm, cell._bas, cell._env, coords, Ls, rcut)          # (4, G, nao)
+    G, nao = len(coords), cell.nao_nr()
+    ao4 = be.to_device(np.full((4, nao, G + 3), 5.0))
+    be.eval_ao_deriv1(cell._atm, cell._bas, cell._env, Ls, rcut, be.to_device(np.ascontiguousarray(coords.T)), ao4)
+    got = be.to_host(ao4)
+    assert (got[:, :, G:] == 5.0).all()
+    got = got[:, :, :G].transpose(0, 2, 1)
+    assert abs(got - ref).max() < 1e-12 * max(1.0, abs(ref).max())
+    ao0 = _gpu_ao(be, cell, coords, Ls, rcut)
+    assert abs(be.to_host(ao0).T - got[0]).max() < 1e-14
+    if mk is cells.cell_c2_ccpvdz:
+        from oracle import pbc_tools as otools
+        assert abs(otools.fp(got) - 8.8004405892746433) < 1e-8
+
+
 def test_partition_by_atom_matches_oracle(be):
     """isdf_partition_by_atom (device Voronoi partition, minimum image, ties to the lowest atom index) == the oracle's brute
     force on an fcc cell full of exact ties, on a triclinic cell, and on a supercell (bit-exact integer output)."""

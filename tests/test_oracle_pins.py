@@ -27,6 +27,17 @@ def test_eval_ao_dshell_pin():
     assert abs(tools.fp(ao) - (-0.54069672246407219)) < 1e-8
 
 
+def test_eval_ao_deriv1_pin():
+    # pyscf/pbc/dft/test/test_numint.py:98-100  fp(ao, deriv=1) = 8.8004405892746433 (places=8), layout (4, G, nao)
+    cell = cells.cell_c2_ccpvdz()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    ao1 = oao.eval_ao_deriv1(cell._atm, cell._bas, cell._env, cell.get_uniform_grids(), Ls, rcut)
+    assert ao1.shape == (4, 21 ** 3, 28)
+    assert abs(tools.fp(ao1) - 8.8004405892746433) < 1e-8
+    assert abs(ao1[0] - _aoR(cell, 'point')[0]).max() == 0
+
+
 def test_truncation_rules_agree_within_precision():
     cell = cells.cell_he_c()
     a56, _ = _aoR(cell, 'blk56')
