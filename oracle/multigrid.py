@@ -449,3 +449,141 @@ def nr_fxc_lda(tasks, atm, dm0, dms, a, fft_mesh, kind='rks', with_j=False, kpts
     if kpts is None:
         return integrate(tasks, atm, wv, a, fft_mesh, nao).reshape(dms.shape)
     return integrate_kpts(tasks, atm, wv, a, fft_mesh, nao, kpts).reshape(dms.shape)
+
+
+# ---- GGA: Becke-88 exchange ('b88,'), Gamma point ------------------------------------------------------------------------
+def b88_energy_density(rho, g):
+    """e(rho, |grad rho|) of Becke's 1988 exchange for a spin-unpolarised density (Becke, PRA 38, 3098 eq. 8; libxc GGA_X_B88:
+    beta = 0.0042, with the LDA exchange included): e = sum_s [-C_x rho_s^(4/3) - beta rho_s^(4/3) x_s^2 / (1 + 6 beta x_s asinh x_s)],
+    x_s = |grad rho_s| / rho_s^(4/3), rho_s = rho / 2."""
+    beta = 0.0042
+    cx = 1.5 * (3.0 / (4.0 * np.pi)) ** (1.0 / 3.0)
+    rs = 0.5 * np.asarray(rho, dtype=float)
+    gs = 0.5 * np.asarray(g, dtype=float)
+    r43 = rs ** (4.0 / 3.0)
+    x = gs / r43
+    return 2.0 * r43 * (-cx - beta * x * x / (1.0 + 6.0 * beta * x * np.arcsinh(x)))
+
+
+def b88_exchange(rho, grad):
+    """(exc per particle, vrho, w = de/d(grad rho)) with rho (G,), grad (3, G); derivatives in closed form (checked against
+    finite differences of b88_energy_density in tests/test_multigrid.py); rho <= 1e-14 -> 0."""
+    rho = np.asarray(rho, dtype=float)
+    grad = np.asarray(grad, dtype=float)
+    beta = 0.0042
+    cx = 1.5 * (3.0 / (4.0 * np.pi)) ** (1.0 / 3.0)
+    m = rho > 1e-14
+    rs = np.where(m, 0.5 * rho, 1.0)
+    gs = 0.5 * np.sqrt((grad ** 2).sum(axis=0))
+    r13 = np.cbrt(rs)
+    r43 = rs * r13
+    x = gs / r43
+    a = np.arcsinh(x)
+    D = 1.0 + 6.0 * beta * x * a
+    Dp = 6.0 * beta * (a + x / np.sqrt(1.0 + x * x))
+    G = -cx - beta * x * x / D
+    Gp_x = -beta * (2.0 * D - x * Dp) / (D * D)
+    exc = np.where(m, 2.0 * r43 * G / np.where(m, rho, 1.0), 0.0)
+    vrho = np.where(m, (4.0 / 3.0) * r13 * (G - x * x * Gp_x), 0.0)
+    w = np.where(m, Gp_x / (2.0 * r43), 0.0)[None] * grad          # de/d|grad rho| = G'(x); x = |grad rho| / (2 rho_s^(4/3))
+    return exc, vrho, w
+
+
+def _rho4_dense(ao4, dm):
+    """(4, G): density and its gradient from AO values and derivatives ao4 (4, G, nao) (numint.eval_rho, GGA, hermi = 1)."""
+    dm = 0.5 * (dm + dm.T)
+    c0 = ao4[0].dot(dm)
+    rho = np.empty((4, ao4.shape[1]))
+    rho[0] = np.einsum('gi,gi->g', c0, ao4[0])
+    for x in range(1, 4):
+        rho[x] = 2.0 * np.einsum('gi,gi->g', c0, ao4[x])
+    return rho
+
+
+def nr_rks_b88_dense(ao4, dm, a, fft_mesh):
+    """(nelec, exc, vxc matrix) by quadrature on the dense uniform grid - what pyscf.pbc.dft.numint.nr_rks does for a GGA
+    (numint.py:nr_rks via pyscf/dft/numint.py: wv[0] *= .5, V = ao0^T (sum_c wv_c ao_c), V + V^T): the reference's answer for
+    'b88,' on a cell (test_newton.py:92-98 runs its SCF on exactly this)."""
+    ngrids = ao4.shape[1]
+    weight = abs(np.linalg.det(a)) / ngrids
+    rho = _rho4_dense(ao4, dm)
+    exc, vrho, w = b88_exchange(rho[0], rho[1:])
+    wv = weight * np.vstack([0.5 * vrho[None], w])
+    aow = sum(wv[c][:, None] * ao4[c] for c in range(4))
+    v = ao4[0].T.dot(aow)
+    return rho[0].sum() * weight, (rho[0] * exc).sum() * weight, v + v.T
+
+
+def _task_ao4(task, atm, a):
+    coords = uniform_grids(np.asarray(a, dtype=float), task['mesh'])
+    return oao.eval_ao_deriv1(atm, task['bas'], task['env'], coords, task['Ls'], task['rcut'])          # (4, G_t, nT)
+
+
+def eval_rhoG_gga(tasks, atm, dm, a, fft_mesh):
+    """(4, N0, N1, N2): spectra of rho and of its three gradient components, every level's gradient taken in REAL space from the
+    AO derivatives on the level mesh (the RHOG_HIGH_ORDER = True branch of multigrid.py:545-560,633-658; hermi = 1)."""
+    a = np.asarray(a, dtype=float)
+    vol = abs(np.linalg.det(a))
+    dm = 0.5 * (np.asarray(dm, dtype=float) + np.asarray(dm, dtype=float).T)
+    rhoG = np.zeros((4,) + tuple(int(x) for x in fft_mesh), dtype=np.complex128)
+    for t in tasks:
+        ao4 = _task_ao4(t, atm, a)
+        nH, idx_h, idx_l = t['nH'], t['idx_h'], t['idx_l']
+        idx_t = np.append(idx_h, idx_l)
+        mesh = tuple(int(x) for x in t['mesh'])
+        ngrids = int(np.prod(mesh))
+        d = dm[idx_h[:, None], idx_t].copy()
+        if len(idx_l):
+            d[:, nH:] += dm[idx_l[:, None], idx_h].T
+        rho = np.empty((4, ngrids))
+        c0 = ao4[0].dot(d.T)                                   # (G, nH): sum_t D'_ht phi_t
+        rho[0] = np.einsum('gh,gh->g', ao4[0][:, :nH], c0)
+        for x in range(1, 4):
+            rho[x] = np.einsum('gh,gh->g', ao4[x][:, :nH], c0) + np.einsum('gh,gh->g', ao4[0][:, :nH], ao4[x].dot(d.T))
+        rho_freq = tools.fft(rho, mesh) * (vol / ngrids)
+        gx, gy, gz = _freq_index(mesh, fft_mesh)
+        rhoG[:, gx[:, None, None], gy[:, None], gz] += rho_freq.reshape((4,) + mesh)
+    return rhoG
+
+
+def integrate_gga(tasks, atm, wvG, a, fft_mesh, nao):
+    """Potential matrix of a GGA potential given by the spectra wvG (4, N0, N1, N2) of (w vrho, w de/d grad rho): per level
+    V_ht = sum_r phi_h [v0 phi_t + v_c d_c phi_t] + (d_c phi_h) v_c phi_t  (role of multigrid.py:936-1043, hermi = 1)."""
+    out = np.zeros((nao, nao))
+    for t in tasks:
+        ao4 = _task_ao4(t, atm, a)
+        nH, idx_h, idx_l = t['nH'], t['idx_h'], t['idx_l']
+        mesh = tuple(int(x) for x in t['mesh'])
+        gx, gy, gz = _freq_index(mesh, fft_mesh)
+        sub = wvG[:, gx[:, None, None], gy[:, None], gz].reshape(4, -1)
+        v = tools.ifft(sub, mesh).real
+        vp = ao4[0][:, :nH].T.dot(v[0][:, None] * ao4[0])
+        for x in range(1, 4):
+            vp += ao4[0][:, :nH].T.dot(v[x][:, None] * ao4[x]) + ao4[x][:, :nH].T.dot(v[x][:, None] * ao4[0])
+        out[idx_h[:, None], idx_h] += vp[:, :nH]
+        if len(idx_l):
+            out[idx_h[:, None], idx_l] += vp[:, nH:]
+            out[idx_l[:, None], idx_h] += vp[:, nH:].T
+    return out
+
+
+def nr_rks_b88(tasks, atm, dm, a, fft_mesh, with_j=False):
+    """(nelec, exc, veff, ecoul) through the ladder, 'b88,' (multigrid.py:1046-1150, GGA branch with real-space gradients)."""
+    a = np.asarray(a, dtype=float)
+    nao = np.asarray(dm).shape[-1]
+    fft_mesh = np.asarray(fft_mesh)
+    ngrids = int(np.prod(fft_mesh))
+    vol = abs(np.linalg.det(a))
+    weight = vol / ngrids
+    rhoG = eval_rhoG_gga(tasks, atm, dm, a, fft_mesh)
+    coulG = tools.get_coulG(a, fft_mesh).reshape(rhoG.shape[1:])
+    vG = rhoG[0] * coulG
+    ecoul = (.5 * (rhoG[0].real * vG.real).sum() + .5 * (rhoG[0].imag * vG.imag).sum()) / vol
+    rhoR = tools.ifft(rhoG.reshape(4, ngrids), fft_mesh).real / weight
+    exc, vrho, w = b88_exchange(rhoR[0], rhoR[1:])
+    wv = weight * np.vstack([vrho[None], w])
+    wvG = tools.fft(wv, fft_mesh).reshape(rhoG.shape)
+    if with_j:
+        wvG[0] += vG
+    veff = integrate_gga(tasks, atm, wvG, a, fft_mesh, nao)
+    return rhoR[0].sum() * weight, (rhoR[0] * exc).sum() * weight, veff, ecoul

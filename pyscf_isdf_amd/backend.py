@@ -462,6 +462,13 @@ class HipBackend:
         assert rho.is_contiguous() and exc.is_contiguous() and vxc.is_contiguous()
         self.handle.call('isdf_lda_exchange', self._p(rho), rho.numel(), self._p(exc), self._p(vxc))
 
+    def gga_b88(self, rho, grad, exc, vrho, w):
+        """rho (G,), grad (3, G) -> exc, vrho (G,), w (3, G) = de/d(grad rho)."""
+        self._stream()
+        assert rho.is_contiguous() and exc.is_contiguous() and vrho.is_contiguous() and grad.stride(1) == 1 and w.stride(1) == 1
+        self.handle.call('isdf_gga_b88', self._p(rho), self._p(grad), grad.stride(0), rho.numel(), self._p(exc), self._p(vrho),
+                         self._p(w), w.stride(0))
+
     def lda_exchange_fxc(self, rho, fxc):
         self._stream()
         assert rho.is_contiguous() and fxc.is_contiguous() and rho.numel() == fxc.numel()

@@ -85,6 +85,41 @@ __global__ void lda_exchange_kernel(const double* __restrict__ rho, int64_t n, d
   vxc[i] = (4.0 / 3.0) * e;
 }
 
+// Becke-88 exchange of a spin-unpolarised density (libxc GGA_X_B88; Becke, PRA 38, 3098): per spin channel
+// f(rho_s, g_s) = rho_s^(4/3) G(x), x = g_s / rho_s^(4/3), G = -C_x - beta x^2 / (1 + 6 beta x asinh x), C_x = (3/2)(3/4pi)^(1/3),
+// beta = 0.0042; e(rho, grad rho) = 2 f(rho/2, |grad rho|/2).  Outputs: exc = e / rho, vrho = de/drho, and the vector
+// w = de/d(grad rho) = 2 vsigma grad rho (what multiplies grad(phi_mu phi_nu) in the potential matrix).
+__global__ void gga_b88_kernel(const double* __restrict__ rho, const double* __restrict__ grad, int64_t gstride, int64_t n,
+                               double* __restrict__ exc, double* __restrict__ vrho, double* __restrict__ w, int64_t wstride) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double r = rho[i];
+  const double gx = grad[i], gy = grad[gstride + i], gz = grad[2 * gstride + i];
+  double e = 0.0, vr = 0.0, wfac = 0.0;
+  if (r > 1e-14) {
+    const double beta = 0.0042;
+    const double cx = 1.5 * cbrt(3.0 / (4.0 * 3.14159265358979323846));
+    const double rs = 0.5 * r;
+    const double r13 = cbrt(rs), r43 = rs * r13;
+    const double gs = 0.5 * sqrt(gx * gx + gy * gy + gz * gz);
+    const double x = gs / r43;
+    const double as = asinh(x);
+    const double D = 1.0 + 6.0 * beta * x * as;
+    const double Dp = 6.0 * beta * (as + x / sqrt(1.0 + x * x));
+    const double Gx = -cx - beta * x * x / D;
+    const double Gp_over_x = -beta * (2.0 * D - x * Dp) / (D * D);          // G'(x) / x, finite at x = 0
+    e = 2.0 * r43 * Gx / r;
+    vr = (4.0 / 3.0) * r13 * (Gx - x * x * Gp_over_x);
+    // de/d|grad rho| = 2 f_gs / 2 = G'(x);  w = G'(x) grad rho / |grad rho| = (G'/x) grad rho / (2 rho_s^(4/3))
+    wfac = Gp_over_x / (2.0 * r43);
+  }
+  exc[i] = e;
+  vrho[i] = vr;
+  w[i] = wfac * gx;
+  w[wstride + i] = wfac * gy;
+  w[2 * wstride + i] = wfac * gz;
+}
+
 // second derivative of the Slater exchange energy density: f = d2(rho exc)/d rho2 = (4/9) C rho^(-2/3), C = -(3/4)(3/pi)^(1/3)
 __global__ void lda_exchange_fxc_kernel(const double* __restrict__ rho, int64_t n, double* __restrict__ fxc) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -241,6 +276,16 @@ extern "C" int isdf_lda_exchange(isdf_handle h, const double* d_rho, int64_t n, 
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_rho && d_exc && d_vxc && n > 0);
   hipLaunchKernelGGL(lda_exchange_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, d_rho, n, d_exc, d_vxc);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_gga_b88(isdf_handle h, const double* d_rho, const double* d_grad, int64_t gstride, int64_t n, double* d_exc,
+                            double* d_vrho, double* d_w, int64_t wstride) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_rho && d_grad && d_exc && d_vrho && d_w && n > 0 && gstride >= n && wstride >= n);
+  hipLaunchKernelGGL(gga_b88_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, d_rho, d_grad, gstride, n, d_exc,
+                     d_vrho, d_w, wstride);
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

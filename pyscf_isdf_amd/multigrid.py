@@ -29,8 +29,8 @@ Surface: MultiGridFFTDF (get_jk, get_j_kpts, get_rho, tasks), nr_rks, nr_uks, nr
 cache_xc_kernel1, multi_grids_tasks, multigrid_fftdf - the names of pyscf/pbc/dft/multigrid/__init__.py.
 
 K is the ISDF exchange of the parent class (``MultiGridFFTDF(ISDF)``): hybrid functionals get J/XC from here and K from the
-interpolation, which is the pairing SURVEY section 8 f-3 names.  XC: only the Slater exchange ('lda,') - libxc is not part of
-this tree.  k-points: the same two passes on the periodic parts u_k, real and imaginary planes stacked so that the complex
+interpolation, which is the pairing SURVEY section 8 f-3 names.  XC: the Slater exchange ('lda,') and Becke's 1988 exchange
+('b88,', a GGA; Gamma point) in closed form - libxc is not part of this tree; both are pinned by the reference's SCF energies.  k-points: the same two passes on the periodic parts u_k, real and imaginary planes stacked so that the complex
 contractions are the Gamma point's real rectangular ones (get_j_kpts, nr_rks with kpts).
 """
 import copy
@@ -272,6 +272,14 @@ class TaggedArray(np.ndarray):
             self.__dict__.update(getattr(obj, '__dict__', {}))
 
 
+def _xc_kind(xc_code):
+    """'lda' (Slater exchange), 'b88' (Becke-88 exchange, a GGA) or None."""
+    code = str(xc_code).replace(' ', '').upper()
+    if code in ('B88,', 'B88', 'GGA_X_B88,', 'GGA_X_B88'):
+        return 'b88'
+    return 'lda' if _is_slater(xc_code) else None
+
+
 def _is_slater(xc_code):
     code = str(xc_code).replace(' ', '').upper()
     return code in ('LDA,', 'SLATER,', 'LDA_X,', 'LDA', 'SLATER', 'LDA_X')
@@ -388,6 +396,91 @@ class MultiGridFFTDF(ISDF):
                     out[i][lv.idx_h[:, None], lv.idx_l] += Vh[:, nH:]
                     out[i][lv.idx_l[:, None], lv.idx_h] += Vh[:, nH:].T
             del v, V, vpad, aoT
+        return out
+
+    # ---- GGA: densities and potentials with real-space gradients on every level (the reference's RHOG_HIGH_ORDER branch) ----
+    def _level_ao4(self, it, keep):
+        """(4, nT, G_t padded): values and x, y, z derivatives of level ``it``'s functions (dense rows first)."""
+        hit = self._level_cache.get((it, 'd1'))
+        if hit is not None:
+            return hit
+        lv, be, cell = self.tasks[it], self.backend, self.cell
+        ao4 = be.zeros((4, lv.nT, -(-lv.ngrids // 32) * 32))
+        coords_soa = be.uniform_grid(lv.mesh, cell.lattice_vectors())
+        nb = lv.nbas_h
+        atm = np.asarray(cell._atm)
+        be.eval_ao_deriv1(atm, lv.bas[:nb], lv.env, lv.Ls, lv.rcut[:nb], coords_soa, ao4[:, :lv.nH])
+        if lv.nT > lv.nH:
+            be.eval_ao_deriv1(atm, lv.bas[nb:], lv.env, lv.Ls, lv.rcut[nb:], coords_soa, ao4[:, lv.nH:])
+        if keep:
+            self._level_cache[(it, 'd1')] = ao4
+        return ao4
+
+    def _cache_plan_gga(self):
+        need = sum(32 * lv.nT * lv.ngrids for lv in self.tasks)
+        return need <= self.ao_cache_fraction * self.backend.free_bytes()
+
+    def _eval_rhoG_gga(self, dms):
+        """(4, nset, gc): half spectra of rho and of d rho / dx, dy, dz; the gradient of a level's density is taken in real space,
+        d_c rho_t = sum_h (d_c phi_h) (D' phi_T)_h + phi_h (D' d_c phi_T)_h  - two rectangular contractions per component."""
+        be, cell = self.backend, self.cell
+        self.build_tasks()
+        dms = np.asarray(dms, dtype=np.float64)
+        dms = 0.5 * (dms + dms.transpose(0, 2, 1))
+        nset = dms.shape[0]
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        spec4 = be.zeros((4, nset, self._spectrum_size()), dtype=torch.complex128)
+        keep = self._cache_plan_gga()
+        for it, lv in enumerate(self.tasks):
+            ao4 = self._level_ao4(it, keep)
+            nH = lv.nH
+            idx_t = np.append(lv.idx_h, lv.idx_l)
+            D = dms[:, lv.idx_h[:, None], idx_t]
+            if len(lv.idx_l):
+                D[:, :, nH:] += dms[:, lv.idx_l[:, None], lv.idx_h].transpose(0, 2, 1)
+            d_D = be.to_device(np.ascontiguousarray(D))
+            rho = be.empty((nset, lv.ngrids))
+            w = cell.vol / lv.ngrids
+            be.rho_pair(ao4[0, :nH], ao4[0], lv.ngrids, d_D, rho)
+            be.mg_embed_density(rho, lv.mesh, w, spec4[0], mesh, accumulate=True)
+            for c in (1, 2, 3):
+                be.rho_pair(ao4[c, :nH], ao4[0], lv.ngrids, d_D, rho)
+                be.mg_embed_density(rho, lv.mesh, w, spec4[c], mesh, accumulate=True)
+                be.rho_pair(ao4[0, :nH], ao4[c], lv.ngrids, d_D, rho)
+                be.mg_embed_density(rho, lv.mesh, w, spec4[c], mesh, accumulate=True)
+            del rho, ao4
+        return spec4
+
+    def _integrate_gga(self, wspec4):
+        """(nset, nao, nao): sum_r [v0 phi_mu phi_nu + v_c d_c(phi_mu phi_nu)] for the potentials with spectra wspec4 (4, nset, gc)
+        (role of _get_gga_pass2, multigrid.py:936-1043): seven MFMA products per level, the potentials as per-k scales."""
+        be, cell = self.backend, self.cell
+        nao = cell.nao_nr()
+        nset = wspec4.shape[1]
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        out = np.zeros((nset, nao, nao))
+        keep = self._cache_plan_gga()
+        for it, lv in enumerate(self.tasks):
+            ao4 = self._level_ao4(it, keep)
+            nH = lv.nH
+            v4 = be.empty((4, nset, lv.ngrids))
+            for c in range(4):
+                be.mg_restrict_potential(wspec4[c], mesh, lv.mesh, 1.0 / lv.ngrids, v4[c])
+            V = be.empty((nH, lv.nT))
+            vpad = be.zeros((ao4.shape[2],))
+            for i in range(nset):
+                vpad[:lv.ngrids].copy_(v4[0, i])
+                be.gemm_nt(ao4[0, :nH], ao4[0], V, kscale=vpad)
+                for c in (1, 2, 3):
+                    vpad[:lv.ngrids].copy_(v4[c, i])
+                    be.gemm_nt(ao4[0, :nH], ao4[c], V, beta=1.0, kscale=vpad)
+                    be.gemm_nt(ao4[c, :nH], ao4[0], V, beta=1.0, kscale=vpad)
+                Vh = be.to_host(V)
+                out[i][lv.idx_h[:, None], lv.idx_h] += Vh[:, :nH]
+                if len(lv.idx_l):
+                    out[i][lv.idx_h[:, None], lv.idx_l] += Vh[:, nH:]
+                    out[i][lv.idx_l[:, None], lv.idx_h] += Vh[:, nH:].T
+            del v4, V, vpad, ao4
         return out
 
     # ---- k-points: periodic parts u_k (the Bloch phases cancel in the density and in the potential matrix) ----------
@@ -559,13 +652,19 @@ def nr_rks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
     exchange; Gamma point (real matrices) or k-points (dm (nk, nao, nao) or (nset, nk, nao, nao), complex result on the
     k-points or on kpts_band).  Returns (nelec, exc, veff) with veff tagged ecoul / exc / vj / vk like the reference's; with_j
     adds the Coulomb potential to veff before the integration pass (one pass for J + XC)."""
-    if not _is_slater(xc_code):
-        raise NotImplementedError("xc=%r: only the Slater exchange ('lda,') is implemented (no libxc in this tree)" % (xc_code,))
+    kind = _xc_kind(xc_code)
+    if kind is None:
+        raise NotImplementedError("xc=%r: 'lda,' (Slater exchange) and 'b88,' (Becke-88 exchange) are implemented (no libxc in this "
+                                  "tree)" % (xc_code,))
     if kpts is None:
         kpts = mydf.kpts
     be, cell = mydf.backend, mydf.cell
     gamma = mydf._is_gamma(kpts) and mydf._is_gamma(kpts_band)
     nao = cell.nao_nr()
+    if kind == 'b88':
+        if not gamma:
+            raise NotImplementedError("'b88,' through the ladder is implemented at the Gamma point")
+        return _nr_rks_gga(mydf, dm_kpts, with_j, return_j)
     if gamma:
         shape, dms = mydf._real_dms(dm_kpts)
         spec = mydf._eval_rhoG(dms)
@@ -607,6 +706,46 @@ def nr_rks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
         spec.zero_()
     be.mg_embed_density(vxc, mesh, weight, spec, mesh, accumulate=True)      # + spectrum of the XC potential
     veff = integrate(spec)
+    if nset == 1:
+        nelec, excsum, ecoul = nelec[0], excsum[0], ecoul[0]
+    return nelec, excsum, TaggedArray(veff, ecoul=ecoul, exc=excsum, vj=vj, vk=None)
+
+
+def _nr_rks_gga(mydf, dm, with_j, return_j):
+    """'b88,' at the Gamma point: rho and grad rho from the ladder (real-space gradients per level), the functional on the dense
+    mesh (isdf_gga_b88), the potential v_rho phi phi + (de/d grad rho) . grad(phi phi) back through the ladder."""
+    be, cell = mydf.backend, mydf.cell
+    shape, dms = mydf._real_dms(dm)
+    nset = dms.shape[0]
+    mesh = np.asarray(mydf.mesh, dtype=np.int32)
+    G = int(np.prod(mesh))
+    weight = cell.vol / G
+    spec4 = mydf._eval_rhoG_gga(dms)
+    rho4 = be.empty((4, nset, G))
+    for c in range(4):
+        be.mg_restrict_potential(spec4[c], mesh, mesh, 1.0 / cell.vol, rho4[c])
+    vHspec = spec4[0].clone()
+    be.mg_coulomb_kernel(vHspec, mesh, cell.lattice_vectors())
+    vH = be.empty((nset, G))
+    be.mg_restrict_potential(vHspec, mesh, mesh, 1.0 / cell.vol, vH)
+    exc = be.empty((nset, G))
+    vrho = be.empty((nset, G))
+    w = be.empty((3, nset, G))
+    nelec, excsum, ecoul = np.zeros(nset), np.zeros(nset), np.zeros(nset)
+    for i in range(nset):
+        be.gga_b88(rho4[0, i], rho4[1:, i], exc[i], vrho[i], w[:, i])
+        nelec[i] = be.dot(rho4[0, i]) * weight
+        excsum[i] = be.dot(rho4[0, i], exc[i]) * weight
+        ecoul[i] = 0.5 * be.dot(rho4[0, i], vH[i]) * weight
+    del exc, vH, rho4
+    vj = mydf._integrate(vHspec).reshape(shape) if return_j else None
+    spec4.zero_()
+    if with_j:
+        spec4[0].copy_(vHspec)
+    be.mg_embed_density(vrho, mesh, weight, spec4[0], mesh, accumulate=True)
+    for c in range(3):
+        be.mg_embed_density(w[c], mesh, weight, spec4[1 + c], mesh, accumulate=True)
+    veff = mydf._integrate_gga(spec4).reshape(shape)
     if nset == 1:
         nelec, excsum, ecoul = nelec[0], excsum[0], ecoul[0]
     return nelec, excsum, TaggedArray(veff, ecoul=ecoul, exc=excsum, vj=vj, vk=None)

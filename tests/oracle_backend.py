@@ -123,6 +123,13 @@ class OracleBackend:
         exc.copy_(torch.from_numpy(e))
         vxc.copy_(torch.from_numpy(v))
 
+    def gga_b88(self, rho, grad, exc, vrho, w):
+        from oracle import multigrid as omg
+        e, vr, ww = omg.b88_exchange(rho.numpy(), grad.numpy())
+        exc.copy_(torch.from_numpy(e))
+        vrho.copy_(torch.from_numpy(vr))
+        w.copy_(torch.from_numpy(ww))
+
     def lda_exchange_fxc(self, rho, fxc):
         from oracle import multigrid as omg
         fxc.copy_(torch.from_numpy(omg.slater_exchange_fxc(rho.numpy())))

@@ -63,7 +63,7 @@ def _diamond_newton_cell():
                     basis='gth-szv', pseudo='gth-pade', mesh=[19] * 3)
 
 
-def test_diamond_rhf_and_lda_rks_total_energies_match_reference():
+def test_diamond_rhf_lda_and_b88_rks_total_energies_match_reference():
     """Diamond primitive cell, gth-szv / gth-pade, 19^3 (pyscf/pbc/scf/test/test_newton.py:51-90): RHF (exxdiv='ewald')
     e_tot = -10.137043711032916 and RKS 'lda,' e_tot = -9.7670882971475663, both places=8 in the reference.  Everything but S, T and
     the Ewald constant comes from the device: get_pp (local + non-local GTH), ISDF K, and J + the Slater-exchange potential
@@ -84,6 +84,13 @@ def test_diamond_rhf_and_lda_rks_total_energies_match_reference():
         return np.asarray(veff), float(veff.ecoul), float(exc)
     e_lda, dm = scf_helpers.rks(hcore, S, veff_lda, 4, e_nuc)
     assert abs(e_lda - (-9.7670882971475663)) < 5e-8            # measured: 5.1e-9 (profiles/r02_scf_pins_diamond_prim.log)
+    # the GGA of the same file (test_newton.py:92-98): RKS 'b88,' e_tot = -9.9355341416893559, rho and grad rho from the ladder
+    # with real-space gradients per level, Becke's exchange on the device
+    def veff_b88(dm):
+        n, exc, veff = pmg.nr_rks(df, 'b88,', dm, with_j=True)
+        return np.asarray(veff), float(veff.ecoul), float(exc)
+    e_b88, dm = scf_helpers.rks(hcore, S, veff_b88, 4, e_nuc)
+    assert abs(e_b88 - (-9.9355341416893559)) < 5e-8
     e_hf, dm = scf_helpers.rhf(hcore, S, lambda d: df.get_jk(d, exxdiv='ewald'), 4, e_nuc)
     assert abs(e_hf - (-10.137043711032916)) < 5e-8             # measured: 6.0e-9
 

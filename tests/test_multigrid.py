@@ -285,6 +285,97 @@ def test_gpu_multigrid_response_functions():
     _check_response(df, cell, 1e-9)
 
 
+def dense_ao4(cell):
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    return oao.eval_ao_deriv1(cell._atm, cell._bas, cell._env, cell.get_uniform_grids(), Ls, rcut)
+
+
+def test_b88_closed_form_derivatives():
+    """oracle.multigrid.b88_exchange: vrho and w = de/d(grad rho) against central differences of the energy density; the
+    uniform-gas limit is the Slater exchange."""
+    rng = np.random.default_rng(0)
+    rho = rng.random(500) * 2 + 1e-3
+    grad = rng.standard_normal((3, 500)) * rho ** 1.2
+    g = np.sqrt((grad ** 2).sum(axis=0))
+    exc, vrho, w = omg.b88_exchange(rho, grad)
+    h = 1e-6
+    assert abs((omg.b88_energy_density(rho * (1 + h), g) - omg.b88_energy_density(rho * (1 - h), g)) / (2 * h * rho) - vrho).max() < 1e-8
+    fd = (omg.b88_energy_density(rho, g * (1 + h)) - omg.b88_energy_density(rho, g * (1 - h))) / (2 * h * g)
+    assert abs(fd[None] * grad / g - w).max() < 1e-8
+    assert abs(omg.b88_exchange(np.array([1.3]), np.zeros((3, 1)))[0][0] - omg.slater_exchange(np.array([1.3]))[0][0]) < 1e-14
+
+
+def test_oracle_scf_reproduces_the_reference_lda_and_b88_energies():
+    """All-oracle SCF on the diamond primitive cell of pyscf/pbc/scf/test/test_newton.py:25-44 (gth-szv / gth-pade, 19^3): RKS
+    'lda,' -9.7670882971475663 and RKS 'b88,' -9.9355341416893559 (both places=8 there).  Pins the closed-form functionals
+    (libxc is absent) and the dense-grid GGA quadrature the ladder is compared with."""
+    import scf_helpers
+    from oracle import pp as opp
+    cell = gto.Cell(unit='B', atom='C 0. 0. 0.; C 1.68506879 1.68506879 1.68506879',
+                    a=[[0., 3.37013758, 3.37013758], [3.37013758, 0., 3.37013758], [3.37013758, 3.37013758, 0.]],
+                    basis='gth-szv', pseudo='gth-pade', mesh=[19] * 3)
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    S, T = scf_helpers.overlap_kinetic_from_ft(cell)
+    ao4 = dense_ao4(cell)
+    ps = [cell._pseudo.get(cell.atom_symbol(i)) for i in range(cell.natm)]
+    vpp = opp.get_pp(cell._atm, cell._bas, cell._env, cell.atom_coords(), cell.atom_charges(), ps, a, mesh,
+                     cell.get_uniform_grids(), [ao4[0]], np.zeros((1, 3)))[0].real
+    e_nuc = scf_helpers.ewald_energy(cell)
+
+    def make(xc):
+        def veff(dm):
+            vj = offt.get_j(ao4[0], dm, a, mesh)
+            n, exc, vxc = xc(dm)
+            return vj + vxc, 0.5 * np.einsum('ij,ji', vj, dm), exc
+        return veff
+    e_b88 = scf_helpers.rks(T + vpp, S, make(lambda dm: omg.nr_rks_b88_dense(ao4, dm, a, mesh)), 4, e_nuc)[0]
+    assert abs(e_b88 - (-9.9355341416893559)) < 5e-8
+    e_lda = scf_helpers.rks(T + vpp, S, make(lambda dm: omg.nr_rks_lda_dense(ao4[0], dm, a, mesh)), 4, e_nuc)[0]
+    assert abs(e_lda - (-9.7670882971475663)) < 5e-8
+
+
+def _check_gga(df, cell, tol):
+    """nr_rks('b88,') of the product against the oracle on the same ladder, against the dense-grid quadrature (1e-7, the
+    reference's own criterion for its GGA: test_multigrid.py:216-226) and against its definition (veff = dE_xc/dD)."""
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    dm = make_dm(cell)
+    n, e, veff = pmg.nr_rks(df, 'b88,', dm, with_j=True, return_j=True)
+    tasks = as_tasks(df.tasks)
+    n0, e0, v0, ec0 = omg.nr_rks_b88(tasks, cell._atm, dm, a, mesh, with_j=True)
+    assert abs(n - n0) < tol * 100 and abs(e - e0) < tol * 100 and abs(veff - v0).max() < tol * 10 and abs(veff.ecoul - ec0) < 1e-7
+    vj = df.get_jk(dm, with_k=False)[0]
+    assert abs(veff.vj - vj).max() < 1e-9
+    nd, ed, vd = omg.nr_rks_b88_dense(dense_ao4(cell), dm, a, mesh)
+    vxc = pmg.nr_rks(df, 'B88,', dm)[2]
+    assert abs(e - ed) < 1e-7 and abs(vxc - vd).max() < 1e-7 and abs(veff - vj - vxc).max() < 1e-9
+    rng = np.random.default_rng(4)
+    d1 = rng.standard_normal(dm.shape) * 0.05
+    d1 = d1 + d1.T
+    eps = 1e-4
+    fd = (pmg.nr_rks(df, 'b88,', dm + eps * d1)[1] - pmg.nr_rks(df, 'b88,', dm - eps * d1)[1]) / (2 * eps)
+    assert abs(fd - np.einsum('ij,ji', vxc, d1)) < 1e-6 * max(1.0, abs(fd))
+    with pytest.raises(NotImplementedError):
+        pmg.nr_rks(df, 'b88,', np.stack([dm, dm]).astype(complex), kpts=np.array([[0.1, 0, 0], [-0.1, 0, 0]]))
+
+
+def test_product_gga_on_checker_backend():
+    from oracle_backend import OracleBackend
+    cell = cell_he_split()
+    df = pmg.MultiGridFFTDF(cell, backend=OracleBackend())
+    df.split = 'all'
+    _check_gga(df, cell, 1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mk', [cell_he_split, cell_c2_orth])
+def test_gpu_multigrid_gga_b88(mk):
+    cell = mk()
+    df = pmg.MultiGridFFTDF(cell)
+    df.split = 'all'
+    _check_gga(df, cell, 1e-9)
+
+
 def test_product_kpts_on_checker_backend():
     """k-point J / LDA of pyscf_isdf_amd.multigrid on the CPU checker backend: stacked real / imaginary planes against the
     oracle's complex arithmetic on the same ladder, and the oracle's FFTDF J at the k-points."""

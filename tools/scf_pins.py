@@ -12,5 +12,10 @@ def veff_lda(dm):
     return np.asarray(veff), float(veff.ecoul), float(exc)
 e, dm = scf_helpers.rks(hcore, S, veff_lda, 4, e_nuc)
 print('LDA  e_tot %.12f  ref -9.7670882971475663  diff %.2e' % (e, e + 9.7670882971475663))
+def veff_b88(dm):
+    n, exc, veff = pmg.nr_rks(df, 'b88,', dm, with_j=True)
+    return np.asarray(veff), float(veff.ecoul), float(exc)
+e, dm = scf_helpers.rks(hcore, S, veff_b88, 4, e_nuc)
+print('B88  e_tot %.12f  ref -9.9355341416893559  diff %.2e' % (e, e + 9.9355341416893559))
 e, dm = scf_helpers.rhf(hcore, S, lambda d: df.get_jk(d, exxdiv='ewald'), 4, e_nuc)
 print('RHF  e_tot %.12f  ref -10.137043711032916  diff %.2e   P=%d' % (e, e + 10.137043711032916, len(df.ip)))
