@@ -136,9 +136,10 @@ def _angular_grad(l, dx, dy, dz):
     raise NotImplementedError('l > 2')
 
 
-def eval_ao_deriv1(atm, bas, env, coords, Ls, rcut):
-    """AO values and Cartesian first derivatives at the Gamma point: (4, G, nao) = (value, d/dx, d/dy, d/dz), the layout of
-    numint.eval_ao(deriv=1) (pyscf/pbc/dft/numint.py:33-93).  Per-point truncation rule (see eval_ao); the derivative of
+def eval_ao_deriv1(atm, bas, env, coords, Ls, rcut, kpt=None):
+    """AO values and Cartesian first derivatives: (4, G, nao) = (value, d/dx, d/dy, d/dz), the layout of
+    numint.eval_ao(deriv=1) (pyscf/pbc/dft/numint.py:33-93); real at the Gamma point, the Bloch sums sum_T exp(i k.T) (...)(r - T)
+    of values and derivatives (complex) at ``kpt`` (eval_gto.py:31-165: the phase multiplies every component alike).  Per-point truncation rule (see eval_ao); the derivative of
     fac * ang(d) * sum_p c_p exp(-a_p r^2) is  grad(ang) * R + ang * (-2 d) * sum_p c_p a_p exp(-a_p r^2)
     (pyscf/lib/gto/deriv1.c:60-69 for the radial part, :166-330 for the Cartesian factors)."""
     atm = np.asarray(atm).reshape(-1, ATM_SLOTS)
@@ -146,7 +147,8 @@ def eval_ao_deriv1(atm, bas, env, coords, Ls, rcut):
     coords = np.asarray(coords, dtype=float)
     G = coords.shape[0]
     loc = ao_loc(bas)
-    out = np.zeros((4, loc[-1], G))
+    gamma = kpt is None or abs(np.asarray(kpt)).sum() < 1e-9
+    out = np.zeros((4, loc[-1], G), dtype=np.float64 if gamma else np.complex128)
     rcut = np.asarray(rcut, dtype=float)
     for ia in range(len(atm)):
         shl = np.where(bas[:, ATOM_OF] == ia)[0]
@@ -155,6 +157,7 @@ def eval_ao_deriv1(atm, bas, env, coords, Ls, rcut):
         ri = env[atm[ia, PTR_COORD]:atm[ia, PTR_COORD] + 3]
         rc_max = rcut[shl].max()
         for L in Ls:
+            ph = 1.0 if gamma else np.exp(1j * np.dot(L, kpt))
             d = coords - (ri + L)
             rr = np.einsum('gx,gx->g', d, d)
             if not (rr < rc_max * rc_max).any():
@@ -177,7 +180,7 @@ def eval_ao_deriv1(atm, bas, env, coords, Ls, rcut):
                 for k in range(nc):
                     for mm in range(deg):
                         row = loc[ib] + k * deg + mm
-                        out[0, row, idx] += rad[k] * ang[mm]
+                        out[0, row, idx] += ph * (rad[k] * ang[mm])
                         for x in range(3):
-                            out[1 + x, row, idx] += gang[mm][x] * rad[k] - 2.0 * dd[x] * ang[mm] * rad1[k]
+                            out[1 + x, row, idx] += ph * (gang[mm][x] * rad[k] - 2.0 * dd[x] * ang[mm] * rad1[k])
     return np.ascontiguousarray(out.transpose(0, 2, 1))

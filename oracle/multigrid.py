@@ -587,3 +587,29 @@ def nr_rks_b88(tasks, atm, dm, a, fft_mesh, with_j=False):
         wvG[0] += vG
     veff = integrate_gga(tasks, atm, wvG, a, fft_mesh, nao)
     return rhoR[0].sum() * weight, (rhoR[0] * exc).sum() * weight, veff, ecoul
+
+
+def nr_rks_b88_dense_kpts(ao4_kpts, dms, a):
+    """(nelec, exc, vxc (nk, nao, nao)) of 'b88,' by quadrature on the dense grid at k-points: what KNumInt.nr_rks does for a GGA
+    (pyscf/pbc/dft/numint.py:1090-1292 with pyscf/dft/numint.py's GGA kernel: rho = 1/nk sum_k Re[...], wv[0] *= .5,
+    V^k = ao0^H (sum_c wv_c ao_c) + h.c.).  ao4_kpts: list over k of (4, G, nao) complex Bloch functions and derivatives."""
+    nk = len(ao4_kpts)
+    ngrids = ao4_kpts[0].shape[1]
+    weight = abs(np.linalg.det(a)) / ngrids
+    rho = np.zeros((4, ngrids))
+    for k in range(nk):
+        ao4, dm = ao4_kpts[k], np.asarray(dms[k])
+        c0 = ao4[0].dot(dm.T)                              # sum_j dm_ij ao_j ... rho = sum_ij conj(ao_i) dm_ij ao_j
+        rho[0] += np.einsum('gi,gi->g', ao4[0].conj(), ao4[0].dot(dm.T)).real
+        for x in range(1, 4):
+            rho[x] += 2.0 * np.einsum('gi,gi->g', ao4[0].conj(), ao4[x].dot(dm.T)).real
+    rho /= nk
+    exc, vrho, w = b88_exchange(rho[0], rho[1:])
+    wv = weight * np.vstack([0.5 * vrho[None], w])
+    vxc = []
+    for k in range(nk):
+        ao4 = ao4_kpts[k]
+        aow = sum(wv[c][:, None] * ao4[c] for c in range(4))
+        v = ao4[0].conj().T.dot(aow)
+        vxc.append(v + v.conj().T)
+    return rho[0].sum() * weight, (rho[0] * exc).sum() * weight, np.array(vxc)

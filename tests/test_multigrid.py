@@ -439,3 +439,34 @@ def test_gpu_multigrid_pairs_with_isdf_k():
     plain = ISDF(cell, c_isdf=8, select='global')
     vj0, vk0 = plain.get_jk(dm)
     assert abs(vj - vj0).max() < 1e-8 and abs(vk - vk0).max() < 1e-9
+
+
+def test_oracle_kpoint_b88_potential_reproduces_the_reference_constant():
+    """The reference's only stored constant for a multigrid XC POTENTIAL (test_multigrid.py:216-227): C2 in the cubic 3.5668 A cell,
+    gth-dzv / gth-pade, 48^3, two k-points k, -k and density matrices drawn after numpy.random.seed(2):
+    fp(vxc['b88,'] + vj) = -0.05697304864467462+0.6990367789096609j (places=7), computed there by KNumInt + FFTDF.  The oracle's
+    dense-grid k-point B88 quadrature + FFTDF J reproduce it: the closed-form Becke POTENTIAL (vrho, de/d grad rho) is pinned to
+    libxc's, and through the oracle comparisons (1e-9) so is the device's Gamma-point GGA potential."""
+    from oracle import pbc_tools as otools
+    np.random.seed(2)
+    np.random.random((3, 3))                                   # the reference draws its non-orthogonal lattice first
+    kpts = np.random.random((2, 3))
+    kpts[1] = -kpts[0]
+    dzvp = gto.Cell(a=np.eye(3) * 3.5668, atom='C 0 0 0; C 1.8 1.8 1.8', basis='gth-dzvp', pseudo='gth-pade', precision=1e-9,
+                    mesh=[48] * 3)
+    # gth-dzv is gth-dzvp without the polarisation shell (pyscf/pbc/gto/basis/gth-dzv.dat:40-46 vs gth-dzvp.dat:60-68)
+    cell = gto.Cell(a=np.eye(3) * 3.5668, atom='C 0 0 0; C 1.8 1.8 1.8', basis={'C': [b for b in dzvp._basis['C'] if b[0] < 2]},
+                    pseudo='gth-pade', precision=1e-9, mesh=[48] * 3)
+    nao = cell.nao_nr()
+    assert nao == 16
+    dm = np.random.random((2, nao, nao)) * .2
+    dm1 = dm + np.eye(nao)
+    dm = dm1 + dm1.transpose(0, 2, 1)
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    coords = cell.get_uniform_grids()
+    ao4 = [oao.eval_ao_deriv1(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpt=k) for k in kpts]
+    n, exc, vxc = omg.nr_rks_b88_dense_kpts(ao4, dm, a)
+    vj = offt.get_jk_kpts([x[0] for x in ao4], dm, a, mesh, coords, kpts)[0]
+    assert abs(otools.fp(vxc + vj) - (-0.05697304864467462 + 0.6990367789096609j)) < 1e-7
