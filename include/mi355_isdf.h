@@ -105,6 +105,12 @@ int isdf_eval_ao(isdf_handle h,
 int isdf_eval_ao_deriv1(isdf_handle h, const int32_t* atm, int natm, const int32_t* bas, int nbas, const double* env,
                         int nenv, const double* Ls, int nimgs, const double* rcut, const double* d_coords,
                         int64_t ngrids, double* d_ao, int64_t ld, int64_t plane_stride);
+/* k-point form: Bloch sums of values and Cartesian derivatives (times exp(-i k.r) with periodic_part - the derivative stays that
+ * of the Bloch function), real and imaginary planes d_re / d_im + comp * plane_stride. */
+int isdf_eval_ao_k_deriv1(isdf_handle h, const int32_t* atm, int natm, const int32_t* bas, int nbas, const double* env,
+                          int nenv, const double* Ls, int nimgs, const double* rcut, const double kpt[3], int periodic_part,
+                          const double* d_coords, int64_t ngrids, double* d_re, double* d_im, int64_t ld,
+                          int64_t plane_stride);
 
 /* k-point collocation: real and imaginary planes (nao rows each, leading dimension ld) of
  *   periodic_part = 0:  phi^k_m(r) = sum_T exp(i k.T) phi_m(r - T)       (eval_gto.py:137, grid_ao.c:421-422)

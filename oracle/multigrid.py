@@ -613,3 +613,66 @@ def nr_rks_b88_dense_kpts(ao4_kpts, dms, a):
         v = ao4[0].conj().T.dot(aow)
         vxc.append(v + v.conj().T)
     return rho[0].sum() * weight, (rho[0] * exc).sum() * weight, np.array(vxc)
+
+
+def _task_ao4_kpts(task, atm, a, kpts):
+    coords = uniform_grids(np.asarray(a, dtype=float), task['mesh'])
+    return [np.asarray(oao.eval_ao_deriv1(atm, task['bas'], task['env'], coords, task['Ls'], task['rcut'], kpt=np.asarray(k, dtype=float)),
+                       dtype=np.complex128) for k in np.reshape(kpts, (-1, 3))]
+
+
+def nr_rks_b88_kpts(tasks, atm, dms, a, fft_mesh, kpts, with_j=False):
+    """(nelec, exc, veff (nk, nao, nao)) of 'b88,' through the ladder at k-points (Hermitian dms (nk, nao, nao)): level densities
+    and gradients in real space from the Bloch functions and their derivatives, the GGA potential integrated per level and k."""
+    a = np.asarray(a, dtype=float)
+    fft_mesh = np.asarray(fft_mesh)
+    ngrids = int(np.prod(fft_mesh))
+    vol = abs(np.linalg.det(a))
+    weight = vol / ngrids
+    dms = np.asarray(dms, dtype=np.complex128)
+    nk, nao = dms.shape[0], dms.shape[-1]
+    rhoG = np.zeros((4,) + tuple(int(x) for x in fft_mesh), dtype=np.complex128)
+    for t in tasks:
+        aos = _task_ao4_kpts(t, atm, a, kpts)
+        nH, idx_h, idx_l = t['nH'], t['idx_h'], t['idx_l']
+        mesh = tuple(int(x) for x in t['mesh'])
+        ng = int(np.prod(mesh))
+        rho = np.zeros((4, ng), dtype=np.complex128)
+        for k in range(nk):
+            ao4 = aos[k]
+            blocks = [(slice(0, nH), slice(0, nH), dms[k][idx_h[:, None], idx_h])]
+            if len(idx_l):
+                blocks += [(slice(0, nH), slice(nH, None), dms[k][idx_h[:, None], idx_l]),
+                           (slice(nH, None), slice(0, nH), dms[k][idx_l[:, None], idx_h])]
+            for si, sj, d in blocks:
+                c = ao4[0][:, si].dot(d)                                                     # sum_i ao_i d_ij
+                rho[0] += np.einsum('gj,gj->g', c, ao4[0][:, sj].conj())
+                for x in range(1, 4):
+                    rho[x] += np.einsum('gj,gj->g', ao4[x][:, si].dot(d), ao4[0][:, sj].conj()) + \
+                        np.einsum('gj,gj->g', c, ao4[x][:, sj].conj())
+        rho_freq = tools.fft(rho, mesh) * (vol / ng / nk)
+        gx, gy, gz = _freq_index(mesh, fft_mesh)
+        rhoG[:, gx[:, None, None], gy[:, None], gz] += rho_freq.reshape((4,) + mesh)
+    coulG = tools.get_coulG(a, fft_mesh).reshape(rhoG.shape[1:])
+    rhoR = tools.ifft(rhoG.reshape(4, ngrids), fft_mesh).real / weight
+    exc, vrho, w = b88_exchange(rhoR[0], rhoR[1:])
+    wvG = tools.fft(weight * np.vstack([vrho[None], w]), fft_mesh).reshape(rhoG.shape)
+    if with_j:
+        wvG[0] += rhoG[0] * coulG
+    veff = np.zeros((nk, nao, nao), dtype=np.complex128)
+    for t in tasks:
+        aos = _task_ao4_kpts(t, atm, a, kpts)
+        nH, idx_h, idx_l = t['nH'], t['idx_h'], t['idx_l']
+        mesh = tuple(int(x) for x in t['mesh'])
+        gx, gy, gz = _freq_index(mesh, fft_mesh)
+        v = tools.ifft(wvG[:, gx[:, None, None], gy[:, None], gz].reshape(4, -1), mesh).real
+        for k in range(nk):
+            ao4 = aos[k]
+            vp = ao4[0][:, :nH].conj().T.dot(v[0][:, None] * ao4[0])
+            for x in range(1, 4):
+                vp += ao4[0][:, :nH].conj().T.dot(v[x][:, None] * ao4[x]) + ao4[x][:, :nH].conj().T.dot(v[x][:, None] * ao4[0])
+            veff[k][idx_h[:, None], idx_h] += vp[:, :nH]
+            if len(idx_l):
+                veff[k][idx_h[:, None], idx_l] += vp[:, nH:]
+                veff[k][idx_l[:, None], idx_h] += vp[:, nH:].conj().T
+    return rhoR[0].sum() * weight, (rhoR[0] * exc).sum() * weight, veff

@@ -159,6 +159,22 @@ class HipBackend:
         self.handle.call('isdf_eval_ao_deriv1', _np_ptr(atm), len(atm), _np_ptr(bas), len(bas), _np_ptr(env), len(env),
                          _np_ptr(Ls), len(Ls), _np_ptr(rcut), self._p(coords_soa), G, self._p(ao4), ao4.stride(1), ao4.stride(0))
 
+    def eval_ao_k_deriv1(self, atm, bas, env, Ls, rcut, kpt, periodic_part, coords_soa, out_re, out_im):
+        """out_re / out_im (4, nao, ld) views of one buffer <- Bloch sums of values and x, y, z derivatives at ``kpt``."""
+        self._stream()
+        atm = np.ascontiguousarray(atm, dtype=np.int32)
+        bas = np.ascontiguousarray(bas, dtype=np.int32)
+        env = np.ascontiguousarray(env, dtype=np.float64)
+        Ls = np.ascontiguousarray(Ls, dtype=np.float64)
+        rcut = np.ascontiguousarray(rcut, dtype=np.float64)
+        kpt = np.ascontiguousarray(kpt, dtype=np.float64)
+        G = coords_soa.shape[1]
+        assert out_re.dim() == 3 and out_re.shape[0] == 4 and tuple(out_re.shape) == tuple(out_im.shape)
+        assert out_re.stride() == out_im.stride() and out_re.stride(2) == 1 and out_re.shape[2] >= G
+        self.handle.call('isdf_eval_ao_k_deriv1', _np_ptr(atm), len(atm), _np_ptr(bas), len(bas), _np_ptr(env), len(env),
+                         _np_ptr(Ls), len(Ls), _np_ptr(rcut), _np_ptr(kpt), int(bool(periodic_part)), self._p(coords_soa), G,
+                         self._p(out_re), self._p(out_im), out_re.stride(1), out_re.stride(0))
+
     def gather_cols(self, src, idx, dst):
         self._stream()
         assert idx.dtype == torch.int64 and src.stride(1) == 1 and dst.stride(1) == 1

@@ -453,6 +453,125 @@ __global__ __launch_bounds__(TPB) void eval_ao_deriv1_kernel(
   }
 }
 
+// k-point form of shell_eval_d1, one component X (0 value, 1..3 d/dx, d/dy, d/dz) per call so that the accumulators stay in
+// registers: Bloch sums sum_T exp(i k.T) (.)(r - T) of the value or of one derivative, times exp(-i k.r) when the periodic part is
+// asked for (then the derivative is that of the Bloch function times the phase, NOT the derivative of the periodic part - callers
+// that differentiate pair products conj(u_i) u_j never see the difference: the phases cancel in the product and in its gradient).
+template <int L, int X>
+__device__ inline void shell_eval_k_d1(const ShellDev sh, const double* __restrict__ env, const double* __restrict__ Ls,
+                                       const double* __restrict__ phT, const int* __restrict__ img_list, int nlist, double px,
+                                       double py, double pz, double ax, double ay, double az, bool valid, double pr, double pi,
+                                       double* __restrict__ out_re, double* __restrict__ out_im, int64_t ld, int64_t g) {
+  constexpr int DEG = 2 * L + 1;
+  double accr[NCMAX][DEG], acci[NCMAX][DEG];
+#pragma unroll
+  for (int c = 0; c < NCMAX; ++c)
+#pragma unroll
+    for (int m = 0; m < DEG; ++m) { accr[c][m] = 0.0; acci[c][m] = 0.0; }
+  const double fac = (L == 0) ? FAC_S : (L == 1 ? FAC_P : 1.0);
+  const double* __restrict__ es = env + sh.pexp;
+  const double* __restrict__ cs = env + sh.pcoef;
+  for (int i = 0; i < nlist; ++i) {
+    const int iL = img_list[i];
+    const double d[3] = {px - (ax + Ls[3 * iL + 0]), py - (ay + Ls[3 * iL + 1]), pz - (az + Ls[3 * iL + 2])};
+    const double rr = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    if (rr < sh.rcut2) {
+      const double tr = phT[2 * iL], ti = phT[2 * iL + 1];
+      double rad[NCMAX], rad1[NCMAX];
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c) { rad[c] = 0.0; rad1[c] = 0.0; }
+      for (int p = 0; p < sh.nprim; ++p) {
+        const double e = exp(-es[p] * rr) * fac;
+#pragma unroll
+        for (int c = 0; c < NCMAX; ++c)
+          if (c < sh.nctr) {
+            rad[c] += cs[c * sh.nprim + p] * e;
+            if (X > 0) rad1[c] += cs[c * sh.nprim + p] * es[p] * e;
+          }
+      }
+      double ang[DEG], gang[DEG];
+      const double dx = d[0], dy = d[1], dz = d[2];
+      if (L == 0) {
+        ang[0] = 1.0; gang[0] = 0.0;
+      } else if (L == 1) {
+        ang[0] = dx; ang[1] = dy; ang[2] = dz;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) gang[m] = (X == m + 1) ? 1.0 : 0.0;
+      } else {
+        ang[0] = D_XY * dx * dy;
+        ang[1] = D_XY * dy * dz;
+        ang[2] = D_Z2_ZZ * dz * dz - D_Z2_XXYY * (dx * dx + dy * dy);
+        ang[3] = D_XY * dx * dz;
+        ang[4] = D_X2Y2 * (dx * dx - dy * dy);
+        if (X == 1) { gang[0] = D_XY * dy; gang[1] = 0.0; gang[2] = -2.0 * D_Z2_XXYY * dx; gang[3] = D_XY * dz; gang[4] = 2.0 * D_X2Y2 * dx; }
+        else if (X == 2) { gang[0] = D_XY * dx; gang[1] = D_XY * dz; gang[2] = -2.0 * D_Z2_XXYY * dy; gang[3] = 0.0; gang[4] = -2.0 * D_X2Y2 * dy; }
+        else { gang[0] = 0.0; gang[1] = D_XY * dy; gang[2] = 2.0 * D_Z2_ZZ * dz; gang[3] = D_XY * dx; gang[4] = 0.0; }
+      }
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c)
+#pragma unroll
+        for (int m = 0; m < DEG; ++m) {
+          const double v = (X == 0) ? rad[c] * ang[m] : gang[m] * rad[c] - 2.0 * d[X > 0 ? X - 1 : 0] * ang[m] * rad1[c];
+          accr[c][m] += v * tr;
+          acci[c][m] += v * ti;
+        }
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c)
+      if (c < sh.nctr) {
+#pragma unroll
+        for (int m = 0; m < DEG; ++m) {
+          const int64_t off = (int64_t)(sh.ao0 + c * DEG + m) * ld + g;
+          out_re[off] = accr[c][m] * pr - acci[c][m] * pi;
+          out_im[off] = accr[c][m] * pi + acci[c][m] * pr;
+        }
+      }
+  }
+}
+
+template <int L>
+__device__ inline void shell_eval_k_d1_all(const ShellDev sh, const double* __restrict__ env, const double* __restrict__ Ls,
+                                           const double* __restrict__ phT, const int* __restrict__ img_list, int nlist, double px,
+                                           double py, double pz, double ax, double ay, double az, bool valid, double pr, double pi,
+                                           double* __restrict__ out_re, double* __restrict__ out_im, int64_t ld, int64_t plane,
+                                           int64_t g) {
+  shell_eval_k_d1<L, 0>(sh, env, Ls, phT, img_list, nlist, px, py, pz, ax, ay, az, valid, pr, pi, out_re, out_im, ld, g);
+  shell_eval_k_d1<L, 1>(sh, env, Ls, phT, img_list, nlist, px, py, pz, ax, ay, az, valid, pr, pi, out_re + plane, out_im + plane, ld, g);
+  shell_eval_k_d1<L, 2>(sh, env, Ls, phT, img_list, nlist, px, py, pz, ax, ay, az, valid, pr, pi, out_re + 2 * plane, out_im + 2 * plane, ld, g);
+  shell_eval_k_d1<L, 3>(sh, env, Ls, phT, img_list, nlist, px, py, pz, ax, ay, az, valid, pr, pi, out_re + 3 * plane, out_im + 3 * plane, ld, g);
+}
+
+__global__ __launch_bounds__(TPB) void eval_ao_k_deriv1_kernel(
+    const AtomDev* __restrict__ atoms, const ShellDev* __restrict__ shells, const double* __restrict__ env,
+    const double* __restrict__ Ls, const double* __restrict__ phT, int nimgs, double kx, double ky, double kz, int periodic,
+    const double* __restrict__ coords, int64_t ngrids, double* __restrict__ out_re, double* __restrict__ out_im, int64_t ld,
+    int64_t plane) {
+  extern __shared__ int img_list[];
+  __shared__ double red[6][TPB / 64];
+  __shared__ int wcnt[TPB / 64];
+  const int64_t g = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  const bool valid = g < ngrids;
+  const int64_t gc = valid ? g : (int64_t)blockIdx.x * TPB;
+  const double px = coords[gc], py = coords[ngrids + gc], pz = coords[2 * ngrids + gc];
+  const AtomDev at = atoms[blockIdx.y];
+  const int nlist = cull_images(at, Ls, nimgs, px, py, pz, img_list, red, wcnt);
+  double pr = 1.0, pi = 0.0;
+  if (periodic) {
+    const double kr = kx * px + ky * py + kz * pz;
+    sincos(-kr, &pi, &pr);
+  }
+  for (int s = at.sh0; s < at.sh1; ++s) {
+    const ShellDev sh = shells[s];
+    switch (sh.l) {
+      case 0: shell_eval_k_d1_all<0>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, plane, g); break;
+      case 1: shell_eval_k_d1_all<1>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, plane, g); break;
+      default: shell_eval_k_d1_all<2>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, plane, g); break;
+    }
+  }
+}
+
 __global__ void gather_cols_kernel(const double* __restrict__ src, int64_t ld_src,
                                    const int64_t* __restrict__ idx, int64_t n,
                                    double* __restrict__ dst, int64_t ld_dst) {
@@ -582,6 +701,31 @@ extern "C" int isdf_eval_ao_k(isdf_handle h, const int32_t* atm, int natm, const
   hipLaunchKernelGGL(eval_ao_k_kernel, grid, dim3(TPB), (size_t)nimgs * sizeof(int), h->stream,
                      t.d_atoms, t.d_shells, t.d_env, t.d_Ls, t.d_phT, nimgs, kpt[0], kpt[1], kpt[2],
                      periodic_part ? 1 : 0, d_coords, ngrids, d_re, d_im, ld);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_eval_ao_k_deriv1(isdf_handle h, const int32_t* atm, int natm, const int32_t* bas, int nbas, const double* env,
+                                     int nenv, const double* Ls, int nimgs, const double* rcut, const double kpt[3],
+                                     int periodic_part, const double* d_coords, int64_t ngrids, double* d_re, double* d_im,
+                                     int64_t ld, int64_t plane_stride) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, kpt && d_coords && d_re && d_im && ngrids > 0 && ld >= ngrids);
+  std::vector<double> ph(2 * (size_t)nimgs);
+  for (int i = 0; i < nimgs; ++i) {
+    const double kl = kpt[0] * Ls[3 * i] + kpt[1] * Ls[3 * i + 1] + kpt[2] * Ls[3 * i + 2];
+    ph[2 * i] = cos(kl);
+    ph[2 * i + 1] = sin(kl);
+  }
+  AoTables t;
+  int rc = upload_ao_tables(h, atm, natm, bas, nbas, env, nenv, Ls, nimgs, rcut, ph.data(), &t);
+  if (rc) return rc;
+  ARG_CHECK(h, plane_stride >= (int64_t)t.nao * ld);
+  dim3 grid((unsigned)cdiv(ngrids, TPB), (unsigned)natm);
+  ProfScope ps(h, "eval_ao_k_deriv1_kernel[byte]", 64.0 * (double)ngrids * t.nao);
+  hipLaunchKernelGGL(eval_ao_k_deriv1_kernel, grid, dim3(TPB), (size_t)nimgs * sizeof(int), h->stream, t.d_atoms, t.d_shells,
+                     t.d_env, t.d_Ls, t.d_phT, nimgs, kpt[0], kpt[1], kpt[2], periodic_part ? 1 : 0, d_coords, ngrids, d_re, d_im,
+                     ld, plane_stride);
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

@@ -81,6 +81,7 @@ SIGNATURES = {
     'isdf_gemm_nn': (c_int, [c_vp, c_int, c_i64, c_int, c_dbl, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp, c_i64]),
     'isdf_hadamard_rows': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_i64]),
     'isdf_eval_ao_deriv1': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64]),
+    'isdf_eval_ao_k_deriv1': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64]),
     'isdf_uniform_grid': (c_int, [c_vp, c_vp, c_vp, c_vp]),
     'isdf_rho_pair': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_i64, c_i64, c_vp, c_int, c_vp, c_i64]),
     'isdf_mg_embed_density': (c_int, [c_vp, c_vp, c_int, c_vp, c_dbl, c_vp, c_vp, c_int]),

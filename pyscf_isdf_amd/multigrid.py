@@ -30,7 +30,7 @@ cache_xc_kernel1, multi_grids_tasks, multigrid_fftdf - the names of pyscf/pbc/df
 
 K is the ISDF exchange of the parent class (``MultiGridFFTDF(ISDF)``): hybrid functionals get J/XC from here and K from the
 interpolation, which is the pairing SURVEY section 8 f-3 names.  XC: the Slater exchange ('lda,') and Becke's 1988 exchange
-('b88,', a GGA; Gamma point) in closed form - libxc is not part of this tree; both are pinned by the reference's SCF energies.  k-points: the same two passes on the periodic parts u_k, real and imaginary planes stacked so that the complex
+('b88,', a GGA; Gamma point and k-points) in closed form - libxc is not part of this tree; both are pinned by the reference's SCF energies.  k-points: the same two passes on the periodic parts u_k, real and imaginary planes stacked so that the complex
 contractions are the Gamma point's real rectangular ones (get_j_kpts, nr_rks with kpts).
 """
 import copy
@@ -558,6 +558,95 @@ class MultiGridFFTDF(ISDF):
             del v
         return out
 
+    def _level_ao4_k(self, it, kpt):
+        """(4, 2 nT, G_t padded): values and derivatives of level ``it``'s functions at ``kpt`` (times exp(-i k.r)), every
+        component with the stacked rows (Re dense | Im dense | Re sparse | Im sparse) of _level_ao_k."""
+        lv, be, cell = self.tasks[it], self.backend, self.cell
+        nH, nL, nb = lv.nH, lv.nT - lv.nH, lv.nbas_h
+        buf = be.zeros((4, 2 * lv.nT, -(-lv.ngrids // 32) * 32))
+        coords_soa = be.uniform_grid(lv.mesh, cell.lattice_vectors())
+        atm = np.asarray(cell._atm)
+        be.eval_ao_k_deriv1(atm, lv.bas[:nb], lv.env, lv.Ls, lv.rcut[:nb], kpt, True, coords_soa, buf[:, :nH], buf[:, nH:2 * nH])
+        if nL:
+            be.eval_ao_k_deriv1(atm, lv.bas[nb:], lv.env, lv.Ls, lv.rcut[nb:], kpt, True, coords_soa,
+                                buf[:, 2 * nH:2 * nH + nL], buf[:, 2 * nH + nL:])
+        return buf
+
+    @staticmethod
+    def _stacked_dm(D, nH, nL):
+        """[[Re D', Im D'], [-Im D', Re D']] in the row / column order of the stacked planes, D' = D with its sparse columns
+        doubled; D (nset, nH, nH + nL) complex."""
+        D = D.copy()
+        D[:, :, nH:] *= 2.0
+        M = np.empty((D.shape[0], 2 * nH, 2 * (nH + nL)))
+        for r0, (P, Q) in ((0, (D.real, D.imag)), (nH, (-D.imag, D.real))):
+            M[:, r0:r0 + nH, 0:nH] = P[:, :, :nH]
+            M[:, r0:r0 + nH, nH:2 * nH] = Q[:, :, :nH]
+            M[:, r0:r0 + nH, 2 * nH:2 * nH + nL] = P[:, :, nH:]
+            M[:, r0:r0 + nH, 2 * nH + nL:] = Q[:, :, nH:]
+        return M
+
+    def _eval_rhoG_gga_k(self, dms, kpts):
+        """(4, nset, gc): spectra of rho and grad rho for Hermitian k-point matrices - _eval_rhoG_gga on the stacked planes."""
+        be, cell = self.backend, self.cell
+        self.build_tasks()
+        nset, nk = dms.shape[:2]
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        spec4 = be.zeros((4, nset, self._spectrum_size()), dtype=torch.complex128)
+        for it, lv in enumerate(self.tasks):
+            nH, nL = lv.nH, lv.nT - lv.nH
+            idx_t = np.append(lv.idx_h, lv.idx_l)
+            rho = be.empty((nset, lv.ngrids))
+            w = cell.vol / lv.ngrids / nk
+            for k in range(nk):
+                buf = self._level_ao4_k(it, kpts[k])
+                d_M = be.to_device(self._stacked_dm(dms[:, k][:, lv.idx_h[:, None], idx_t], nH, nL))
+                be.rho_pair(buf[0, :2 * nH], buf[0], lv.ngrids, d_M, rho)
+                be.mg_embed_density(rho, lv.mesh, w, spec4[0], mesh, accumulate=True)
+                for c in (1, 2, 3):
+                    be.rho_pair(buf[c, :2 * nH], buf[0], lv.ngrids, d_M, rho)
+                    be.mg_embed_density(rho, lv.mesh, w, spec4[c], mesh, accumulate=True)
+                    be.rho_pair(buf[0, :2 * nH], buf[c], lv.ngrids, d_M, rho)
+                    be.mg_embed_density(rho, lv.mesh, w, spec4[c], mesh, accumulate=True)
+                del buf
+        return spec4
+
+    def _integrate_gga_k(self, wspec4, kpts_band):
+        """(nset, nband, nao, nao) complex: conj(u_i) [v0 u_j + v_c d_c u_j] + conj(d_c u_i) v_c u_j, seven real products per level
+        and k-point on the stacked planes, combined once."""
+        be, cell = self.backend, self.cell
+        nao = cell.nao_nr()
+        nset = wspec4.shape[1]
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        out = np.zeros((nset, len(kpts_band), nao, nao), dtype=np.complex128)
+        for it, lv in enumerate(self.tasks):
+            nH, nL = lv.nH, lv.nT - lv.nH
+            v4 = be.empty((4, nset, lv.ngrids))
+            for c in range(4):
+                be.mg_restrict_potential(wspec4[c], mesh, lv.mesh, 1.0 / lv.ngrids, v4[c])
+            cre = np.r_[0:nH, 2 * nH:2 * nH + nL]
+            cim = np.r_[nH:2 * nH, 2 * nH + nL:2 * lv.nT]
+            for ib, kb in enumerate(kpts_band):
+                buf = self._level_ao4_k(it, kb)
+                R = be.empty((2 * nH, 2 * lv.nT))
+                vpad = be.zeros((buf.shape[2],))
+                for i in range(nset):
+                    vpad[:lv.ngrids].copy_(v4[0, i])
+                    be.gemm_nt(buf[0, :2 * nH], buf[0], R, kscale=vpad)
+                    for c in (1, 2, 3):
+                        vpad[:lv.ngrids].copy_(v4[c, i])
+                        be.gemm_nt(buf[0, :2 * nH], buf[c], R, beta=1.0, kscale=vpad)
+                        be.gemm_nt(buf[c, :2 * nH], buf[0], R, beta=1.0, kscale=vpad)
+                    Rh = be.to_host(R)
+                    V = (Rh[:nH][:, cre] + Rh[nH:][:, cim]) + 1j * (Rh[:nH][:, cim] - Rh[nH:][:, cre])
+                    out[i, ib][lv.idx_h[:, None], lv.idx_h] += V[:, :nH]
+                    if nL:
+                        out[i, ib][lv.idx_h[:, None], lv.idx_l] += V[:, nH:]
+                        out[i, ib][lv.idx_l[:, None], lv.idx_h] += V[:, nH:].conj().T
+                del buf, R, vpad
+            del v4
+        return out
+
     def _hermitian_parts(self, dms):
         """D = H + i A with H, A Hermitian: the density of D is rho(H) + i rho(A), both real (fft_jk.py:63-72 builds a complex
         density for hermi = 0; J is linear, so the two real densities go through the ladder one after the other)."""
@@ -662,9 +751,7 @@ def nr_rks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
     gamma = mydf._is_gamma(kpts) and mydf._is_gamma(kpts_band)
     nao = cell.nao_nr()
     if kind == 'b88':
-        if not gamma:
-            raise NotImplementedError("'b88,' through the ladder is implemented at the Gamma point")
-        return _nr_rks_gga(mydf, dm_kpts, with_j, return_j)
+        return _nr_rks_gga(mydf, dm_kpts, with_j, return_j, None if gamma else kpts, kpts_band)
     if gamma:
         shape, dms = mydf._real_dms(dm_kpts)
         spec = mydf._eval_rhoG(dms)
@@ -711,16 +798,30 @@ def nr_rks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
     return nelec, excsum, TaggedArray(veff, ecoul=ecoul, exc=excsum, vj=vj, vk=None)
 
 
-def _nr_rks_gga(mydf, dm, with_j, return_j):
-    """'b88,' at the Gamma point: rho and grad rho from the ladder (real-space gradients per level), the functional on the dense
-    mesh (isdf_gga_b88), the potential v_rho phi phi + (de/d grad rho) . grad(phi phi) back through the ladder."""
+def _nr_rks_gga(mydf, dm, with_j, return_j, kpts=None, kpts_band=None):
+    """'b88,': rho and grad rho from the ladder (real-space gradients per level), the functional on the dense mesh (isdf_gga_b88),
+    the potential v_rho phi phi + (de/d grad rho) . grad(phi phi) back through the ladder; Gamma point (kpts None) or k-points."""
     be, cell = mydf.backend, mydf.cell
-    shape, dms = mydf._real_dms(dm)
+    nao = cell.nao_nr()
+    if kpts is None:
+        shape, dms = mydf._real_dms(dm)
+        spec4 = mydf._eval_rhoG_gga(dms)
+        integrate_lda = lambda sp: mydf._integrate(sp).reshape(shape)            # noqa: E731
+        integrate_gga = lambda sp4: mydf._integrate_gga(sp4).reshape(shape)      # noqa: E731
+    else:
+        kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
+        dm_in = np.asarray(dm)
+        dms = np.asarray(dm_in, dtype=np.complex128).reshape(-1, len(kpts), nao, nao)
+        band_in = None if kpts_band is None else np.asarray(kpts_band, dtype=float)
+        band = kpts if band_in is None else band_in.reshape(-1, 3)
+        shape = dm_in.shape if band_in is None else (dm_in.shape[:-3] + ((len(band),) if band_in.ndim > 1 else ()) + (nao, nao))
+        spec4 = mydf._eval_rhoG_gga_k(0.5 * (dms + dms.conj().transpose(0, 1, 3, 2)), kpts)
+        integrate_lda = lambda sp: mydf._integrate_k(sp, band).reshape(shape)    # noqa: E731
+        integrate_gga = lambda sp4: mydf._integrate_gga_k(sp4, band).reshape(shape)   # noqa: E731
     nset = dms.shape[0]
     mesh = np.asarray(mydf.mesh, dtype=np.int32)
     G = int(np.prod(mesh))
     weight = cell.vol / G
-    spec4 = mydf._eval_rhoG_gga(dms)
     rho4 = be.empty((4, nset, G))
     for c in range(4):
         be.mg_restrict_potential(spec4[c], mesh, mesh, 1.0 / cell.vol, rho4[c])
@@ -738,14 +839,14 @@ def _nr_rks_gga(mydf, dm, with_j, return_j):
         excsum[i] = be.dot(rho4[0, i], exc[i]) * weight
         ecoul[i] = 0.5 * be.dot(rho4[0, i], vH[i]) * weight
     del exc, vH, rho4
-    vj = mydf._integrate(vHspec).reshape(shape) if return_j else None
+    vj = integrate_lda(vHspec) if return_j else None
     spec4.zero_()
     if with_j:
         spec4[0].copy_(vHspec)
     be.mg_embed_density(vrho, mesh, weight, spec4[0], mesh, accumulate=True)
     for c in range(3):
         be.mg_embed_density(w[c], mesh, weight, spec4[1 + c], mesh, accumulate=True)
-    veff = mydf._integrate_gga(spec4).reshape(shape)
+    veff = integrate_gga(spec4)
     if nset == 1:
         nelec, excsum, ecoul = nelec[0], excsum[0], ecoul[0]
     return nelec, excsum, TaggedArray(veff, ecoul=ecoul, exc=excsum, vj=vj, vk=None)

@@ -141,6 +141,15 @@ class OracleBackend:
         v = oao.eval_ao_deriv1(atm, bas, env, coords_soa.numpy().T, Ls, rcut)           # (4, G, nao)
         ao4[:, :, :v.shape[1]] = torch.from_numpy(np.ascontiguousarray(v.transpose(0, 2, 1)))
 
+    def eval_ao_k_deriv1(self, atm, bas, env, Ls, rcut, kpt, periodic_part, coords_soa, out_re, out_im):
+        c = coords_soa.numpy().T
+        v = np.asarray(oao.eval_ao_deriv1(atm, bas, env, c, Ls, rcut, kpt=np.asarray(kpt, dtype=float)), dtype=complex)   # (4, G, nao)
+        if periodic_part:
+            v = v * np.exp(-1j * c.dot(kpt))[None, :, None]
+        v = np.ascontiguousarray(v.transpose(0, 2, 1))
+        out_re[:, :, :len(c)] = torch.from_numpy(np.ascontiguousarray(v.real))
+        out_im[:, :, :len(c)] = torch.from_numpy(np.ascontiguousarray(v.imag))
+
     def gather_cols(self, src, idx, dst):
         dst[:, :idx.numel()] = src[:, idx]
 

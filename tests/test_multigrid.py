@@ -355,8 +355,6 @@ def _check_gga(df, cell, tol):
     eps = 1e-4
     fd = (pmg.nr_rks(df, 'b88,', dm + eps * d1)[1] - pmg.nr_rks(df, 'b88,', dm - eps * d1)[1]) / (2 * eps)
     assert abs(fd - np.einsum('ij,ji', vxc, d1)) < 1e-6 * max(1.0, abs(fd))
-    with pytest.raises(NotImplementedError):
-        pmg.nr_rks(df, 'b88,', np.stack([dm, dm]).astype(complex), kpts=np.array([[0.1, 0, 0], [-0.1, 0, 0]]))
 
 
 def test_product_gga_on_checker_backend():
@@ -441,13 +439,8 @@ def test_gpu_multigrid_pairs_with_isdf_k():
     assert abs(vj - vj0).max() < 1e-8 and abs(vk - vk0).max() < 1e-9
 
 
-def test_oracle_kpoint_b88_potential_reproduces_the_reference_constant():
-    """The reference's only stored constant for a multigrid XC POTENTIAL (test_multigrid.py:216-227): C2 in the cubic 3.5668 A cell,
-    gth-dzv / gth-pade, 48^3, two k-points k, -k and density matrices drawn after numpy.random.seed(2):
-    fp(vxc['b88,'] + vj) = -0.05697304864467462+0.6990367789096609j (places=7), computed there by KNumInt + FFTDF.  The oracle's
-    dense-grid k-point B88 quadrature + FFTDF J reproduce it: the closed-form Becke POTENTIAL (vrho, de/d grad rho) is pinned to
-    libxc's, and through the oracle comparisons (1e-9) so is the device's Gamma-point GGA potential."""
-    from oracle import pbc_tools as otools
+def reference_gga_kpts_case():
+    """Cell, k-points and density matrices of test_multigrid.py:28-67,216-227 (numpy.random.seed(2) sequence)."""
     np.random.seed(2)
     np.random.random((3, 3))                                   # the reference draws its non-orthogonal lattice first
     kpts = np.random.random((2, 3))
@@ -458,10 +451,58 @@ def test_oracle_kpoint_b88_potential_reproduces_the_reference_constant():
     cell = gto.Cell(a=np.eye(3) * 3.5668, atom='C 0 0 0; C 1.8 1.8 1.8', basis={'C': [b for b in dzvp._basis['C'] if b[0] < 2]},
                     pseudo='gth-pade', precision=1e-9, mesh=[48] * 3)
     nao = cell.nao_nr()
-    assert nao == 16
     dm = np.random.random((2, nao, nao)) * .2
     dm1 = dm + np.eye(nao)
-    dm = dm1 + dm1.transpose(0, 2, 1)
+    return cell, kpts, dm1 + dm1.transpose(0, 2, 1)
+
+
+def _check_gga_kpts(df, cell, kpts, dms, tol):
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    n, e, veff = pmg.nr_rks(df, 'b88,', dms, kpts=kpts, with_j=True)
+    tasks = as_tasks(df.tasks)
+    n0, e0, v0 = omg.nr_rks_b88_kpts(tasks, cell._atm, dms, a, mesh, kpts, with_j=True)
+    assert veff.shape == dms.shape and abs(n - n0) < tol * 100 and abs(e - e0) < tol * 100 and abs(veff - v0).max() < tol * 10
+    assert abs(veff - veff.conj().transpose(0, 2, 1)).max() < tol * 10
+    return veff
+
+
+def test_product_gga_kpts_on_checker_backend():
+    from oracle_backend import OracleBackend
+    cell = cell_he_split()
+    kpts, dms = make_kpts_dms(cell)
+    df = pmg.MultiGridFFTDF(cell, backend=OracleBackend())
+    df.split = 'all'
+    _check_gga_kpts(df, cell, kpts, dms, 1e-10)
+
+
+@pytest.mark.gpu
+def test_gpu_multigrid_gga_kpts_and_the_reference_constant():
+    """k-point 'b88,' on the device against the oracle on the same ladder (He cell with d functions, 1e-9), and the reference's own
+    case (test_multigrid.py:216-227): fp(nr_rks(..., with_j=True)) = -0.05697304864467462+0.6990367789096609j, which the reference
+    asserts to 7 places for its dense-grid answer and to 1e-7 between that and its multigrid."""
+    from oracle import pbc_tools as otools
+    cell = cell_he_split()
+    kpts, dms = make_kpts_dms(cell)
+    df = pmg.MultiGridFFTDF(cell)
+    df.split = 'all'
+    _check_gga_kpts(df, cell, kpts, dms, 1e-9)
+    cell, kpts, dms = reference_gga_kpts_case()
+    df = pmg.MultiGridFFTDF(cell)
+    df.split = 'all'
+    n, e, veff = pmg.nr_rks(df, 'b88,', dms, kpts=kpts, with_j=True)
+    assert len(df.tasks) > 1
+    assert abs(otools.fp(veff) - (-0.05697304864467462 + 0.6990367789096609j)) < 2e-7
+
+
+def test_oracle_kpoint_b88_potential_reproduces_the_reference_constant():
+    """The reference's only stored constant for a multigrid XC POTENTIAL (test_multigrid.py:216-227): C2 in the cubic 3.5668 A cell,
+    gth-dzv / gth-pade, 48^3, two k-points k, -k and density matrices drawn after numpy.random.seed(2):
+    fp(vxc['b88,'] + vj) = -0.05697304864467462+0.6990367789096609j (places=7), computed there by KNumInt + FFTDF.  The oracle's
+    dense-grid k-point B88 quadrature + FFTDF J reproduce it: the closed-form Becke POTENTIAL (vrho, de/d grad rho) is pinned to
+    libxc's, and through the oracle comparisons (1e-9) so is the device's Gamma-point GGA potential."""
+    from oracle import pbc_tools as otools
+    cell, kpts, dm = reference_gga_kpts_case()
+    assert cell.nao_nr() == 16
     a, mesh = cell.lattice_vectors(), cell.mesh
     rcut = gto.estimate_rcut_per_shell(cell)
     Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
