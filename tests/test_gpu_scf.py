@@ -95,7 +95,7 @@ def test_diamond_rhf_lda_and_b88_rks_total_energies_match_reference():
     assert abs(e_hf - (-10.137043711032916)) < 5e-8             # measured: 6.0e-9
 
 
-def test_diamond_krks_lda_total_energy_matches_reference():
+def test_diamond_krks_lda_and_b88_total_energies_match_reference():
     """KRKS 'lda,' on the same cell with a [2,1,1] k-mesh (pyscf/pbc/scf/test/test_newton.py:135-142): e_tot =
     -10.307756038726733 (places=8).  J + v_xc from the k-point form of the multigrid ladder (periodic parts on stacked planes),
     get_pp at the k-points from the device."""
@@ -115,6 +115,13 @@ def test_diamond_krks_lda_total_energy_matches_reference():
         return np.asarray(veff), float(veff.ecoul), float(exc)
     e_lda, dms = scf_helpers.krks(hcore, S, veff_lda, 4, e_nuc)
     assert abs(e_lda - (-10.307756038726733)) < 5e-8
+
+    # KRKS 'b88,' on the same mesh (test_newton.py:151-157): e_tot = -10.446717855794008, the k-point GGA ladder
+    def veff_b88(dms):
+        n, exc, veff = pmg.nr_rks(df, 'b88,', dms, kpts=kpts, with_j=True)
+        return np.asarray(veff), float(veff.ecoul), float(exc)
+    e_b88, dms = scf_helpers.krks(hcore, S, veff_b88, 4, e_nuc)
+    assert abs(e_b88 - (-10.446717855794008)) < 5e-8
     assert not df._built                                  # no ISDF fit was needed
 
 
