@@ -676,3 +676,53 @@ def nr_rks_b88_kpts(tasks, atm, dms, a, fft_mesh, kpts, with_j=False):
                 veff[k][idx_h[:, None], idx_l] += vp[:, nH:]
                 veff[k][idx_l[:, None], idx_h] += vp[:, nH:].conj().T
     return rhoR[0].sum() * weight, (rhoR[0] * exc).sum() * weight, veff
+
+
+def b88_spin_channel(rho_s, grad_s):
+    """One spin channel of Becke's exchange in its own variables: f(rho_s, grad rho_s) = rho_s^(4/3) G(x_s), and its derivatives
+    df/drho_s and df/d(grad rho_s) (no spin-scaling shortcut); rho_s <= 5e-15 -> 0."""
+    beta = 0.0042
+    cx = 1.5 * (3.0 / (4.0 * np.pi)) ** (1.0 / 3.0)
+    rho_s = np.asarray(rho_s, dtype=float)
+    m = rho_s > 5e-15
+    rs = np.where(m, rho_s, 1.0)
+    r13 = np.cbrt(rs)
+    r43 = rs * r13
+    x = np.sqrt((np.asarray(grad_s) ** 2).sum(axis=0)) / r43
+    a = np.arcsinh(x)
+    D = 1.0 + 6.0 * beta * x * a
+    Dp = 6.0 * beta * (a + x / np.sqrt(1.0 + x * x))
+    G = -cx - beta * x * x / D
+    Gp_x = -beta * (2.0 * D - x * Dp) / (D * D)
+    f = np.where(m, r43 * G, 0.0)
+    vrho = np.where(m, (4.0 / 3.0) * r13 * (G - x * x * Gp_x), 0.0)
+    w = np.where(m, Gp_x / r43, 0.0)[None] * np.asarray(grad_s)
+    return f, vrho, w
+
+
+def nr_uks_b88(tasks, atm, dms, a, fft_mesh, with_j=False):
+    """(nelec, exc, veff (2, nao, nao), ecoul) of an (alpha, beta) pair at the Gamma point, 'b88,' through the ladder
+    (multigrid.py:1152-1257, GGA branch; spin channels evaluated in their own variables)."""
+    a = np.asarray(a, dtype=float)
+    fft_mesh = np.asarray(fft_mesh)
+    ngrids = int(np.prod(fft_mesh))
+    vol = abs(np.linalg.det(a))
+    weight = vol / ngrids
+    nao = np.asarray(dms).shape[-1]
+    rhoG = [eval_rhoG_gga(tasks, atm, dms[s], a, fft_mesh) for s in range(2)]
+    coulG = tools.get_coulG(a, fft_mesh).reshape(rhoG[0].shape[1:])
+    tot = rhoG[0][0] + rhoG[1][0]
+    vG = tot * coulG
+    ecoul = (.5 * (tot.real * vG.real).sum() + .5 * (tot.imag * vG.imag).sum()) / vol
+    nelec = exc = 0.0
+    veff = []
+    for s in range(2):
+        rhoR = tools.ifft(rhoG[s].reshape(4, ngrids), fft_mesh).real / weight
+        f, vrho, w = b88_spin_channel(rhoR[0], rhoR[1:])
+        nelec += rhoR[0].sum() * weight
+        exc += f.sum() * weight
+        wvG = tools.fft(weight * np.vstack([vrho[None], w]), fft_mesh).reshape(rhoG[s].shape)
+        if with_j:
+            wvG[0] += vG
+        veff.append(integrate_gga(tasks, atm, wvG, a, fft_mesh, nao))
+    return nelec, exc, np.array(veff), ecoul

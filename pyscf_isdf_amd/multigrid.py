@@ -857,8 +857,10 @@ def nr_uks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
     k-points.  Returns (nelec [both spins together], exc, veff (2, ...)); Slater exchange by spin scaling,
     E_x[rho_a, rho_b] = (E_x[2 rho_a] + E_x[2 rho_b]) / 2, v_a = v_x[2 rho_a]; the Coulomb potential of with_j is that of the
     total density."""
-    if not _is_slater(xc_code):
-        raise NotImplementedError("xc=%r: only the Slater exchange ('lda,') is implemented (no libxc in this tree)" % (xc_code,))
+    kind = _xc_kind(xc_code)
+    if kind is None:
+        raise NotImplementedError("xc=%r: 'lda,' (Slater exchange) and 'b88,' (Becke-88 exchange) are implemented (no libxc in this "
+                                  "tree)" % (xc_code,))
     if kpts is None:
         kpts = mydf.kpts
     be, cell = mydf.backend, mydf.cell
@@ -867,6 +869,8 @@ def nr_uks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
     dm_in = np.asarray(dm_kpts)
     if dm_in.shape[0] != 2 or dm_in.ndim != (3 if gamma else 4):
         raise ValueError('nr_uks takes one pair (alpha, beta) of density matrices')
+    if kind == 'b88':
+        return _nr_uks_gga(mydf, dm_in, with_j, return_j, None if gamma else kpts, kpts_band)
     if gamma:
         shape, dms = mydf._real_dms(dm_in)
         spec = mydf._eval_rhoG(dms)
@@ -1062,6 +1066,60 @@ def cache_xc_kernel1(mydf, xc_code, dm, spin=0, kpts=None):
 
 def cache_xc_kernel(mydf, xc_code, mo_coeff, mo_occ, spin=0, kpts=None):
     raise NotImplementedError          # as the reference (multigrid.py:1454-1455)
+
+
+def _nr_uks_gga(mydf, dm_in, with_j, return_j, kpts, kpts_band):
+    """Open-shell 'b88,': exchange functionals obey E_x[rho_a, rho_b] = (E_x[2 rho_a] + E_x[2 rho_b]) / 2, so each spin channel is
+    the closed-shell kernel at (2 rho_s, 2 grad rho_s) - potentials come out as they are, energies halved."""
+    be, cell = mydf.backend, mydf.cell
+    nao = cell.nao_nr()
+    if kpts is None:
+        shape, dms = mydf._real_dms(dm_in)
+        spec4 = mydf._eval_rhoG_gga(dms)
+        integrate_lda = lambda sp: mydf._integrate(sp).reshape(shape)            # noqa: E731
+        integrate_gga = lambda sp4: mydf._integrate_gga(sp4).reshape(shape)      # noqa: E731
+    else:
+        kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
+        dms = np.asarray(dm_in, dtype=np.complex128)
+        band_in = None if kpts_band is None else np.asarray(kpts_band, dtype=float)
+        band = kpts if band_in is None else band_in.reshape(-1, 3)
+        shape = dm_in.shape if band_in is None else ((2,) + ((len(band),) if band_in.ndim > 1 else ()) + (nao, nao))
+        spec4 = mydf._eval_rhoG_gga_k(0.5 * (dms + dms.conj().transpose(0, 1, 3, 2)), kpts)
+        integrate_lda = lambda sp: mydf._integrate_k(sp, band).reshape(shape)    # noqa: E731
+        integrate_gga = lambda sp4: mydf._integrate_gga_k(sp4, band).reshape(shape)   # noqa: E731
+    mesh = np.asarray(mydf.mesh, dtype=np.int32)
+    G = int(np.prod(mesh))
+    weight = cell.vol / G
+    rho2 = be.empty((4, 2, G))                                               # 2 rho_s and 2 grad rho_s
+    for c in range(4):
+        be.mg_restrict_potential(spec4[c], mesh, mesh, 2.0 / cell.vol, rho2[c])
+    vHspec = spec4[0].clone()
+    be.mg_coulomb_kernel(vHspec, mesh, cell.lattice_vectors())
+    vH = be.empty((2, G))
+    be.mg_restrict_potential(vHspec, mesh, mesh, 1.0 / cell.vol, vH)
+    exc, vrho, w = be.empty((2, G)), be.empty((2, G)), be.empty((3, 2, G))
+    nelec = excsum = ecoul = 0.0
+    for sp in range(2):
+        be.gga_b88(rho2[0, sp], rho2[1:, sp], exc[sp], vrho[sp], w[:, sp])
+        nelec += 0.5 * be.dot(rho2[0, sp]) * weight
+        excsum += 0.5 * be.dot(rho2[0, sp], exc[sp]) * weight
+        ecoul += 0.25 * (be.dot(rho2[0, sp], vH[0]) + be.dot(rho2[0, sp], vH[1])) * weight
+    vj = None
+    if return_j:
+        vj2 = integrate_lda(vHspec)
+        vj = vj2[0] + vj2[1]
+    spec4.zero_()
+    be.mg_embed_density(vrho, mesh, weight, spec4[0], mesh, accumulate=True)
+    for c in range(3):
+        be.mg_embed_density(w[c], mesh, weight, spec4[1 + c], mesh, accumulate=True)
+    if with_j:
+        vtot = be.empty((2, G))
+        for sp in range(2):
+            vtot[sp].copy_(vH[1 - sp])
+        be.mg_embed_density(vH, mesh, weight, spec4[0], mesh, accumulate=True)
+        be.mg_embed_density(vtot, mesh, weight, spec4[0], mesh, accumulate=True)
+    veff = integrate_gga(spec4)
+    return nelec, excsum, TaggedArray(veff, ecoul=ecoul, exc=excsum, vj=vj, vk=None)
 
 
 def multigrid_fftdf(mf):

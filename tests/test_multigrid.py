@@ -349,6 +349,14 @@ def _check_gga(df, cell, tol):
     nd, ed, vd = omg.nr_rks_b88_dense(dense_ao4(cell), dm, a, mesh)
     vxc = pmg.nr_rks(df, 'B88,', dm)[2]
     assert abs(e - ed) < 1e-7 and abs(vxc - vd).max() < 1e-7 and abs(veff - vj - vxc).max() < 1e-9
+    # open shell: the spin-scaling route of the product against the oracle's spin channels in their own variables
+    pair = np.stack([dm * .6, make_dm(cell, seed=8) * .4])
+    nu, eu, vu = pmg.nr_uks(df, 'b88,', pair, with_j=True)
+    n0, e0, v0, ec0 = omg.nr_uks_b88(tasks, cell._atm, pair, a, mesh, with_j=True)
+    assert vu.shape == pair.shape and abs(nu - n0) < tol * 100 and abs(eu - e0) < tol * 100 and abs(vu - v0).max() < tol * 10
+    assert abs(vu.ecoul - ec0) < 1e-7
+    nu, eu, vu = pmg.nr_uks(df, 'b88,', np.stack([dm, dm]) * .5)
+    assert abs(nu - n) < 1e-9 and abs(eu - e) < 1e-9 and abs(vu[0] - vxc).max() < 1e-9 and abs(vu[1] - vxc).max() < 1e-9
     rng = np.random.default_rng(4)
     d1 = rng.standard_normal(dm.shape) * 0.05
     d1 = d1 + d1.T
