@@ -62,3 +62,13 @@ for frac, label in ((0.0, 'multigrid J, levels collocated in both passes'), (0.2
         print('      %-40s launches %4d  %8.2f ms' % (k, v['launches'], v['ms']))
     be.prof_enable(False)
     print('   max |J_multigrid - J_plain| = %.3e   (|J|max %.3f)' % (abs(vj - ref).max(), abs(ref).max()), flush=True)
+
+# J + XC in one pass pair (what an SCF iteration of a (hybrid) functional asks of this object; K = 0.05 s from the ISDF fit)
+df.ao_cache_fraction = 0.25
+df._level_cache = {}
+torch.cuda.empty_cache()
+for xc in ('lda,', 'b88,'):
+    out, t = timed(lambda: pmg.nr_rks(df, xc, dm, with_j=True), "nr_rks('%s', with_j=True): J + XC potential matrix" % xc)
+    print('   nelec %.8f  exc %.8f  ecoul %.8f' % (out[0], out[1], out[2].ecoul), flush=True)
+    df._level_cache = {}
+    torch.cuda.empty_cache()
