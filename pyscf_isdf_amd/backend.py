@@ -29,8 +29,8 @@ class HipBackend:
         self.handle = _lib.Handle(device)
         if os.environ.get('ISDF_TRSM') == 'subst':        # cross-check path (include/mi355_isdf.h)
             self.set_option('trsm_substitution', 1)
-        if os.environ.get('ISDF_OWN_FFT') == '0':         # A/B runs: hipFFT instead of fft_conv.hip
-            self.set_option('own_fft', 0)
+        if os.environ.get('ISDF_OWN_FFT') in ('0', '1', '2'):   # A/B runs: 0 hipFFT, 1 the five-pass own FFT, 2 the three-pass plane form
+            self.set_option('own_fft', int(os.environ['ISDF_OWN_FFT']))
         if os.environ.get('ISDF_GEMM_NN') == '1':         # A/B runs: own MFMA NN kernel for the pair-density rows instead of rocBLAS
             self.set_option('gemm_nn_own', 1)
 

@@ -456,6 +456,189 @@ __global__ __launch_bounds__(TPB) void strided_fft_fast_kernel(double2* __restri
   }
 }
 
+// ---- PLANE path: z and y transforms of one (y, z) plane fused in LDS: three passes instead of five ---------------------------
+// A workgroup of 1024 threads owns the plane of one (row, x): n1 real lines of n2 points = 115 KB at 120^3, the half-complex plane
+// n1 x (n2/2+1) = 117 KB - the whole of it stays in LDS between the z and the y transform, so the pair
+//   forward:  real plane -> z real-to-half-complex (two lines per complex transform) -> y forward -> complex plane
+//   inverse:  complex plane -> y inverse -> z half-complex-to-real -> real plane
+// reads and writes each plane ONCE (48 G bytes per row for the whole convolution with the fused x pass in between, against 80 G
+// for the five passes; algorithmic 32 G).  One workgroup per CU; stages as in the FAST path (in place, outputs held in
+// registers across a barrier), generalised to any number of lines and 1024 threads.  Layouts: z stage x[z][pair] with the pitch
+// chosen = 1 mod 16 (the real-plane load and the separation walk z fastest: a stride of 4 banks), y stage P[y][kz] with pitch
+// n2/2+1 = the global layout of the half spectrum.
+constexpr int TPBP = 1024;
+constexpr int PLANE_ENTRIES = 10240;             // complex numbers: the most a plane buffer may hold (160 KB of LDS)
+
+template <int SIGN, int R>
+__device__ inline void stage_plane(double2* __restrict__ buf, int N, int n_cur, int s, int Ls, int M,
+                                   const double2* __restrict__ tw) {
+  constexpr int KMAX = (PLANE_ENTRIES / TPBP + R - 1) / R;
+  const int mm = n_cur / R;
+  const int total = (N / R) * M;
+  const float inv_s = 1.0f / (float)s, inv_M = 1.0f / (float)M;
+  double2 out[KMAX][R];
+#pragma unroll
+  for (int u = 0; u < KMAX; ++u) {
+    const int i = threadIdx.x + u * TPBP;
+    if (i < total) {
+      const int bf = (int)(((float)i + 0.5f) * inv_M), m = i - bf * M;
+      const int p = (int)(((float)bf + 0.5f) * inv_s), q = bf - p * s;
+      const double2* xi = buf + (q + s * p) * Ls + m;
+      const int sin_ = s * mm * Ls;
+      double2 a[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) a[k] = xi[k * sin_];
+      butterfly_r<SIGN, R>(a, out[u]);
+      const int tstep = p * s;
+      int t = tstep;
+#pragma unroll
+      for (int j = 1; j < R; ++j) {
+        out[u][j] = cmul(out[u][j], twid<SIGN>(tw, t));
+        t += tstep;
+        if (t >= N) t -= N;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < KMAX; ++u) {
+    const int i = threadIdx.x + u * TPBP;
+    if (i < total) {
+      const int bf = (int)(((float)i + 0.5f) * inv_M), m = i - bf * M;
+      const int p = (int)(((float)bf + 0.5f) * inv_s), q = bf - p * s;
+      double2* yo = buf + (q + s * R * p) * Ls + m;
+      const int sout = s * Ls;
+#pragma unroll
+      for (int j = 0; j < R; ++j) yo[j * sout] = out[u][j];
+    }
+  }
+  __syncthreads();
+}
+
+template <int SIGN>
+__device__ inline void fft_plane(double2* buf, const Axis& ax, int Ls, int M, const double2* tw) {
+  int n_cur = ax.n, s = 1;
+  for (int st = 0; st < ax.nstage; ++st) {
+    const int r = ax.radix[st];
+    if (r == 4) stage_plane<SIGN, 4>(buf, ax.n, n_cur, s, Ls, M, tw);
+    else if (r == 2) stage_plane<SIGN, 2>(buf, ax.n, n_cur, s, Ls, M, tw);
+    else if (r == 3) stage_plane<SIGN, 3>(buf, ax.n, n_cur, s, Ls, M, tw);
+    else stage_plane<SIGN, 5>(buf, ax.n, n_cur, s, Ls, M, tw);
+    n_cur /= r;
+    s *= r;
+  }
+}
+
+// forward: in = real planes (n1 x n2 each, back to back), out = half-complex planes (n1 x n2h), y already transformed
+__global__ __launch_bounds__(TPBP) void plane_fwd_kernel(const double* __restrict__ in, double2* __restrict__ out, Axis az, Axis ay,
+                                                         int Lz, int bufsz) {
+  extern __shared__ double2 lds[];
+  const int n2 = az.n, n1 = ay.n, n2h = n2 / 2 + 1, npair = (n1 + 1) / 2;
+  double2* x = lds;
+  double2* twz = lds + bufsz;
+  double2* twy = twz + n2;
+  for (int k = threadIdx.x; k < n2; k += TPBP) twz[k] = az.tw[k];
+  for (int k = threadIdx.x; k < n1; k += TPBP) twy[k] = ay.tw[k];
+  const double* src = in + (int64_t)blockIdx.x * n1 * n2;
+  double2* dst = out + (int64_t)blockIdx.x * n1 * n2h;
+  if (n1 & 1)                                           // the last line has no partner: its imaginary slot is zero
+    for (int e = threadIdx.x; e < n2; e += TPBP) x[e * Lz + npair - 1].y = 0.0;
+  const float inv_n2 = 1.0f / (float)n2, inv_nh = 1.0f / (float)n2h;
+  for (int c = threadIdx.x; c < n1 * n2; c += TPBP) {
+    const int l = (int)(((float)c + 0.5f) * inv_n2), e = c - l * n2;
+    ((double*)(x + e * Lz + (l >> 1)))[l & 1] = src[c];
+  }
+  __syncthreads();
+  fft_plane<-1>(x, az, Lz, npair, twz);
+  // separate the line pairs, A_k = (Z_k + conj Z_{n-k}) / 2, B_k = (Z_k - conj Z_{n-k}) / 2i, and re-lay the plane as P[y][k]
+  constexpr int KS = PLANE_ENTRIES / TPBP;
+  double2 r[KS];
+#pragma unroll
+  for (int u = 0; u < KS; ++u) {
+    const int c = threadIdx.x + u * TPBP;
+    if (c < n1 * n2h) {
+      const int l = (int)(((float)c + 0.5f) * inv_nh), k = c - l * n2h;
+      const int m = l >> 1;
+      const double2 zk = x[k * Lz + m];
+      const double2 zn = x[(k == 0 ? 0 : n2 - k) * Lz + m];
+      if ((l & 1) == 0) r[u] = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
+      else r[u] = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < KS; ++u) {
+    const int c = threadIdx.x + u * TPBP;
+    if (c < n1 * n2h) x[c] = r[u];
+  }
+  __syncthreads();
+  fft_plane<-1>(x, ay, n2h, n2h, twy);
+  for (int c = threadIdx.x; c < n1 * n2h; c += TPBP) dst[c] = x[c];
+}
+
+// inverse: in = half-complex planes, out = real planes (unnormalised: the 1/N sits in the kernel table)
+__global__ __launch_bounds__(TPBP) void plane_inv_kernel(const double2* __restrict__ in, double* __restrict__ out, Axis az, Axis ay,
+                                                         int Lz, int bufsz) {
+  extern __shared__ double2 lds[];
+  const int n2 = az.n, n1 = ay.n, n2h = n2 / 2 + 1, npair = (n1 + 1) / 2;
+  double2* x = lds;
+  double2* twz = lds + bufsz;
+  double2* twy = twz + n2;
+  for (int k = threadIdx.x; k < n2; k += TPBP) twz[k] = az.tw[k];
+  for (int k = threadIdx.x; k < n1; k += TPBP) twy[k] = ay.tw[k];
+  const double2* src = in + (int64_t)blockIdx.x * n1 * n2h;
+  double* dst = out + (int64_t)blockIdx.x * n1 * n2;
+  for (int c = threadIdx.x; c < n1 * n2h; c += TPBP) x[c] = src[c];
+  __syncthreads();
+  fft_plane<1>(x, ay, n2h, n2h, twy);
+  // pairs of lines back into one complex line each: Z_k = A_k + i B_k, Z_{n-k} = conj(A_k) + i conj(B_k)
+  constexpr int KS = PLANE_ENTRIES / TPBP / 2 + 1;
+  const float inv_nh = 1.0f / (float)n2h, inv_n2 = 1.0f / (float)n2;
+  double2 za[KS], zb[KS];
+#pragma unroll
+  for (int u = 0; u < KS; ++u) {
+    const int c = threadIdx.x + u * TPBP;
+    if (c < npair * n2h) {
+      const int m = (int)(((float)c + 0.5f) * inv_nh), k = c - m * n2h;
+      double2 a = x[(2 * m) * n2h + k];
+      double2 b = (2 * m + 1 < n1) ? x[(2 * m + 1) * n2h + k] : make_double2(0.0, 0.0);
+      if (k == 0 || 2 * k == n2) { a.y = 0.0; b.y = 0.0; }
+      za[u] = make_double2(a.x - b.y, a.y + b.x);
+      zb[u] = make_double2(a.x + b.y, -a.y + b.x);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < KS; ++u) {
+    const int c = threadIdx.x + u * TPBP;
+    if (c < npair * n2h) {
+      const int m = (int)(((float)c + 0.5f) * inv_nh), k = c - m * n2h;
+      x[k * Lz + m] = za[u];
+      if (!(k == 0 || 2 * k == n2)) x[(n2 - k) * Lz + m] = zb[u];
+    }
+  }
+  __syncthreads();
+  fft_plane<1>(x, az, Lz, npair, twz);
+  for (int c = threadIdx.x; c < n1 * n2; c += TPBP) {
+    const int l = (int)(((float)c + 0.5f) * inv_n2), e = c - l * n2;
+    dst[c] = ((const double*)(x + e * Lz + (l >> 1)))[l & 1];
+  }
+}
+
+// plane path geometry: pitch of the z stage and LDS bytes, or 0 when the plane does not fit
+size_t plane_lds_bytes(int n1, int n2, int* Lz_out, int* bufsz_out) {
+  const int n2h = n2 / 2 + 1, npair = (n1 + 1) / 2;
+  int Lz = npair;
+  while (Lz % 16 != 1) ++Lz;
+  const int bufsz = std::max(n2 * Lz, n1 * n2h);
+  if (std::max(n2 * npair, n1 * n2h) > PLANE_ENTRIES || n1 * n2 > 2 * PLANE_ENTRIES) return 0;
+  const size_t bytes = sizeof(double2) * ((size_t)bufsz + n1 + n2);
+  if (bytes > 160 * 1024) return 0;
+  *Lz_out = Lz;
+  *bufsz_out = bufsz;
+  return bytes;
+}
+
 template <class F>
 void with_lines(int L, F f) {       // run f with the tile width as a compile-time constant
   switch (L) {
@@ -547,8 +730,32 @@ int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, cons
   const int ZY = lines_per_tile(n1, 0), ZX = lines_per_tile(n0, 0);
   if (LP < 1 || ZY < 1 || ZX < 1) return isdf_fail(h, ISDF_ERR_ARG, "conv_rows_own: mesh too large for the LDS tiles");
   const int64_t G = (int64_t)n0 * n1 * n2;
-  ProfScope ps(h, "coulomb_conv_own_5pass[byte]", 32.0 * (double)G * nb, 5);
   const int FZ = fast_lines(n2), FY = fast_lines(n1), FX = fast_lines(n0);
+  int Lz = 0, bufsz = 0;
+  const size_t plane_lds = (h->own_fft == 2 && smooth235(ax[0]) && smooth235(ax[1]) && smooth235(ax[2]) && FX >= 1)
+                               ? plane_lds_bytes(n1, n2, &Lz, &bufsz) : 0;
+  ProfScope ps(h, plane_lds ? "coulomb_conv_own_3pass[byte]" : "coulomb_conv_own_5pass[byte]", 32.0 * (double)G * nb,
+               plane_lds ? 3 : 5);
+  if (plane_lds) {
+    // PLANE path: (z, y) forward per plane, x forward . table . x inverse, (y, z) inverse per plane
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_TRY(h, hipFuncSetAttribute((const void*)plane_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(h, hipFuncSetAttribute((const void*)plane_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    const size_t ldsx = sizeof(double2) * ((size_t)n0 * FX + n0);
+    const int ntx = (int)cdiv((int64_t)n1 * n2h, FX);
+    const dim3 gp((unsigned)((int64_t)nb * n0)), gx((unsigned)((int64_t)nb * ntx));
+    hipStream_t st = h->stream;
+    plane_fwd_kernel<<<gp, dim3(TPBP), plane_lds, st>>>(d_in, zbuf, ax[2], ax[1], Lz, bufsz);
+    with_lines(FX, [&](auto z) {
+      strided_fft_fast_kernel<2, decltype(z)::value><<<gx, dim3(TPB), ldsx, st>>>(zbuf, gc, (int64_t)n1 * n2h, n1 * n2h, ax[0], ntx, cg);
+    });
+    plane_inv_kernel<<<gp, dim3(TPBP), plane_lds, st>>>(zbuf, d_out, ax[2], ax[1], Lz, bufsz);
+    KERNEL_CHECK(h);
+    return ISDF_OK;
+  }
   if (smooth235(ax[0]) && smooth235(ax[1]) && smooth235(ax[2]) && FZ >= 1 && FY >= 1 && FX >= 1) {
     const size_t ldsz = sizeof(double2) * ((size_t)n2 * (FZ + 1) + n2);
     const size_t ldsy = sizeof(double2) * ((size_t)n1 * FY + n1), ldsx = sizeof(double2) * ((size_t)n0 * FX + n0);

@@ -303,7 +303,8 @@ def test_coulomb_W(be, mk):
 
 
 @pytest.mark.parametrize('mesh,nrow', [((12, 12, 12), 5), ((21, 21, 21), 3), ((10, 9, 8), 37), ((11, 9, 7), 4), ((16, 20, 24), 7),
-                                       ((26, 14, 22), 2), ((5, 3, 2), 9), ((1, 4, 6), 3), ((17, 8, 8), 3), ((40, 40, 40), 33)])
+                                       ((26, 14, 22), 2), ((5, 3, 2), 9), ((1, 4, 6), 3), ((17, 8, 8), 3), ((40, 40, 40), 33),
+                                       ((6, 45, 50), 3), ((4, 27, 25), 5), ((3, 120, 120), 2), ((2, 128, 128), 1)])
 def test_own_fft_convolution_matches_oracle_and_hipfft(be, mesh, nrow):
     """S4 through the hand-written five-pass FFT (fft_conv.hip: radices 4/2/3/5 and the generic 7/11/13 butterflies, odd and
     even lengths, odd line counts, several tiles) against the oracle's complex FFT + .real on a triclinic lattice
@@ -315,13 +316,16 @@ def test_own_fft_convolution_matches_oracle_and_hipfft(be, mesh, nrow):
     rows = rng.standard_normal((nrow, G))
     ref = oisdf.coulomb_V(rows, a, np.asarray(mesh))
     out = {}
-    for own in (1, 0):
-        be.set_option('own_fft', own)
-        d = be.to_device(rows)
-        be.coulomb_rows(d, np.asarray(mesh), a, max(1, nrow // 2 + 1))          # two batches, the second one smaller
-        out[own] = be.to_host(d)
-    be.set_option('own_fft', 1)
+    try:
+        for own in (2, 1, 0):                        # 2: the three-pass plane form (2-3-5 smooth meshes that fit LDS), else as 1
+            be.set_option('own_fft', own)
+            d = be.to_device(rows)
+            be.coulomb_rows(d, np.asarray(mesh), a, max(1, nrow // 2 + 1))          # two batches, the second one smaller
+            out[own] = be.to_host(d)
+    finally:
+        be.set_option('own_fft', 1)
     scale = abs(ref).max()
+    assert abs(out[2] - ref).max() < 1e-12 * scale
     assert abs(out[1] - ref).max() < 1e-12 * scale
     assert abs(out[0] - ref).max() < 1e-12 * scale
     # out of place keeps the input
