@@ -54,10 +54,10 @@ int isdf_release_workspace(isdf_handle h);
 /* Runtime switches.  "trsm_substitution": 0 (default) the fit's triangular solves with Cholesky factors go through rocBLAS
  * dtrsm, 1 through the substitution blocks of trsm.hip (plain forward/backward substitution on 64-row diagonal blocks +
  * dgemm updates: slower, no inverted diagonal blocks; an independent cross-check of rocBLAS's algorithm).  Unknown keys are
- * an error.  "own_fft": 1 (default) the Coulomb convolution runs through the hand-written five-pass FFT (fft_conv.hip) on
- * meshes whose dimensions factor into 2, 3, 5, 7, 11, 13; 0 forces hipFFT (D2Z, kernel multiply, Z2D) everywhere; 2 selects the
- * three-pass form (z and y transforms of a whole (y, z) plane fused in LDS) on 2-3-5 smooth meshes whose plane fits 160 KB -
- * same time as the five passes, 0.6x the traffic (profiles/r02_conv_paths.log).
+ * an error.  "own_fft": 2 (default) the Coulomb convolution runs through the hand-written FFT (fft_conv.hip): on 2-3-5 smooth
+ * meshes whose (y, z) plane fits 160 KB of LDS in three passes (z and y transforms of a plane fused, x forward . kernel . x inverse
+ * fused), otherwise - dimensions that factor into 2, 3, 5, 7, 11, 13 - in five streaming passes; 1 forces the five passes; 0
+ * forces hipFFT (D2Z, kernel multiply, Z2D) everywhere (profiles/r02_conv_paths.log).
  * "gemm_nn_own": 0 (default) the pair-density rows phi_P^T phi go through rocBLAS dgemm (74 TF/s on that shape), 1 through the
  * hand-written MFMA NN kernel with the element-wise square in its epilogue (66-71 TF/s; profiles/r02_gemm_nn_vs_rocblas.log). */
 int isdf_set_option(isdf_handle h, const char* key, int value);

@@ -52,9 +52,9 @@ struct isdf_ctx {
   int num_cu = 256;
   // triangular solves of the fit: 0 = rocBLAS dtrsm (default, faster), 1 = substitution blocks of trsm.hip
   int trsm_substitution = 0;
-  // Coulomb convolution: 1 = the hand-written five-pass FFT of fft_conv.hip where the mesh allows (default), 0 = hipFFT,
-  // 2 = the three-pass plane form where the mesh allows (else as 1)
-  int own_fft = 1;
+  // Coulomb convolution: 2 = the hand-written FFT of fft_conv.hip in its three-pass plane form where the mesh allows, else its
+  // five-pass form (default); 1 = always the five-pass form; 0 = hipFFT
+  int own_fft = 2;
   // pair-density rows aoP ao: 0 = rocBLAS dgemm (default: 74 TF/s on that shape), 1 = the own MFMA NN kernel of gemm_f64.hip with
   // the square fused into its epilogue (66-71 TF/s; kept as the library-free route and for A/B runs)
   int gemm_nn_own = 0;

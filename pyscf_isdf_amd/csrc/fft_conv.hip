@@ -30,6 +30,7 @@
 // Reference semantics: pyscf/pbc/tools/pbc.py:149-211 (fft unscaled, ifft 1/N, C order over the mesh).
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -280,6 +281,49 @@ __device__ inline void butterfly_r(const double2* a, double2* b) {
   }
 }
 
+// Composite radices in registers: R = R1 R2 point DFT as R2 DFTs of length R1 (inputs R2 apart), the constant twiddles
+// W_R^(n2 k1) = tw[n2 k1 N / R] (R divides N, so the axis table holds them), then R1 DFTs of length R2; output index k1 + R1 k2.
+// A 120-point line is then two stages (15 x 8) instead of four (4 x 2 x 3 x 5): half the LDS round trips and barriers, which is
+// what bounds these passes.
+template <int SIGN, int R1, int R2>
+__device__ inline void butterfly_comp(const double2* a, double2* b, const double2* __restrict__ tw, int N) {
+  constexpr int R = R1 * R2;
+  double2 t[R2][R1];
+#pragma unroll
+  for (int n2 = 0; n2 < R2; ++n2) {
+    double2 u[R1];
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) u[n1] = a[R2 * n1 + n2];
+    butterfly_r<SIGN, R1>(u, t[n2]);
+  }
+  const int step = N / R;
+#pragma unroll
+  for (int n2 = 1; n2 < R2; ++n2)
+#pragma unroll
+    for (int k1 = 1; k1 < R1; ++k1) t[n2][k1] = cmul(t[n2][k1], twid<SIGN>(tw, n2 * k1 * step));
+#pragma unroll
+  for (int k1 = 0; k1 < R1; ++k1) {
+    double2 v[R2], w[R2];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) v[n2] = t[n2][k1];
+    butterfly_r<SIGN, R2>(v, w);
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) b[k1 + R1 * k2] = w[k2];
+  }
+}
+
+template <int SIGN, int R>
+__device__ inline void butterfly_any(const double2* a, double2* b, const double2* __restrict__ tw, int N) {
+  if (R <= 5) butterfly_r<SIGN, (R <= 5 ? R : 2)>(a, b);
+  else if (R == 6) butterfly_comp<SIGN, 3, 2>(a, b, tw, N);
+  else if (R == 8) butterfly_comp<SIGN, 4, 2>(a, b, tw, N);
+  else if (R == 9) butterfly_comp<SIGN, 3, 3>(a, b, tw, N);
+  else if (R == 10) butterfly_comp<SIGN, 5, 2>(a, b, tw, N);
+  else if (R == 12) butterfly_comp<SIGN, 4, 3>(a, b, tw, N);
+  else if (R == 15) butterfly_comp<SIGN, 5, 3>(a, b, tw, N);
+  else butterfly_comp<SIGN, 4, 4>(a, b, tw, N);        // 16
+}
+
 template <int SIGN, int R, int ZCT>
 __device__ inline void stage_inplace(double2* __restrict__ buf, int N, int n_cur, int s, int Ls,
                                      const double2* __restrict__ tw) {
@@ -299,7 +343,7 @@ __device__ inline void stage_inplace(double2* __restrict__ buf, int N, int n_cur
       double2 a[R];
 #pragma unroll
       for (int k = 0; k < R; ++k) a[k] = xi[k * sin_];
-      butterfly_r<SIGN, R>(a, out[u]);
+      butterfly_any<SIGN, R>(a, out[u], tw, N);
       const int tstep = p * s;           // < N
       int t = tstep;
 #pragma unroll
@@ -331,10 +375,19 @@ __device__ inline void fft_inplace(double2* buf, const Axis& ax, int Ls, const d
   int n_cur = ax.n, s = 1;
   for (int st = 0; st < ax.nstage; ++st) {
     const int r = ax.radix[st];
-    if (r == 4) stage_inplace<SIGN, 4, ZCT>(buf, ax.n, n_cur, s, Ls, tw);
-    else if (r == 2) stage_inplace<SIGN, 2, ZCT>(buf, ax.n, n_cur, s, Ls, tw);
-    else if (r == 3) stage_inplace<SIGN, 3, ZCT>(buf, ax.n, n_cur, s, Ls, tw);
-    else stage_inplace<SIGN, 5, ZCT>(buf, ax.n, n_cur, s, Ls, tw);
+    switch (r) {
+      case 16: stage_inplace<SIGN, 16, ZCT>(buf, ax.n, n_cur, s, Ls, tw); break;
+      case 15: stage_inplace<SIGN, 15, ZCT>(buf, ax.n, n_cur, s, Ls, tw); break;
+      case 12: stage_inplace<SIGN, 12, ZCT>(buf, ax.n, n_cur, s, Ls, tw); break;
+      case 10: stage_inplace<SIGN, 10, ZCT>(buf, ax.n, n_cur, s, Ls, tw); break;
+      case 9: stage_inplace<SIGN, 9, ZCT>(buf, ax.n, n_cur, s, Ls, tw); break;
+      case 8: stage_inplace<SIGN, 8, ZCT>(buf, ax.n, n_cur, s, Ls, tw); break;
+      case 6: stage_inplace<SIGN, 6, ZCT>(buf, ax.n, n_cur, s, Ls, tw); break;
+      case 5: stage_inplace<SIGN, 5, ZCT>(buf, ax.n, n_cur, s, Ls, tw); break;
+      case 4: stage_inplace<SIGN, 4, ZCT>(buf, ax.n, n_cur, s, Ls, tw); break;
+      case 3: stage_inplace<SIGN, 3, ZCT>(buf, ax.n, n_cur, s, Ls, tw); break;
+      default: stage_inplace<SIGN, 2, ZCT>(buf, ax.n, n_cur, s, Ls, tw); break;
+    }
     n_cur /= r;
     s *= r;
   }
@@ -488,7 +541,7 @@ __device__ inline void stage_plane(double2* __restrict__ buf, int N, int n_cur, 
       double2 a[R];
 #pragma unroll
       for (int k = 0; k < R; ++k) a[k] = xi[k * sin_];
-      butterfly_r<SIGN, R>(a, out[u]);
+      butterfly_any<SIGN, R>(a, out[u], tw, N);
       const int tstep = p * s;
       int t = tstep;
 #pragma unroll
@@ -520,10 +573,19 @@ __device__ inline void fft_plane(double2* buf, const Axis& ax, int Ls, int M, co
   int n_cur = ax.n, s = 1;
   for (int st = 0; st < ax.nstage; ++st) {
     const int r = ax.radix[st];
-    if (r == 4) stage_plane<SIGN, 4>(buf, ax.n, n_cur, s, Ls, M, tw);
-    else if (r == 2) stage_plane<SIGN, 2>(buf, ax.n, n_cur, s, Ls, M, tw);
-    else if (r == 3) stage_plane<SIGN, 3>(buf, ax.n, n_cur, s, Ls, M, tw);
-    else stage_plane<SIGN, 5>(buf, ax.n, n_cur, s, Ls, M, tw);
+    switch (r) {
+      case 16: stage_plane<SIGN, 16>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+      case 15: stage_plane<SIGN, 15>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+      case 12: stage_plane<SIGN, 12>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+      case 10: stage_plane<SIGN, 10>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+      case 9: stage_plane<SIGN, 9>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+      case 8: stage_plane<SIGN, 8>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+      case 6: stage_plane<SIGN, 6>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+      case 5: stage_plane<SIGN, 5>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+      case 4: stage_plane<SIGN, 4>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+      case 3: stage_plane<SIGN, 3>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+      default: stage_plane<SIGN, 2>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+    }
     n_cur /= r;
     s *= r;
   }
@@ -650,9 +712,11 @@ void with_lines(int L, F f) {       // run f with the tile width as a compile-ti
   }
 }
 
-bool smooth235(const Axis& ax) {
-  for (int i = 0; i < ax.nstage; ++i)
-    if (ax.radix[i] > 5) return false;
+bool smooth235(const Axis& ax) {          // every stage radix is one the register butterflies know (2-3-5 smooth length)
+  for (int i = 0; i < ax.nstage; ++i) {
+    const int r = ax.radix[i];
+    if (r == 7 || r == 11 || r == 13) return false;
+  }
   return true;
 }
 int fast_lines(int n) {          // largest power of two <= 16 with n * lines <= 2048
@@ -664,6 +728,41 @@ int fast_lines(int n) {          // largest power of two <= 16 with n * lines <=
 bool factorise(int n, Axis* ax) {
   ax->n = n;
   ax->nstage = 0;
+  {
+    // 2-3-5 smooth lengths (the FAST and PLANE paths): as few stages as the in-register radices up to 16 allow, the split with
+    // the smallest largest radix among the shortest ones (120 = 12 x 10, 108 = 12 x 9, 128 = 16 x 8, 96 = 12 x 8)
+    int m = n;
+    for (int p : {2, 3, 5})
+      while (m % p == 0) m /= p;
+    static const int big[] = {16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
+    static const bool big_radix = getenv("ISDF_FFT_BIG_RADIX") ? atoi(getenv("ISDF_FFT_BIG_RADIX")) != 0 : true;
+    if (m == 1 && n > 1 && big_radix) {
+      int best[MAXSTAGE], nbest = MAXSTAGE + 1, bestmax = 1 << 30;
+      int cur[MAXSTAGE];
+      // depth-first over non-increasing radix sequences (tiny search: n <= 1024)
+      struct Rec {
+        static void go(int rest, int maxr, int depth, int* cur, int* best, int& nbest, int& bestmax) {
+          if (rest == 1) {
+            const int mx = depth ? cur[0] : 1;
+            if (depth < nbest || (depth == nbest && mx < bestmax)) {
+              nbest = depth; bestmax = mx;
+              for (int i = 0; i < depth; ++i) best[i] = cur[i];
+            }
+            return;
+          }
+          if (depth + 1 > nbest || depth >= MAXSTAGE) return;
+          for (int r : big)
+            if (r <= maxr && rest % r == 0) { cur[depth] = r; go(rest / r, r, depth + 1, cur, best, nbest, bestmax); }
+        }
+      };
+      Rec::go(n, 16, 0, cur, best, nbest, bestmax);
+      if (nbest <= MAXSTAGE) {
+        ax->nstage = nbest;
+        for (int i = 0; i < nbest; ++i) ax->radix[i] = best[i];
+        return true;
+      }
+    }
+  }
   const int order[4] = {4, 2, 3, 5};
   for (int r : order)
     while (n % r == 0 && n > 1) {

@@ -323,7 +323,7 @@ def test_own_fft_convolution_matches_oracle_and_hipfft(be, mesh, nrow):
             be.coulomb_rows(d, np.asarray(mesh), a, max(1, nrow // 2 + 1))          # two batches, the second one smaller
             out[own] = be.to_host(d)
     finally:
-        be.set_option('own_fft', 1)
+        be.set_option('own_fft', 2)
     scale = abs(ref).max()
     assert abs(out[2] - ref).max() < 1e-12 * scale
     assert abs(out[1] - ref).max() < 1e-12 * scale

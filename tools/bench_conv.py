@@ -27,4 +27,4 @@ for mesh, nrow in (((120, 120, 120), 512), ((108, 108, 108), 512), ((128, 128, 1
         print('mesh %s rows %d own_fft %d: %.2f ms  %.2f TB/s algorithmic  (max rel diff vs hipFFT %.1e)' % (mesh, nrow, own, ms, 32.0 * G * nrow / ms / 1e9, err), flush=True)
     del rows, out, ref
     torch.cuda.empty_cache()
-be.set_option('own_fft', 1)
+be.set_option('own_fft', 2)
