@@ -311,6 +311,10 @@ class MultiGridFFTDF(ISDF):
     def build(self):
         self.build_tasks()
         if self._k_requested:
+            # the ISDF build sizes its fit buffers against the free HBM: hand the level collocations back first (they are
+            # re-made on demand and kept again only while they fit next to the fit)
+            self._level_cache = {}
+            self.backend.empty_cache()
             ISDF.build(self)
         return self
 
