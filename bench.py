@@ -234,6 +234,16 @@ def main():
         df.build()
         return df.get_jk(dm) if kpts is None else df.get_jk(dm, kpts=kpts)
 
+    # a progress line on stderr about once a minute: a long run (--steps 20) is otherwise silent for minutes, and a silent
+    # GPU command is taken for a hung one by the box's watchdog; stdout carries the one JSON line only
+    last_note = [time.perf_counter()]
+
+    def progress(what, i, n):
+        now = time.perf_counter()
+        if rank == 0 and now - last_note[0] > 45.0:
+            last_note[0] = now
+            print('[bench] %s step %d of %d done, %.0f s since start' % (what, i + 1, n, now - T_PROCESS_START), file=sys.stderr, flush=True)
+
     cold_first_step = None
     for i in range(args.warmup):
         torch.cuda.synchronize()
@@ -242,12 +252,14 @@ def main():
         torch.cuda.synchronize()
         if i == 0:
             cold_first_step = time.perf_counter() - tc     # allocations, FFT plans, rocBLAS kernel loading: what a one-shot caller pays
+        progress('warmup', i, args.warmup)
     be.prof_reset()
     be.prof_enable(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         vj, vk = step()
+        progress('timed', i, args.steps)
     barrier()
     t1 = time.perf_counter()
     be.prof_enable(False)
@@ -352,6 +364,7 @@ def main():
                     'north-star tolerance 1e-6 Eh: see DESIGN.md section 2 for the c / selection scan')
             if ta - T_PROCESS_START <= args.accuracy_budget_s:
                 _, c_mo, occ_mo = workloads.make_dm(cell)
+                print('[bench] exact exchange on the GPU for the accuracy entry (about 40 s)', file=sys.stderr, flush=True)
                 df.release_fit_buffers()                # the fit's buffers fill HBM; the exact exchange needs phi and its own batches
                 vk_ex = df.get_k_exact(mo_coeff=c_mo, mo_occ=occ_mo)
                 ek_ex = float(np.einsum('ij,ji', vk_ex, dm) / 4)
@@ -388,6 +401,7 @@ def main():
                 ncores = max(pools) if pools else 1
             except Exception:                      # noqa: BLE001 - threadpoolctl missing: report the host's cores
                 ncores = os.cpu_count() or 1
+            print('[bench] cpu_baseline sample on the host cores (about 30 s)', file=sys.stderr, flush=True)
             val, sample = cpu_baseline(cell, args.c_isdf, dict(P=P))
             out['cpu_baseline'] = {'value': round(val, 1), 'unit': 's', 'cores': ncores, 'kind': 'port',
                                    'sample': sample + '; host has %d logical CPUs' % (os.cpu_count() or 1)}
