@@ -73,6 +73,11 @@ int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out
 int get_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9], double extra_scale, double** out);
 // fft_conv.hip: d_out rows = ifft(cg * fft(d_in rows)) with the scaled half-spectrum table cg; zbuf nb * n0 n1 (n2/2+1) complex
 bool conv_rows_own_supported(const int32_t mesh[3]);
+// k-point form (fft_conv.hip): d_re + i d_im rows = ifft(tab * fft(d_in rows)) with a full real table; zhalf nb * n0 n1 (n2/2+1),
+// zfull nb * G complex scratch
+bool conv_rows_q_own_supported(isdf_handle h, const int32_t mesh[3]);
+int conv_rows_q_own(isdf_handle h, const double* d_in, double* d_re, double* d_im, int nb, const int32_t mesh[3], const double* tab,
+                    double2* zhalf, double2* zfull);
 int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, const int32_t mesh[3], const double* cg,
                   double2* zbuf);
 

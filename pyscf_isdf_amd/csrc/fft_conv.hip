@@ -687,6 +687,86 @@ __global__ __launch_bounds__(TPBP) void plane_inv_kernel(const double2* __restri
   }
 }
 
+// ---- k-point form: real rows in, COMPLEX rows out (the kernel table of q != 0 is not inversion symmetric, so the product
+// spectrum is not Hermitian).  Forward = the real-input half spectrum of the plane path + an x pass; then the half spectrum is
+// expanded to the full one under the table multiply; inverse = x pass + one fused (y, z) complex plane pass writing Re and Im.
+// full[b][kx][ky][kz] = tab[kx][ky][kz] * scale * F(kx, ky, kz),  F = half[...] for kz <= n2/2, conj(half[-kx, -ky, n2 - kz]) above
+__global__ void expand_mul_kernel(const double2* __restrict__ half, double2* __restrict__ full, const double* __restrict__ tab,
+                                  int n0, int n1, int n2, double scale) {
+  const int n2h = n2 / 2 + 1;
+  const int64_t G = (int64_t)n0 * n1 * n2, gc = (int64_t)n0 * n1 * n2h;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G) return;
+  const int kz = (int)(idx % n2), ky = (int)((idx / n2) % n1), kx = (int)(idx / ((int64_t)n2 * n1));
+  const double2* hb = half + (int64_t)blockIdx.y * gc;
+  double2 v;
+  if (kz < n2h) {
+    v = hb[((int64_t)kx * n1 + ky) * n2h + kz];
+  } else {
+    const int mx = kx ? n0 - kx : 0, my = ky ? n1 - ky : 0;
+    v = hb[((int64_t)mx * n1 + my) * n2h + (n2 - kz)];
+    v.y = -v.y;
+  }
+  const double c = tab[idx] * scale;
+  full[(int64_t)blockIdx.y * G + idx] = make_double2(c * v.x, c * v.y);
+}
+
+// inverse y and z transforms of one complex (y, z) plane in LDS, Re and Im written to separate real arrays
+__global__ __launch_bounds__(TPBP) void plane_c2c_inv_kernel(const double2* __restrict__ in, double* __restrict__ out_re,
+                                                             double* __restrict__ out_im, Axis az, Axis ay, int Lz, int bufsz) {
+  extern __shared__ double2 lds[];
+  const int n2 = az.n, n1 = ay.n;
+  double2* x = lds;
+  double2* twz = lds + bufsz;
+  double2* twy = twz + n2;
+  for (int k = threadIdx.x; k < n2; k += TPBP) twz[k] = az.tw[k];
+  for (int k = threadIdx.x; k < n1; k += TPBP) twy[k] = ay.tw[k];
+  const int64_t off = (int64_t)blockIdx.x * n1 * n2;
+  const double2* src = in + off;
+  for (int c = threadIdx.x; c < n1 * n2; c += TPBP) x[c] = src[c];            // P[y][z], pitch n2
+  __syncthreads();
+  fft_plane<1>(x, ay, n2, n2, twy);                                           // along y: element y, line z
+  // transpose to X[z][y] (pitch Lz) through registers so that z becomes the element index
+  constexpr int KS = PLANE_ENTRIES / TPBP;
+  const float inv_n2 = 1.0f / (float)n2;
+  double2 r[KS];
+#pragma unroll
+  for (int u = 0; u < KS; ++u) {
+    const int c = threadIdx.x + u * TPBP;
+    if (c < n1 * n2) r[u] = x[c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < KS; ++u) {
+    const int c = threadIdx.x + u * TPBP;
+    if (c < n1 * n2) {
+      const int y = (int)(((float)c + 0.5f) * inv_n2), z = c - y * n2;
+      x[z * Lz + y] = r[u];
+    }
+  }
+  __syncthreads();
+  fft_plane<1>(x, az, Lz, n1, twz);                                           // along z: element z, line y
+  for (int c = threadIdx.x; c < n1 * n2; c += TPBP) {
+    const int y = (int)(((float)c + 0.5f) * inv_n2), z = c - y * n2;
+    const double2 v = x[z * Lz + y];
+    out_re[off + c] = v.x;
+    out_im[off + c] = v.y;
+  }
+}
+
+// geometry of the complex plane pass: 0 when the plane does not fit
+size_t plane_c2c_lds_bytes(int n1, int n2, int* Lz_out, int* bufsz_out) {
+  if (n1 * n2 > PLANE_ENTRIES) return 0;
+  int Lz = n1;
+  while (Lz % 16 != 1) ++Lz;
+  const int bufsz = std::max(n2 * Lz, n1 * n2);
+  const size_t bytes = sizeof(double2) * ((size_t)bufsz + n1 + n2);
+  if (bytes > 160 * 1024) return 0;
+  *Lz_out = Lz;
+  *bufsz_out = bufsz;
+  return bytes;
+}
+
 // plane path geometry: pitch of the z stage and LDS bytes, or 0 when the plane does not fit
 size_t plane_lds_bytes(int n1, int n2, int* Lz_out, int* bufsz_out) {
   const int n2h = n2 / 2 + 1, npair = (n1 + 1) / 2;
@@ -910,6 +990,72 @@ int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, cons
     hipLaunchKernelGGL(z_c2r_kernel, dim3((unsigned)cdiv(nlines, 2 * LP)), dim3(TPB), lds, h->stream, zbuf, d_out, nlines,
                        ax[2], LP);
   }
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+// k-point convolution of real rows with a FULL real kernel table (n0, n1, n2; no 1/G inside): Vre + i Vim = ifft(tab fft(rows)).
+// zhalf: nb * n0 n1 (n2/2+1) complex scratch, zfull: nb * G complex scratch.  Supported: 2-3-5 smooth meshes whose real and
+// complex (y, z) planes fit LDS (up to ~100^2 per plane: the k-point configs of BASELINE.json); the caller falls back to hipFFT.
+bool conv_rows_q_own_supported(isdf_handle h, const int32_t mesh[3]) {
+  if (!h->own_fft) return false;
+  Axis ax[3];
+  for (int d = 0; d < 3; ++d)
+    if (mesh[d] < 2 || mesh[d] > 1024 || !factorise(mesh[d], &ax[d]) || !smooth235(ax[d])) return false;
+  int a = 0, b = 0;
+  return fast_lines(mesh[0]) >= 1 && plane_lds_bytes(mesh[1], mesh[2], &a, &b) && plane_c2c_lds_bytes(mesh[1], mesh[2], &a, &b);
+}
+
+int conv_rows_q_own(isdf_handle h, const double* d_in, double* d_re, double* d_im, int nb, const int32_t mesh[3],
+                    const double* tab, double2* zhalf, double2* zfull) {
+  const int n0 = mesh[0], n1 = mesh[1], n2 = mesh[2], n2h = n2 / 2 + 1;
+  Axis ax[3];
+  for (int d = 0; d < 3; ++d) {
+    if (!factorise(mesh[d], &ax[d])) return isdf_fail(h, ISDF_ERR_ARG, "conv_rows_q_own: unsupported mesh dimension %d", mesh[d]);
+    char name[32];
+    snprintf(name, sizeof(name), "fft_tw_%d", mesh[d]);
+    const bool fresh = h->ws.find(name) == h->ws.end();
+    double2* tw = (double2*)isdf_ws(h, name, sizeof(double2) * (size_t)mesh[d]);
+    if (!tw) return ISDF_ERR_HIP;
+    if (fresh) {
+      std::vector<double2> host(mesh[d]);
+      for (int k = 0; k < mesh[d]; ++k) {
+        const double t = -2.0 * 3.14159265358979323846 * (double)k / (double)mesh[d];
+        host[k] = make_double2(cos(t), sin(t));
+      }
+      HIP_TRY(h, hipMemcpyAsync(tw, host.data(), sizeof(double2) * (size_t)mesh[d], hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    ax[d].tw = tw;
+  }
+  const int64_t G = (int64_t)n0 * n1 * n2, gc = (int64_t)n0 * n1 * n2h;
+  int Lz = 0, bufsz = 0, Lc = 0, bufc = 0;
+  const size_t lds_r = plane_lds_bytes(n1, n2, &Lz, &bufsz), lds_c = plane_c2c_lds_bytes(n1, n2, &Lc, &bufc);
+  const int FX = fast_lines(n0);
+  ARG_CHECK(h, lds_r && lds_c && FX >= 1 && (int64_t)nb * n0 < 2147483647LL && nb <= 65535);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(h, hipFuncSetAttribute((const void*)plane_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)plane_c2c_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  // algorithmic bytes as the hipFFT form's label counts them: 8 G in, 16 G out per row and the table
+  ProfScope ps(h, "coulomb_conv_q_own[byte]", 64.0 * (double)G * nb, 5);
+  hipStream_t st = h->stream;
+  const size_t ldsx = sizeof(double2) * ((size_t)n0 * FX + n0);
+  const dim3 gp((unsigned)((int64_t)nb * n0));
+  plane_fwd_kernel<<<gp, dim3(TPBP), lds_r, st>>>(d_in, zhalf, ax[2], ax[1], Lz, bufsz);
+  const int ntx = (int)cdiv((int64_t)n1 * n2h, FX), ntf = (int)cdiv((int64_t)n1 * n2, FX);
+  with_lines(FX, [&](auto z) {
+    strided_fft_fast_kernel<0, decltype(z)::value><<<dim3((unsigned)((int64_t)nb * ntx)), dim3(TPB), ldsx, st>>>(
+        zhalf, gc, (int64_t)n1 * n2h, n1 * n2h, ax[0], ntx, (const double*)nullptr);
+  });
+  expand_mul_kernel<<<dim3((unsigned)cdiv(G, 256), (unsigned)nb), dim3(256), 0, st>>>(zhalf, zfull, tab, n0, n1, n2, 1.0 / (double)G);
+  with_lines(FX, [&](auto z) {
+    strided_fft_fast_kernel<1, decltype(z)::value><<<dim3((unsigned)((int64_t)nb * ntf)), dim3(TPB), ldsx, st>>>(
+        zfull, G, (int64_t)n1 * n2, n1 * n2, ax[0], ntf, (const double*)nullptr);
+  });
+  plane_c2c_inv_kernel<<<gp, dim3(TPBP), lds_c, st>>>(zfull, d_re, d_im, ax[2], ax[1], Lc, bufc);
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

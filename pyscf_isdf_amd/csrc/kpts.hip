@@ -145,10 +145,23 @@ extern "C" int isdf_coulomb_Wq(isdf_handle h, const double* d_theta, int P, int6
   double* Vre = (double*)isdf_ws(h, "coul_V", sizeof(double) * (size_t)batch * G);
   double* Vim = (double*)isdf_ws(h, "coul_Vim", sizeof(double) * (size_t)batch * G);
   if (!Z || !Vre || !Vim) return ISDF_ERR_HIP;
+  // own FFT (fft_conv.hip: real-input forward through the half spectrum, table-expanding multiply, complex inverse) where the
+  // mesh allows, hipFFT Z2Z otherwise
+  const bool own = conv_rows_q_own_supported(h, mesh);
+  double2* Zh = nullptr;
+  if (own) {
+    Zh = (double2*)isdf_ws(h, "coul_Z", sizeof(double2) * (size_t)batch * mesh[0] * mesh[1] * (mesh[2] / 2 + 1));
+    if (!Zh) return ISDF_ERR_HIP;
+  }
   for (int r = row0; r < row0 + nrows; r += batch) {
     const int nb = std::min(batch, row0 + nrows - r);
+    int rc = ISDF_OK;
+    if (own) {
+      rc = conv_rows_q_own(h, d_theta + (int64_t)r * ldt, Vre, Vim, nb, mesh, d_coulG, Zh, Z);
+      if (rc) return rc;
+    } else {
     hipfftHandle plan;
-    int rc = get_z2z_plan(h, mesh, nb, &plan);
+    rc = get_z2z_plan(h, mesh, nb, &plan);
     if (rc) return rc;
     const int64_t total = (int64_t)nb * G;
     const unsigned nblocks = (unsigned)std::min<int64_t>(cdiv(total, 256), (int64_t)h->num_cu * 16);
@@ -161,6 +174,7 @@ extern "C" int isdf_coulomb_Wq(isdf_handle h, const double* d_theta, int P, int6
       FFT_TRY(h, hipfftExecZ2Z(plan, (hipfftDoubleComplex*)Z, (hipfftDoubleComplex*)Z, HIPFFT_BACKWARD));
       hipLaunchKernelGGL(unpack_complex_kernel, dim3(nblocks), dim3(256), 0, h->stream, Z, Vre, Vim, total);
       KERNEL_CHECK(h);
+    }
     }
     const int c0 = upper_only ? r : 0;
     rc = gemm_nt_f64(h, nb, P - c0, G, weight, Vre, G, d_theta + (int64_t)c0 * ldt, ldt, 0.0,

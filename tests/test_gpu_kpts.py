@@ -157,6 +157,32 @@ def test_coulomb_Wq(be):
         assert abs(be.to_host(Wc) - ref).max() < 1e-10 * abs(ref).max()
 
 
+@pytest.mark.parametrize('mesh', [(12, 10, 9), (16, 15, 20), (6, 45, 50), (5, 96, 96), (8, 27, 25), (9, 7, 8)])
+def test_coulomb_Wq_own_fft_matches_hipfft_and_numpy(be, mesh):
+    """isdf_coulomb_Wq through the own k-point FFT (real-input forward through the half spectrum, table-expanding multiply,
+    complex (y, z) plane inverse) against hipFFT Z2Z (own_fft = 0) and against numpy, for a kernel table WITHOUT inversion
+    symmetry (what q != 0 gives); (9, 7, 8) has a factor 7 and takes the hipFFT form either way."""
+    rng = np.random.default_rng(sum(mesh))
+    G = int(np.prod(mesh))
+    P = 11
+    theta = rng.standard_normal((P, G))
+    tab = rng.random(G) + 0.1
+    w = 0.37
+    V = np.fft.ifftn(np.fft.fftn(theta.reshape(P, *mesh), axes=(1, 2, 3)) * tab.reshape(mesh), axes=(1, 2, 3)).reshape(P, G)
+    ref = w * V.dot(theta.T)
+    out = {}
+    try:
+        for own in (2, 0):
+            be.set_option('own_fft', own)
+            Wre = be.empty((P, P)); Wim = be.empty((P, P))
+            be.coulomb_Wq(be.to_device(theta), np.asarray(mesh), be.to_device(tab), w, 0, P, 4, Wre, Wim)
+            out[own] = be.to_host(Wre) + 1j * be.to_host(Wim)
+    finally:
+        be.set_option('own_fft', 2)
+    scale = abs(ref).max()
+    assert abs(out[2] - ref).max() < 1e-12 * scale and abs(out[0] - ref).max() < 1e-12 * scale
+
+
 @pytest.mark.parametrize('select', ['global', 'local', 'refined'])
 def test_isdf_kpts_end_to_end(select):
     """ISDF(cell, kpts).get_jk: J exact (vs the reference formula), K converging to the exact k-point
