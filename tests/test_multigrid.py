@@ -159,7 +159,7 @@ def _check_product_against_oracle(df, cell, tol):
     return vj, dms
 
 
-@pytest.mark.parametrize('mk', [cell_he_split, cell_c2_nonorth])
+@pytest.mark.parametrize('mk', [cell_he_split, cell_he])
 def test_product_orchestration_on_checker_backend(mk):
     """pyscf_isdf_amd.multigrid end to end on tests/oracle_backend.py (half spectra by numpy rfftn) against the full-spectrum
     oracle on the same ladder, and the FFTDF J."""
