@@ -248,6 +248,22 @@ int isdf_pair_rows_block_apply(isdf_handle h, const double* d_aoP, int P, int na
                                int64_t ld, const double* d_Dinv, int64_t ldd, int nblk, const int32_t* blk_off,
                                double* d_B, int64_t ldb);
 
+/* The (AO x occupied orbital) pair space: what the reference's K works on when the density matrix carries its orbitals
+ * (mo_coeff / mo_occ tag, pyscf/pbc/df/fft_jk.py:206-210,235-238: pair densities phi_mu psi_i, N x N_occ of them instead of
+ * N(N+1)/2).  With psi (nocc, ng) = C_occ^T phi on the grid and psiP (P, nocc) its values at the points, the Gram matrix of
+ * the pair products is the element-wise PRODUCT of two Gram matrices where isdf_gram_sq / isdf_pair_gram_rows have a square:
+ *   isdf_gram_prod       d_A (P, P)   = (aoP aoP^T) o (psiP psiP^T)
+ *   isdf_pair_prod_rows  d_B (P, ldb) = (aoP ao) o (psiP psi) on ng grid columns (ld / ldpsi: leading dimensions of ao / psi)
+ *   isdf_factor_solve_half  X (P, n) <- L^-1 X (backward 0) | L^-T X (backward 1) for A = L L^T as stored by
+ *                        isdf_chol_inplace: the Cholesky fit route on rows the caller produced with isdf_pair_prod_rows.
+ * Selection (isdf_select_ip_gram on isdf_gram_prod of the candidates), block factors, W and K are the same calls as in the
+ * AO x AO pair space. */
+int isdf_gram_prod(isdf_handle h, const double* d_aoP, int P, int nao, const double* d_psiP, int nocc, double* d_A);
+int isdf_pair_prod_rows(isdf_handle h, const double* d_aoP, int P, int nao, const double* d_psiP, int nocc,
+                        const double* d_ao, int64_t ld, const double* d_psi, int64_t ldpsi, int64_t ng,
+                        double* d_B, int64_t ldb);
+int isdf_factor_solve_half(isdf_handle h, const double* d_fac, int P, int backward, double* d_X, int64_t n, int64_t ldx);
+
 /* d_A <- d_A + shift_rel * max(diag d_A) * I. */
 int isdf_shift_diag(isdf_handle h, double* d_A, int P, double shift_rel);
 int isdf_chol_inplace(isdf_handle h, double* d_A, int P, double shift_rel, double* d_scratch, double* reg_used);

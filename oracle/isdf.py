@@ -269,6 +269,56 @@ def theta_dense_from_blocks(blocks, G):
     return th
 
 
+# ---- (AO x occupied orbital) pair space --------------------------------------------------------------
+# The reference's K only ever forms the pair densities phi_mu psi_i of the OCCUPIED orbitals when the density matrix carries
+# them (pyscf/pbc/df/fft_jk.py:206-210: mo_coeff[:, mo_occ > 0] * sqrt(mo_occ); :235-238, :276-287).  Interpolating that pair
+# space instead of all AO pairs changes the Gram matrix from (phi^T phi)^2 to (phi^T phi) o (psi^T psi); points, fit, W and K
+# keep their formulas (K = phi_P^T [(phi_P D phi_P^T) o W] phi_P with D = sum_i psi_i psi_i^T).
+def occupied_on_grid(aoT, mo_coeff, mo_occ):
+    """psi (nocc, m) = (C[:, occ > 0] sqrt(occ))^T phi; several density matrices: stack their orbitals."""
+    occ = np.asarray(mo_occ, dtype=float)
+    c = np.asarray(mo_coeff, dtype=float)[:, occ > 0] * np.sqrt(occ[occ > 0])
+    return c.T.dot(aoT)
+
+
+def refine_selection_occ(aoT, psi, cand, k, tol=-1.0, tie_rtol=TIE_RTOL):
+    """refine_selection on the Gram matrix of the (AO x occupied) pair products restricted to the candidates."""
+    aoC, psC = aoT[:, cand], psi[:, cand]
+    piv, _ = pivoted_cholesky_gram(aoC.T.dot(aoC) * psC.T.dot(psC), k, tol=tol, tie_rtol=tie_rtol)
+    return np.asarray(cand)[piv]
+
+
+def fit_theta_occ_chol(aoT, psi, ip, reg_rel=0.0):
+    """Theta = [(aoP^T aoP) o (psiP^T psiP) + reg]^-1 [(aoP^T ao) o (psiP^T psi)]  (fit_theta_global_chol in the
+    (AO x occupied) pair space; include/mi355_isdf.h isdf_gram_prod / isdf_pair_prod_rows / isdf_factor_solve_half)."""
+    aoP, psP = aoT[:, ip], psi[:, ip]
+    A = aoP.T.dot(aoP) * psP.T.dot(psP)
+    if reg_rel > 0:
+        A = A + reg_rel * np.diag(A).max() * np.eye(len(ip))
+    B = aoP.T.dot(aoT) * psP.T.dot(psi)
+    return scipy.linalg.cho_solve(scipy.linalg.cho_factor(A), B)
+
+
+def build_W_blockjacobi_occ(aoT, psi, ip, blk_off, a, mesh, reg_rel=1e-12, block_shift=0.0):
+    """build_W_blockjacobi with the product Gram matrices of the (AO x occupied) pair space."""
+    aoP, psP = aoT[:, ip], psi[:, ip]
+    A = aoP.T.dot(aoP) * psP.T.dot(psP)
+    A = A + reg_rel * A.diagonal().max() * np.eye(len(ip))
+    B = aoP.T.dot(aoT) * psP.T.dot(psi)
+    P = len(ip)
+    D = np.zeros((P, P))
+    for b in range(len(blk_off) - 1):
+        s = slice(blk_off[b], blk_off[b + 1])
+        if s.stop > s.start:
+            D[s, s] = np.linalg.cholesky(A[s, s] + block_shift * A.diagonal().max() * np.eye(s.stop - s.start))
+    Yp = scipy.linalg.solve_triangular(D, B, lower=True)
+    Mp = build_W(Yp, a, mesh)
+    Ap = scipy.linalg.solve_triangular(D, scipy.linalg.solve_triangular(D, A, lower=True).T, lower=True).T
+    cf = scipy.linalg.cho_factor(Ap)
+    Wp = scipy.linalg.cho_solve(cf, scipy.linalg.cho_solve(cf, Mp).T).T
+    return scipy.linalg.solve_triangular(D, scipy.linalg.solve_triangular(D, Wp, lower=True, trans='T').T, lower=True, trans='T').T
+
+
 # ---- J / K -------------------------------------------------------------------------------------
 def get_j(aoT, dm, a, mesh, omega=None):
     """Exact J (FFTDF formula) in the (nao, G) layout."""

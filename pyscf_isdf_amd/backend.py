@@ -248,6 +248,27 @@ class HipBackend:
         self.handle.call('isdf_pair_gram_rows', self._p(aoP), aoP.shape[0], aoP.shape[1], int(nh), self._p(ao), int(ng),
                          ao.stride(0), self._p(B), B.stride(0))
 
+    # ---- (AO x occupied orbital) pair space: products of two Gram matrices instead of squares ----
+    def gram_prod(self, aoP, psiP, A):
+        """A (P, P) <- (aoP aoP^T) o (psiP psiP^T)."""
+        self._stream()
+        assert aoP.is_contiguous() and psiP.is_contiguous() and A.is_contiguous() and aoP.shape[0] == psiP.shape[0]
+        self.handle.call('isdf_gram_prod', self._p(aoP), aoP.shape[0], aoP.shape[1], self._p(psiP), psiP.shape[1], self._p(A))
+
+    def pair_prod_rows(self, aoP, psiP, ao, psi, ng, B):
+        """B (P, ng) <- (aoP ao) o (psiP psi)."""
+        self._stream()
+        assert aoP.is_contiguous() and psiP.is_contiguous() and aoP.shape[0] == psiP.shape[0]
+        assert ao.stride(1) == 1 and psi.stride(1) == 1 and B.stride(1) == 1
+        self.handle.call('isdf_pair_prod_rows', self._p(aoP), aoP.shape[0], aoP.shape[1], self._p(psiP), psiP.shape[1],
+                         self._p(ao), ao.stride(0), self._p(psi), psi.stride(0), int(ng), self._p(B), B.stride(0))
+
+    def factor_solve_half(self, fac, backward, X):
+        """X (P, n) <- L^-1 X (backward False) or L^-T X (backward True), A = L L^T (fac as stored by chol_inplace)."""
+        self._stream()
+        self.handle.call('isdf_factor_solve_half', self._p(fac), fac.shape[0], int(bool(backward)), self._p(X), X.shape[1],
+                         X.stride(0))
+
     def block_chol(self, A, blk_off, shift_rel, D):
         self._stream()
         blk_off = np.ascontiguousarray(blk_off, dtype=np.int32)

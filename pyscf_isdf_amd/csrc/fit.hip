@@ -566,6 +566,81 @@ extern "C" int isdf_bj_probe_rows(isdf_handle h, double* d_T, int n, const doubl
   return isdf_rows_combine(h, d_T, n, P, P, d_Yp, ng, ldy, d_F, ldf, 0);
 }
 
+// ---- (AO x occupied orbital) pair space ------------------------------------------------------------------------
+// The exchange of a density D = sum_i psi_i psi_i^T only needs the pair products phi_mu psi_i (the reduction the reference makes
+// with mo_coeff-tagged density matrices, pyscf/pbc/df/fft_jk.py:206-210,235-238).  Their Gram matrix is
+//   A(r, r') = (sum_mu phi_mu(r) phi_mu(r')) * (sum_i psi_i(r) psi_i(r'))
+// - the element-wise PRODUCT of two Gram matrices where the AO x AO pair space has the square of one.  Selection, fit, W and K
+// keep their formulas; only these two products change.
+namespace {
+// x (rows, ld) .*= y (rows, ldy) on `cols` columns
+__global__ void mul_rows_kernel(double* __restrict__ x, int64_t ld, const double* __restrict__ y, int64_t ldy, int64_t cols) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (c >= cols) return;
+  x[r * ld + c] *= y[r * ldy + c];
+}
+// columns per chunk of the second factor: its (P x chunk) scratch stays under 2 GiB
+inline int64_t prod_chunk(int P) {
+  int64_t ch = ((int64_t)1 << 28) / std::max(P, 1);
+  ch = std::max<int64_t>(1024, std::min<int64_t>(65536, ch));
+  return ch / 256 * 256;
+}
+}  // namespace
+
+extern "C" int isdf_gram_prod(isdf_handle h, const double* d_aoP, int P, int nao, const double* d_psiP, int nocc, double* d_A) {
+  // A (P, P) = (aoP aoP^T) o (psiP psiP^T)
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_aoP && d_psiP && d_A && P > 0 && P <= 65535 && nao > 0 && nocc > 0);
+  int rc = gemm_rm(h, 'N', 'T', P, P, nao, 1.0, d_aoP, nao, d_aoP, nao, 0.0, d_A, P);
+  if (rc) return rc;
+  const int64_t CH = prod_chunk(P);                          // rows of the second factor per pass
+  double* tmp = (double*)isdf_ws(h, "fit_tmpB", sizeof(double) * (size_t)P * CH);
+  if (!tmp) return ISDF_ERR_HIP;
+  for (int64_t r0 = 0; r0 < P; r0 += CH) {
+    const int64_t nr = std::min<int64_t>(CH, P - r0);
+    rc = gemm_rm(h, 'N', 'T', nr, P, nocc, 1.0, d_psiP + r0 * nocc, nocc, d_psiP, nocc, 0.0, tmp, P);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mul_rows_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)nr), dim3(256), 0, h->stream, d_A + r0 * P,
+                       (int64_t)P, tmp, (int64_t)P, (int64_t)P);
+  }
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_pair_prod_rows(isdf_handle h, const double* d_aoP, int P, int nao, const double* d_psiP, int nocc,
+                                   const double* d_ao, int64_t ld, const double* d_psi, int64_t ldpsi, int64_t ng,
+                                   double* d_B, int64_t ldb) {
+  // B (P, ng) = (aoP ao) o (psiP psi): the second product in column chunks through the library workspace
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_aoP && d_psiP && d_ao && d_psi && d_B && P > 0 && P <= 65535 && nao > 0 && nocc > 0 && ng > 0);
+  ARG_CHECK(h, ld >= ng && ldpsi >= ng && ldb >= ng);
+  int rc = product_rows(h, P, ng, nao, d_aoP, d_ao, ld, d_B, ldb, false);
+  if (rc) return rc;
+  const int64_t CH = prod_chunk(P);
+  double* tmp = (double*)isdf_ws(h, "fit_tmpB", sizeof(double) * (size_t)P * CH);
+  if (!tmp) return ISDF_ERR_HIP;
+  for (int64_t c0 = 0; c0 < ng; c0 += CH) {
+    const int64_t nc = std::min(CH, ng - c0);
+    rc = gemm_rm(h, 'N', 'N', P, nc, nocc, 1.0, d_psiP, nocc, d_psi + c0, ldpsi, 0.0, tmp, CH);
+    if (rc) return rc;
+    ProfScope ps(h, "mul_rows_kernel[byte]", 24.0 * (double)P * (double)nc);
+    hipLaunchKernelGGL(mul_rows_kernel, dim3((unsigned)cdiv(nc, 256), (unsigned)P), dim3(256), 0, h->stream, d_B + c0, ldb, tmp,
+                       CH, nc);
+  }
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_factor_solve_half(isdf_handle h, const double* d_fac, int P, int backward, double* d_X, int64_t n,
+                                      int64_t ldx) {
+  // X (P, n) row-major <- L^-1 X (backward 0) or L^-T X (backward 1), A = L L^T (d_fac as in isdf_factor_solve): the two halves
+  // of the Cholesky fit route for rows the caller produced itself (isdf_pair_prod_rows)
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_fac && d_X && P > 0 && n > 0 && ldx >= n && n < 2147483647LL && ldx < 2147483647LL);
+  return tri_left(h, backward != 0, P, n, d_fac, P, d_X, ldx);
+}
+
 extern "C" int isdf_gather_aoP(isdf_handle h, const double* d_ao, int nao, int64_t ld, const int64_t* d_ip, int P,
                                double* d_aoP) {
   if (!h) return ISDF_ERR_ARG;

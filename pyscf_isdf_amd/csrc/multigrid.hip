@@ -10,8 +10,8 @@
 //
 // Frequencies follow numpy.fft.fftfreq like the reference's index lists (multigrid.py:669-673): index i of an n-point axis
 // carries f = i for i < (n+1)/2, else i - n, and sits at index f (f >= 0) or N + f (f < 0) of the N-point dense axis.  Along
-// the halved axis only f >= 0 is stored on both meshes; an even level mesh's Nyquist plane (labelled -n/2 by fftfreq) goes
-// to +n/2 there, which gives the same real field after Z2D because a real field's Nyquist plane is Hermitian in-plane.
+// the halved axis only f >= 0 is stored on both meshes.  The Nyquist entries of an even level mesh need care (see nyq_info):
+// the reference keeps a non-Hermitian spectrum and the real part of the field; here the Hermitian equivalent is stored.
 #include "common.h"
 
 namespace {
@@ -21,6 +21,24 @@ constexpr int64_t RCHUNK = 32768;   // grid columns per pass of the density cont
 __device__ inline int dense_index(int i, int n, int N) {
   const int f = (i < (n + 1) / 2) ? i : i - n;
   return f >= 0 ? f : f + N;
+}
+
+// Nyquist entries of an even level mesh (index n/2 along an axis on which the dense mesh is finer - "proper" Nyquist below).
+// The reference places such an entry v at dense frequency -n/2 ONLY (fftfreq labels it so, multigrid.py:669-673), leaves +n/2
+// empty and takes .real of the transformed field at the end: the real field it keeps has the spectrum (R(f) + conj(R(-f)))/2,
+// i.e. v/2 at f_L and conj(v)/2 at -f_L for an entry whose frequency vector f_L has a proper Nyquist component (every other entry
+// meets its own Hermitian partner and keeps weight 1).  A half spectrum can only hold Hermitian fields, so that symmetrised
+// form is what is stored: weight 1/2, at f_L when its z component is stored (>= 0), else as the conjugate at -f_L; in a
+// self-conjugate z plane (z = 0, or the dense mesh's own Nyquist plane) both f_L and -f_L are stored and both are written.
+// The map stays injective: a +n/2 component is produced by these entries only.
+struct NyqInfo { bool pnx, pny, pnz, any; };
+__device__ inline NyqInfo nyq_info(int ix, int iy, int iz, int n0, int n1, int n2, int N0, int N1, int N2) {
+  NyqInfo q;
+  q.pnx = (n0 % 2 == 0) && ix == n0 / 2 && N0 > n0;
+  q.pny = (n1 % 2 == 0) && iy == n1 / 2 && N1 > n1;
+  q.pnz = (n2 % 2 == 0) && iz == n2 / 2 && N2 > n2;
+  q.any = q.pnx || q.pny || q.pnz;
+  return q;
 }
 
 // full[set][dense(ix,iy,iz)] (+)= scale * sub[set][ix,iy,iz]; the map is injective, so no two threads meet
@@ -33,15 +51,31 @@ __global__ void spectrum_embed_kernel(const double2* __restrict__ sub, int n0, i
   const int iz = (int)(idx % n2h);
   const int iy = (int)((idx / n2h) % n1);
   const int ix = (int)(idx / ((int64_t)n2h * n1));
-  const int64_t j = ((int64_t)dense_index(ix, n0, N0) * N1 + dense_index(iy, n1, N1)) * N2h + iz;
+  const NyqInfo q = nyq_info(ix, iy, iz, n0, n1, n2, N0, N1, N2);
+  const int jx = dense_index(ix, n0, N0), jy = dense_index(iy, n1, N1);
+  const int mx = (N0 - jx) % N0, my = (N1 - jy) % N1;                       // the dense indices of -fx, -fy
   const double2 v = sub[(int64_t)set * gc + idx];
-  double2* q = full + (int64_t)set * N0 * N1 * N2h + j;
-  if (accumulate) { q->x += scale * v.x; q->y += scale * v.y; }
-  else { q->x = scale * v.x; q->y = scale * v.y; }
+  const double w = q.any ? 0.5 * scale : scale;
+  double2* base = full + (int64_t)set * N0 * N1 * N2h;
+  auto put = [&](int tx, int ty, int tz, double re, double im) {
+    double2* p = base + ((int64_t)tx * N1 + ty) * N2h + tz;
+    if (accumulate) { p->x += re; p->y += im; }
+    else { p->x = re; p->y = im; }
+  };
+  if (q.pnz) {
+    put(mx, my, iz, w * v.x, -w * v.y);                                      // f_L has z = -n2/2: stored as the conjugate at -f_L
+  } else {
+    put(jx, jy, iz, w * v.x, w * v.y);
+    const bool self_z = iz == 0 || ((n2 % 2 == 0) && iz == n2 / 2);         // (the second case: N2 == n2 here)
+    if (q.any && self_z) put(mx, my, iz, w * v.x, -w * v.y);
+  }
 }
 
-__global__ void spectrum_restrict_kernel(const double2* __restrict__ full, int N0, int N1, int N2h, double2* __restrict__ sub,
-                                         int n0, int n1, int n2h, double scale) {
+// sub[set][ix,iy,iz] = scale * (the reference's level spectrum after its .real): for a Hermitian dense spectrum V that is
+// V(f_L) for ordinary entries and (V(f_L) + V(f_L with its proper Nyquist components flipped to +n/2)) / 2 for Nyquist entries
+// (multigrid.py:905-915 picks the fftfreq entries and keeps the real part of the level field)
+__global__ void spectrum_restrict_kernel(const double2* __restrict__ full, int N0, int N1, int N2h, int N2, double2* __restrict__ sub,
+                                         int n0, int n1, int n2h, int n2, double scale) {
   const int64_t gc = (int64_t)n0 * n1 * n2h;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= gc) return;
@@ -49,9 +83,25 @@ __global__ void spectrum_restrict_kernel(const double2* __restrict__ full, int N
   const int iz = (int)(idx % n2h);
   const int iy = (int)((idx / n2h) % n1);
   const int ix = (int)(idx / ((int64_t)n2h * n1));
-  const int64_t j = ((int64_t)dense_index(ix, n0, N0) * N1 + dense_index(iy, n1, N1)) * N2h + iz;
-  const double2 v = full[(int64_t)set * N0 * N1 * N2h + j];
-  sub[(int64_t)set * gc + idx] = make_double2(scale * v.x, scale * v.y);
+  const NyqInfo q = nyq_info(ix, iy, iz, n0, n1, n2, N0, N1, N2);
+  const int jx = dense_index(ix, n0, N0), jy = dense_index(iy, n1, N1);
+  const double2* base = full + (int64_t)set * N0 * N1 * N2h;
+  auto get = [&](int tx, int ty, int tz) { return base[((int64_t)tx * N1 + ty) * N2h + tz]; };
+  double2 r;
+  if (!q.any) {
+    r = get(jx, jy, iz);
+  } else {
+    const int fx = q.pnx ? n0 / 2 : jx, fy = q.pny ? n1 / 2 : jy;            // flipped components: +n/2
+    double2 a, b = get(fx, fy, iz);                                          // (flipped z = +n2/2 = iz when pnz)
+    if (q.pnz) {
+      a = get((N0 - jx) % N0, (N1 - jy) % N1, iz);                           // V(fx, fy, -n2/2) = conj V(-fx, -fy, +n2/2)
+      a.y = -a.y;
+    } else {
+      a = get(jx, jy, iz);
+    }
+    r = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
+  }
+  sub[(int64_t)set * gc + idx] = make_double2(scale * r.x, scale * r.y);
 }
 
 __global__ void spectrum_scale_kernel(double2* __restrict__ z, const double* __restrict__ table, int64_t gc) {
@@ -251,7 +301,7 @@ extern "C" int isdf_mg_restrict_potential(isdf_handle h, const double* d_spec, i
   const int64_t G = (int64_t)mesh_sub[0] * mesh_sub[1] * mesh_sub[2];
   ProfScope ps(h, "mg_restrict_z2d[byte]", (8.0 * G + 16.0 * gc * 3) * nset, 2);
   hipLaunchKernelGGL(spectrum_restrict_kernel, dim3((unsigned)cdiv(gc, 256), (unsigned)nset), dim3(256), 0, h->stream,
-                     (const double2*)d_spec, mesh[0], mesh[1], N2h, Z, mesh_sub[0], mesh_sub[1], n2h, scale);
+                     (const double2*)d_spec, mesh[0], mesh[1], N2h, mesh[2], Z, mesh_sub[0], mesh_sub[1], n2h, mesh_sub[2], scale);
   KERNEL_CHECK(h);
   FFT_TRY(h, hipfftExecZ2D(plan->bwd, (hipfftDoubleComplex*)Z, (hipfftDoubleReal*)d_field));
   return ISDF_OK;

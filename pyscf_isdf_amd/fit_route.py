@@ -12,7 +12,11 @@ class FitRouteMixin:
         P = aoP.shape[0]
         be.gather_aoP(ao, d_ip, aoP)
         A = self._buffer('factor', (P, P))
-        be.gram_sq(aoP, A, nh)
+        if getattr(self, '_psi', None) is not None and not nh:
+            be.gram_prod(aoP, self._psiP, A)             # (AO x occupied) pair space
+        else:
+            be.gram_sq(aoP, A, nh)
+        self._Dinv_key = None                            # the block factors are about to be rewritten (a refit in the same buffers)
         # the fit's regularisation goes onto A itself, before the block scaling: both routes then solve the same
         # (A + reg I) x = b and differ by rounding only; A' gets a further shift only if its factorisation fails
         be.shift_diag(A, self.reg_rel)
@@ -40,6 +44,13 @@ class FitRouteMixin:
         """out (P, ng) <- Y' = D^-1 (aoP ao)^2 on ng grid columns."""
         be = self.backend
         Dinv = self._block_inverse(Dblk, ip_off)
+        if getattr(self, '_psi', None) is not None and not nh:
+            be.pair_prod_rows(aoP, self._psiP, ao, self._psi, ng, out)      # (AO x occupied) pair space
+            if Dinv is not None:
+                be.block_apply(Dinv, ip_off, out)
+            else:
+                be.block_solve(Dblk, ip_off, 0, 0, out)
+            return
         if Dinv is not None and not nh:
             be.pair_rows_block_apply(aoP, ao, ng, Dinv, ip_off, out)        # the square rides the block apply's staging
             return
@@ -61,6 +72,10 @@ class FitRouteMixin:
         be = self.backend
         have = be.free_bytes() + sum(int(b.numel()) * 8 for k, b in self._bufs.items() if k in ('theta', 'W', 'factor', 'Dblk', 'Dinv', 'rows_scratch'))
         fixed = 4 * 8 * P * P + (3 << 30)
+        if getattr(self, 'pair_space', 'ao') == 'occ':
+            # occupied orbitals on the grid (nocc <= N/2 rows; the electron count is the usual case) + the product scratch
+            nocc = min(self.cell.nao_nr() // 2, int(getattr(self.cell, 'nelectron', 0)) // 2 + 8)
+            fixed += 8 * G * nocc + (2 << 30)
         single = (have - fixed - 24 * 128 * G) // (8 * G)
         panel = (have - fixed - 40 * 512 * G) // (8 * G)
         return max(0, int(single)), max(0, int(panel))
@@ -106,7 +121,13 @@ class FitRouteMixin:
         G = self.ao.shape[1]
         Dinv = self._block_inverse(st['Dblk'], ip_off)
         sub = (ip_off[i0:i1 + 1] - r0).astype(np.int32)
-        if Dinv is not None:
+        if getattr(self, '_psi', None) is not None:
+            be.pair_prod_rows(self.aoP[r0:r1], self._psiP[r0:r1], self.ao, self._psi, G, out)
+            if Dinv is not None:
+                be.block_apply(Dinv[r0:r1, r0:r1], sub, out)
+            else:
+                be.block_solve(st['Dblk'][r0:r1, r0:r1], sub, 0, 0, out)
+        elif Dinv is not None:
             be.pair_rows_block_apply(self.aoP[r0:r1], self.ao, G, Dinv[r0:r1, r0:r1], sub, out)
         else:
             be.pair_gram_rows(self.aoP[r0:r1], self.ao, G, out, 0)

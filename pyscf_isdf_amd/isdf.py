@@ -47,6 +47,13 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
                                           # 'refined': local candidates (refine_over x too many), then ONE pivoted Cholesky
                                           # restricted to the candidate set picks the final points
         self.refine_over = 2.0            # 'refined': candidates per atom = refine_over * c_isdf * nao_atom
+        self.pair_space = 'ao'            # 'ao': interpolate all AO pairs (the fit does not depend on the density: build once, any
+                                          # number of get_jk); 'occ': interpolate the (AO x occupied orbital) pairs of the density
+                                          # get_jk is called with (mo_coeff/mo_occ tag, fft_jk.py:206-210; untagged: eigenvectors of
+                                          # a positive semidefinite low-rank D) - build() stops after the candidate stage, the
+                                          # final pick, the fit and W are made in get_jk (Gamma point, select 'local'/'refined')
+        self.occ_refit = 'always'         # pair_space='occ': 'always' = refit whenever get_jk sees another occupied space;
+                                          # 'once' = keep the first fit until the next build()
         self.cand_ao_cutoff = None        # 'refined', Bohr: the CANDIDATE stage of an atom's block sees only the AOs of atoms
                                           # within this distance (minimum image); None: all AOs.  The final pick always uses all.
         self.tie_rtol = 1e-10
@@ -86,6 +93,9 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         self._built = False
         self._W_omega = {}               # range-separated W per omega (get_jk(omega=...)), valid until the next build
         self._fit_state = None
+        self._fit_pending = False        # pair_space='occ': candidates selected, the fit waits for a density
+        self._psi = self._psiP = None    # pair_space='occ': occupied orbitals on the grid (nocc, G) and at the points (P, nocc)
+        self._fit_dm = None              # the projector sum_i psi_i psi_i^T the current fit was made for (host, N x N)
         self._V = None                   # robust_k: V = conv(Theta) (P, G), in the fit buffer
         self._bufs = {}
         self._ovlp = None
@@ -147,7 +157,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         ao = self.ao
         self._drop_build_state()
         self.ao = ao
-        for name in ('theta', 'rows_scratch', 'W', 'factor', 'Dblk', 'Dinv', 'aoP'):
+        for name in ('theta', 'rows_scratch', 'W', 'factor', 'Dblk', 'Dinv', 'aoP', 'psi', 'psiP'):
             self._bufs.pop(name, None)
         self._Dinv = None
         self._Dinv_key = None
@@ -162,6 +172,12 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         every build path."""
         self.ao = self.aoP = self.W = self.ip = None
         self._fit_state = None
+        self._fit_pending = False
+        self._psi = self._psiP = None
+        self._fit_dm = None
+        self._sel = None
+        self._Dinv = None
+        self._Dinv_key = None
         self._kfit_state = None
         self._V = None
         self._Wq = None
@@ -177,7 +193,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         out = self.stdout
         out.write('\n******** %s ********\n' % self.__class__)
         out.write('mesh = %s (%d PWs)\n' % (self.mesh, np.prod(self.mesh)))
-        out.write('c_isdf = %s  select = %s  tie_rtol = %g\n' % (self.c_isdf, self.select, self.tie_rtol))
+        out.write('c_isdf = %s  select = %s  pair_space = %s  tie_rtol = %g\n' % (self.c_isdf, self.select, self.pair_space, self.tie_rtol))
         out.write('len(kpts) = %d\n' % len(self.kpts))
         return self
 
@@ -261,7 +277,11 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         t0 = self._tick('S1_eval_ao', t0)
 
         # S2 + S3 selection and fit
+        if self.pair_space not in ('ao', 'occ'):
+            raise ValueError("pair_space must be 'ao' or 'occ'")
         if self.select == 'global':
+            if self.pair_space == 'occ':
+                raise NotImplementedError("pair_space='occ' is implemented for select='local' and 'refined'")
             P = int(min(self.c_isdf * nao, G))
             theta = self._buffer('theta', (P, G))
             piv = be.empty((1, P), dtype=torch.int64)
@@ -285,92 +305,16 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             del tmp
             t0 = self._tick('S3_fit', t0)
         elif self.select in ('local', 'refined'):
-            owner = be.partition_by_atom(coords, cell.atom_coords(), a)
-            perm = np.argsort(owner, kind='stable').astype(np.int64)
-            counts = np.bincount(owner, minlength=cell.natm)
-            blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)
-            nip_final = np.minimum(self.nip_per_atom(), counts).astype(np.int32)
-            nip = nip_final
-            if self.select == 'refined':
-                nip = np.minimum(np.ceil(self.nip_per_atom() * float(self.refine_over)).astype(np.int64), counts).astype(np.int32)
-            kmax = int(nip.max())
-            t0 = self._tick('host_partition', t0)
-            d_perm = be.to_device(perm)
-            # the block-major copy of phi and the Cholesky rows are scratch that dies before the fit:
-            # they live inside the (P, G) fit buffer, which is not in use yet
-            Pmax = int(nip_final.sum())
-            # how many fit rows HBM can hold next to everything else: above that the rows are produced panel by panel
-            # (fit_route.FitRouteMixin._finish_W_paneled; block-Jacobi route only)
-            # (decided once per problem size: later builds find the persistent buffers already allocated)
-            key = (Pmax, G, nao, self.max_resident_rows, self.fft_batch)
-            if getattr(self, '_rows_plan', (None,))[0] != key:
-                self._rows_plan = (key,) + self._resident_rows(G, Pmax)
-            rows_single, rows_panel = self._rows_plan[1:]
-            paneled = Pmax > rows_single and not self._want_theta and self.fit_route != 'cholesky'
-            rows_buf = max(min(Pmax, rows_panel) if paneled else Pmax, 2 * nao + kmax)
-            scratch = self._buffer('theta', (rows_buf, G))
-            ao_sel = scratch[:nao]
-            L = scratch[nao:nao + kmax]
-            be.gather_cols(self.ao, d_perm, ao_sel)
-            if self.select == 'refined' and self.cand_ao_cutoff:
-                ao_sel = self._local_ao_rows(ao_sel, scratch[nao + kmax:], blk_off, a)
-            piv = be.empty((cell.natm, kmax), dtype=torch.int64)
-            rank = be.select_ip(ao_sel, blk_off, nip, self.select_tol, self.tie_rtol, L, piv)
-            del ao_sel, L, scratch
-            piv_h = be.to_host(piv)
-            clusters = self._bj_clusters()
-            if self.select == 'refined':
-                t0 = self._tick('S2_select_candidates', t0)
-                rank = self._refine_selection(perm, blk_off, piv_h, rank, int(nip_final.sum()), owner)
-                ip = np.concatenate([self._refined_by_atom[b] for cl in clusters for b in cl])
-            else:
-                ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for cl in clusters for b in cl])
-            self.ip = ip.astype(np.int64)
-            P = len(ip)
-            t0 = self._tick('S2_select_ip', t0)
-            self.aoP = self._buffer('aoP', (P, nao))
-            d_ip = be.to_device(self.ip)
-            self.W = self._buffer('W', (P, P))
-            if paneled:
-                self._build_paneled(rank, clusters, d_ip, rows_buf, rows_panel, t0)
+            self._select_candidates(t0)
+            if self.pair_space == 'occ':
+                # the final pick, the fit and W need the occupied orbitals: made by get_jk (_ensure_fit)
+                self._fit_pending = True
                 self._built = True
                 return self
-            theta = self._buffer('theta', (rows_buf, G))[:P]
-            for route in self._fit_routes():
-                if route == 'blockjacobi':
-                    # S3c: no triangular solve over the grid.  theta <- Y' = D^-1 (aoP ao)^2
-                    ip_off = self._bj_blocks(rank, clusters)
-                    Afac, Dblk = self._bj_prepare(self.ao, 0, d_ip, ip_off, self.aoP, scratch=self.W)
-                    self._bj_rows(self.aoP, 0, self.ao, G, Dblk, ip_off, theta)
-                else:
-                    chol = self._buffer('factor', (P, P))
-                    self.reg_used = be.fit_prepare(self.ao, d_ip, self.reg_rel, self.aoP, chol)
-                    # forward solve only (Y = Lr^-1 B); the backward solve is applied to the (P, P) matrix below
-                    be.fit_apply(chol, self.aoP, self.ao, G, theta, forward_only=not self._want_theta)
-                t0 = self._tick('S3_fit', t0)
-                if route == 'blockjacobi':
-                    self._fit_state = dict(kind='blockjacobi', theta=theta, Afac=Afac, Dblk=Dblk, ip_off=ip_off)
-                else:
-                    self._fit_state = dict(kind='explicit' if self._want_theta else 'cholesky', theta=theta, chol=chol)
-                self._finish_W(self.W)
-                t0 = self._tick('S4S5_coulomb_W', t0)
-                self.fit_route_used = route
-                if route == 'blockjacobi' and self.fit_route == 'auto':
-                    aoT = be.empty((nao, P))
-                    be.gather_cols(self.ao, d_ip, aoT)
-                    self.bj_check = self._bj_probe_mismatch(aoT, Afac, Dblk, ip_off, theta, G, None)
-                    del aoT
-                    t0 = self._tick('S5_route_check', t0)
-                    if self.bj_check <= self.bj_check_tol:
-                        break
-                    warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e); '
-                                  'rebuilding W with the Cholesky route' % (self.bj_check, self.bj_check_tol))
-            self._keep_V_for_robust_k(t0)
-            del theta
-            self._built = True
+            self._pick_and_fit()
             return self
         else:
-            raise ValueError("select must be 'local' or 'global'")
+            raise ValueError("select must be 'local', 'refined' or 'global'")
 
         # S4 + S5 Coulomb convolution and W (global selection)
         self.W = self._buffer('W', (P, P))
@@ -383,6 +327,194 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         self._keep_V_for_robust_k(t0)
         self._built = True
         return self
+
+    def _select_candidates(self, t0):
+        """S2, first stage, for select='local' / 'refined': Voronoi partition of the grid by atoms and the per-atom
+        pivoted-Cholesky selections on the AO-pair Gram matrix (for 'refined': refine_over x too many points each, the
+        CANDIDATES).  Does not depend on the density; the result stays in self._sel for _pick_and_fit."""
+        cell, be = self.cell, self.backend
+        nao, G = self.ao.shape
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        owner = be.partition_by_atom(self.grids.coords, cell.atom_coords(), a)
+        perm = np.argsort(owner, kind='stable').astype(np.int64)
+        counts = np.bincount(owner, minlength=cell.natm)
+        blk_off = np.append(0, np.cumsum(counts)).astype(np.int64)
+        nip_final = np.minimum(self.nip_per_atom(), counts).astype(np.int32)
+        nip = nip_final
+        if self.select == 'refined':
+            nip = np.minimum(np.ceil(self.nip_per_atom() * float(self.refine_over)).astype(np.int64), counts).astype(np.int32)
+        kmax = int(nip.max())
+        t0 = self._tick('host_partition', t0)
+        d_perm = be.to_device(perm)
+        # the block-major copy of phi and the Cholesky rows are scratch that dies before the fit:
+        # they live inside the (P, G) fit buffer, which is not in use yet
+        Pmax = int(nip_final.sum())
+        # how many fit rows HBM can hold next to everything else: above that the rows are produced panel by panel
+        # (fit_route.FitRouteMixin._finish_W_paneled; block-Jacobi route only)
+        # (decided once per problem size: later builds find the persistent buffers already allocated)
+        key = (Pmax, G, nao, self.max_resident_rows, self.fft_batch, self.pair_space)
+        if getattr(self, '_rows_plan', (None,))[0] != key:
+            self._rows_plan = (key,) + self._resident_rows(G, Pmax)
+        rows_single, rows_panel = self._rows_plan[1:]
+        paneled = Pmax > rows_single and not self._want_theta and self.fit_route != 'cholesky'
+        rows_buf = max(min(Pmax, rows_panel) if paneled else Pmax, 2 * nao + kmax)
+        scratch = self._buffer('theta', (rows_buf, G))
+        ao_sel = scratch[:nao]
+        L = scratch[nao:nao + kmax]
+        be.gather_cols(self.ao, d_perm, ao_sel)
+        if self.select == 'refined' and self.cand_ao_cutoff:
+            ao_sel = self._local_ao_rows(ao_sel, scratch[nao + kmax:], blk_off, a)
+        piv = be.empty((cell.natm, kmax), dtype=torch.int64)
+        rank = be.select_ip(ao_sel, blk_off, nip, self.select_tol, self.tie_rtol, L, piv)
+        del ao_sel, L, scratch
+        piv_h = be.to_host(piv)
+        self._tick('S2_select_candidates' if self.select == 'refined' else 'S2_select_ip', t0)
+        self._sel = dict(owner=owner, perm=perm, blk_off=blk_off, nip_final=nip_final, piv_h=piv_h, rank=rank, paneled=paneled,
+                         rows_buf=rows_buf, rows_panel=rows_panel)
+
+    def _pick_and_fit(self, orbitals=None):
+        """S2 second stage + S3 + S4 + S5 from the candidates of _select_candidates: the final points ('refined': one pivoted
+        Cholesky of the candidates' Gram matrix), the fit (block-Jacobi / Cholesky route, paneled when the rows exceed HBM) and W.
+        orbitals: None = the AO x AO pair space; (N, nocc) occupied orbital coefficients (already scaled with sqrt(occ)) = the
+        (AO x occupied) pair space of that density (pair_space='occ')."""
+        cell, be, sel = self.cell, self.backend, self._sel
+        nao, G = self.ao.shape
+        t0 = time.perf_counter()
+        perm, blk_off, piv_h, rank, owner = sel['perm'], sel['blk_off'], sel['piv_h'], sel['rank'], sel['owner']
+        paneled, rows_buf, rows_panel = sel['paneled'], sel['rows_buf'], sel['rows_panel']
+        self._fit_state = None
+        self._W_omega = {}
+        self._V = None
+        self._psi = self._psiP = None
+        if orbitals is not None:
+            # psi = C_occ^T phi on the grid (fft_jk.py:235-238 forms the same rows, mo = ao C)
+            nocc = orbitals.shape[1]
+            self._psi = self._buffer('psi', (nocc, G))
+            be.gemm_nn(be.to_device(np.ascontiguousarray(orbitals.T)), self.ao, self._psi)
+            t0 = self._tick('S2_occupied_on_grid', t0)
+        clusters = self._bj_clusters()
+        if self.select == 'refined':
+            rank = self._refine_selection(perm, blk_off, piv_h, rank, int(sel['nip_final'].sum()), owner)
+            ip = np.concatenate([self._refined_by_atom[b] for cl in clusters for b in cl])
+        else:
+            ip = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for cl in clusters for b in cl])
+        self.ip = ip.astype(np.int64)
+        P = len(ip)
+        t0 = self._tick('S2_select_ip', t0)
+        self.aoP = self._buffer('aoP', (P, nao))
+        d_ip = be.to_device(self.ip)
+        if self._psi is not None:
+            self._psiP = self._buffer('psiP', (P, self._psi.shape[0]))
+            be.gather_aoP(self._psi, d_ip, self._psiP)
+        self.W = self._buffer('W', (P, P))
+        if paneled:
+            self._build_paneled(rank, clusters, d_ip, rows_buf, rows_panel, t0)
+            self._built = True
+            return self
+        theta = self._buffer('theta', (rows_buf, G))[:P]
+        for route in self._fit_routes():
+            if route == 'blockjacobi':
+                # S3c: no triangular solve over the grid.  theta <- Y' = D^-1 (aoP ao)^2
+                ip_off = self._bj_blocks(rank, clusters)
+                Afac, Dblk = self._bj_prepare(self.ao, 0, d_ip, ip_off, self.aoP, scratch=self.W)
+                self._bj_rows(self.aoP, 0, self.ao, G, Dblk, ip_off, theta)
+            else:
+                chol = self._buffer('factor', (P, P))
+                # forward solve only (Y = Lr^-1 B); the backward solve is applied to the (P, P) matrix below
+                self._chol_fit(d_ip, chol, theta, forward_only=not self._want_theta)
+            t0 = self._tick('S3_fit', t0)
+            if route == 'blockjacobi':
+                self._fit_state = dict(kind='blockjacobi', theta=theta, Afac=Afac, Dblk=Dblk, ip_off=ip_off)
+            else:
+                self._fit_state = dict(kind='explicit' if self._want_theta else 'cholesky', theta=theta, chol=chol)
+            self._finish_W(self.W)
+            t0 = self._tick('S4S5_coulomb_W', t0)
+            self.fit_route_used = route
+            if route == 'blockjacobi' and self.fit_route == 'auto':
+                aoT = be.empty((nao, P))
+                be.gather_cols(self.ao, d_ip, aoT)
+                self.bj_check = self._bj_probe_mismatch(aoT, Afac, Dblk, ip_off, theta, G, None)
+                del aoT
+                t0 = self._tick('S5_route_check', t0)
+                if self.bj_check <= self.bj_check_tol:
+                    break
+                warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e); '
+                              'rebuilding W with the Cholesky route' % (self.bj_check, self.bj_check_tol))
+        self._keep_V_for_robust_k(t0)
+        del theta
+        self._built = True
+        return self
+
+    def _chol_fit(self, d_ip, chol, theta, forward_only):
+        """S3b: chol <- Cholesky factor of the regularised Gram matrix of the points, theta <- Lr^-1 (rows) (and Lr^-T of that
+        unless forward_only), in the AO x AO or the (AO x occupied) pair space."""
+        be = self.backend
+        G = self.ao.shape[1]
+        if self._psi is None:
+            self.reg_used = be.fit_prepare(self.ao, d_ip, self.reg_rel, self.aoP, chol)
+            be.fit_apply(chol, self.aoP, self.ao, G, theta, forward_only=forward_only)
+            return
+        be.gather_aoP(self.ao, d_ip, self.aoP)
+        be.gram_prod(self.aoP, self._psiP, chol)
+        be.shift_diag(chol, self.reg_rel)
+        self.reg_used = self.reg_rel + be.chol_inplace(chol, 0.0, scratch=self.W)
+        be.pair_prod_rows(self.aoP, self._psiP, self.ao, self._psi, G, theta)
+        be.factor_solve_half(chol, False, theta)
+        if not forward_only:
+            be.factor_solve_half(chol, True, theta)
+
+    # ---- pair_space='occ': the fit follows the density ----------------------------------------------------------
+    def _occupied_orbitals(self, dm):
+        """(N, nocc) coefficients C_occ sqrt(occ) of the density get_jk was called with - from its mo_coeff / mo_occ tag
+        exactly as the reference's K does (pyscf/pbc/df/fft_jk.py:206-210), else from the eigenvectors of a symmetric positive
+        semidefinite D of rank <= N/2 (several density matrices: their orbitals side by side).  None when the density has no
+        such form (a difference or response density, full rank): the AO x AO pair space is used then."""
+        nao = self.cell.nao_nr()
+        mo_coeff, mo_occ = getattr(dm, 'mo_coeff', None), getattr(dm, 'mo_occ', None)
+        cols = []
+        if mo_coeff is not None and mo_occ is not None:
+            mo_coeff, mo_occ = np.asarray(mo_coeff), np.asarray(mo_occ)
+            if np.iscomplexobj(mo_coeff) and abs(mo_coeff.imag).max() > 1e-12:
+                return None
+            mo_coeff = mo_coeff.real.reshape(-1, nao, mo_coeff.shape[-1])
+            mo_occ = np.asarray(mo_occ, dtype=float).reshape(len(mo_coeff), -1)
+            for c, occ in zip(mo_coeff, mo_occ):
+                cols.append(c[:, occ > 0] * np.sqrt(occ[occ > 0]))
+        else:
+            dms = np.asarray(dm)
+            if np.iscomplexobj(dms):
+                if abs(dms.imag).max() > 1e-12:
+                    return None
+                dms = dms.real
+            for d in dms.reshape(-1, nao, nao):
+                if abs(d - d.T).max() > 1e-10 * max(abs(d).max(), 1e-300):
+                    return None
+                ev, u = np.linalg.eigh(0.5 * (d + d.T))
+                if ev.min() < -1e-10 * abs(ev).max():
+                    return None
+                keep = ev > 1e-12 * ev.max()
+                cols.append(u[:, keep] * np.sqrt(ev[keep]))
+        c = np.ascontiguousarray(np.hstack(cols), dtype=np.float64)
+        if c.shape[1] == 0 or c.shape[1] > nao // 2:
+            return None
+        return c
+
+    def _ensure_fit(self, dm=None):
+        """pair_space='occ': make the fit (final points, rows, W) for the density ``dm`` unless the current one was made for the
+        same occupied space (or occ_refit = 'once' and a fit exists).  dm = None or a density without occupied-orbital form:
+        the AO x AO pair space, once per build."""
+        if self.pair_space != 'occ' or self._sel is None or self.ao is None:
+            return
+        orb = None if dm is None else self._occupied_orbitals(dm)
+        if not self._fit_pending:
+            if orb is None or self.occ_refit == 'once' or self._fit_dm is None:
+                return
+            proj = orb.dot(orb.T)
+            if abs(proj - self._fit_dm).max() <= 1e-12 * abs(proj).max():
+                return
+        self._fit_dm = None if orb is None else orb.dot(orb.T)
+        self._pick_and_fit(orb)
+        self._fit_pending = False
 
     def _build_paneled(self, rank, clusters, d_ip, rows_buf, rows_panel, t0):
         """S3c + S4 + S5 with the fit rows produced panel by panel (more points than HBM holds rows for): block-Jacobi
@@ -446,17 +578,22 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         natm = self.cell.natm
         cand = np.concatenate([perm[blk_off[b] + piv_h[b, :rank[b]]] for b in range(natm)]).astype(np.int64)
         aoC = be.empty((len(cand), self.ao.shape[0]))
-        be.gather_aoP(self.ao, be.to_device(cand), aoC)
+        d_cand = be.to_device(cand)
+        be.gather_aoP(self.ao, d_cand, aoC)
+        psiC = None
+        if self._psi is not None:                 # (AO x occupied) pair space: the candidates' Gram matrix is a product
+            psiC = be.empty((len(cand), self._psi.shape[0]))
+            be.gather_aoP(self._psi, d_cand, psiC)
         # the candidate Gram matrix (17 GB at c = 14) lives in the fit-row buffer, which is not in use yet
         rows_buf = self._bufs.get('theta')
         gram = None if rows_buf is None or rows_buf.numel() < len(cand) ** 2 else rows_buf[:len(cand) ** 2].view(len(cand), len(cand))
-        chosen = self._refine_pick(aoC, cand, P_target, gram=gram)
-        del aoC, gram
+        chosen = self._refine_pick(aoC, cand, P_target, gram=gram, psiC=psiC)
+        del aoC, gram, psiC
         own = owner[chosen]
         self._refined_by_atom = [chosen[own == b] for b in range(natm)]
         return np.array([len(x) for x in self._refined_by_atom], dtype=np.int32)
 
-    def _refine_pick(self, aoC, cand, P_target, gram=None, nh=0):
+    def _refine_pick(self, aoC, cand, P_target, gram=None, nh=0, psiC=None):
         """One pivoted Cholesky of the pair-density Gram matrix restricted to the candidate set (aoC: AO values at the
         candidates, (m, nao); isdf_gram_sq + isdf_select_ip_gram, pivot rule pyscf/lib/scipy_helper.py:71-110) picks the
         final P_target points.  Returns their grid indices in pivot order."""
@@ -464,7 +601,10 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         m = len(cand)
         P_target = min(int(P_target), m)
         A = be.empty((m, m)) if gram is None else gram
-        be.gram_sq(aoC, A, nh)                      # nh > 0: k-point (complex) mode, aoC = [Re u | Im u] at the candidates
+        if psiC is not None:
+            be.gram_prod(aoC, psiC, A)
+        else:
+            be.gram_sq(aoC, A, nh)                  # nh > 0: k-point (complex) mode, aoC = [Re u | Im u] at the candidates
         piv2 = be.empty((P_target,), dtype=torch.int64)
         r2 = be.select_ip_gram(A, P_target, self.select_tol, self.tie_rtol, piv2)
         chosen = np.asarray(cand)[be.to_host(piv2)[:r2]]
@@ -628,6 +768,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             raise NotImplementedError('range-separated J/K with robust_k is not implemented')
         if not self._built:
             self.build()
+        if with_k and self.pair_space == 'occ':
+            self._ensure_fit(dm)
         key = round(float(omega), 10)
         be.set_coulomb_omega(omega)
         try:
@@ -669,6 +811,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             raise NotImplementedError("exxdiv=%r: None, 'ewald', 'vcut_sph' and 'vcut_ws' are implemented" % (exxdiv,))
         if not self._built:
             self.build()
+        if with_k and self.pair_space == 'occ':
+            self._ensure_fit(dm)
         be = self.backend
         if exxdiv in ('vcut_sph', 'vcut_ws') and with_k:
             # K with a truncated kernel (spherical: pbc.py:312-317; Wigner-Seitz: pbc.py:318-346): its own W, built once from
@@ -790,6 +934,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             return self._get_ao_eri_kpts(self.kpts if kpts is None else kpts)
         if not self._built:
             self.build()
+        self._ensure_fit()                        # pair_space='occ' and no fit yet: integrals come from the AO x AO pair space
         aoP = self.backend.to_host(self.aoP)
         W = self.backend.to_host(self.W)
         nao = aoP.shape[1]
@@ -815,6 +960,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             raise NotImplementedError('compact MO integrals are not implemented; use compact=False')
         if not self._built:
             self.build()
+        self._ensure_fit()
         aoP = self.backend.to_host(self.aoP)
         W = self.backend.to_host(self.W)
         ci, cj, ck, cl = [aoP.dot(np.asarray(c)) for c in mo_coeffs]

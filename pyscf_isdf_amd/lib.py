@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lib = None
 
@@ -43,6 +43,9 @@ SIGNATURES = {
     'isdf_gather_aoP': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp]),
     'isdf_gram_sq': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'isdf_pair_gram_rows': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64]),
+    'isdf_gram_prod': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
+    'isdf_pair_prod_rows': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64]),
+    'isdf_factor_solve_half': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_i64]),
     'isdf_block_chol': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_dbl, c_vp, ctypes.POINTER(c_dbl)]),
     'isdf_block_solve': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_i64, c_i64]),
     'isdf_block_invert': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),

@@ -92,21 +92,30 @@ class OracleBackend:
             rho[i, :ng] = torch.from_numpy(np.einsum('hg,hg->g', A, dm[i].numpy().dot(B)))
 
     def mg_embed_density(self, field, mesh_sub, scale, spec, mesh, accumulate=True):
+        # the reference's placement (multigrid.py:669-673: level spectrum at the fftfreq indices of the dense mesh, Nyquist entries
+        # at -n/2 only) followed by the Hermitian part (R(f) + conj(R(-f)))/2 - the spectrum of the real field the reference keeps
         n, N = [int(x) for x in mesh_sub], [int(x) for x in mesh]
-        sub = np.fft.rfftn(field.numpy().reshape(-1, *n), axes=(1, 2, 3)) * scale
+        sub = np.fft.fftn(field.numpy().reshape(-1, *n), axes=(1, 2, 3)) * scale
+        raw = np.zeros((len(sub), N[0], N[1], N[2]), dtype=np.complex128)
+        jx, jy, jz = (self._dense_index(n[i], N[i]) for i in range(3))
+        raw[:, jx[:, None, None], jy[:, None], jz] = sub
+        neg = raw[np.ix_(np.arange(len(sub)), (-np.arange(N[0])) % N[0], (-np.arange(N[1])) % N[1], (-np.arange(N[2])) % N[2])].conj()
+        herm = (0.5 * (raw + neg))[..., :N[2] // 2 + 1]
         full = spec.numpy().reshape(-1, N[0], N[1], N[2] // 2 + 1)
-        jx, jy = self._dense_index(n[0], N[0]), self._dense_index(n[1], N[1])
         if accumulate:
-            full[:, jx[:, None, None], jy[:, None], np.arange(n[2] // 2 + 1)] += sub
+            full += herm
         else:
-            full[:, jx[:, None, None], jy[:, None], np.arange(n[2] // 2 + 1)] = sub
+            full[...] = herm
 
     def mg_restrict_potential(self, spec, mesh, mesh_sub, scale, field):
+        # the dense half spectrum completed to the full Hermitian one, the reference's pick of the fftfreq entries, its inverse
+        # transform on the level mesh and .real (multigrid.py:905-915)
         n, N = [int(x) for x in mesh_sub], [int(x) for x in mesh]
-        full = spec.numpy().reshape(-1, N[0], N[1], N[2] // 2 + 1)
-        jx, jy = self._dense_index(n[0], N[0]), self._dense_index(n[1], N[1])
-        sub = full[:, jx[:, None, None], jy[:, None], np.arange(n[2] // 2 + 1)]
-        out = np.fft.irfftn(sub, s=n, axes=(1, 2, 3)) * (np.prod(n) * scale)
+        half = spec.numpy().reshape(-1, N[0], N[1], N[2] // 2 + 1)
+        dense = np.fft.fftn(np.fft.irfftn(half, s=N, axes=(1, 2, 3)), axes=(1, 2, 3))
+        jx, jy, jz = (self._dense_index(n[i], N[i]) for i in range(3))
+        sub = dense[:, jx[:, None, None], jy[:, None], jz]
+        out = np.fft.ifftn(sub, axes=(1, 2, 3)).real * (np.prod(n) * scale)
         field.copy_(torch.from_numpy(np.ascontiguousarray(out.reshape(field.shape))))
 
     def mg_coulomb_kernel(self, spec, mesh, a):
@@ -210,6 +219,16 @@ class OracleBackend:
         if nh:
             b += np.hstack([ap[:, nh:], -ap[:, :nh]]).dot(x) ** 2
         B[:, :ng] = torch.from_numpy(b)
+
+    def gram_prod(self, aoP, psiP, A):
+        ap, pp = aoP.numpy(), psiP.numpy()
+        A.copy_(torch.from_numpy(ap.dot(ap.T) * pp.dot(pp.T)))
+
+    def pair_prod_rows(self, aoP, psiP, ao, psi, ng, B):
+        B[:, :ng] = torch.from_numpy(aoP.numpy().dot(ao.numpy()[:, :ng]) * psiP.numpy().dot(psi.numpy()[:, :ng]))
+
+    def factor_solve_half(self, fac, backward, X):
+        X.copy_(torch.from_numpy(scipy.linalg.solve_triangular(fac.numpy(), X.numpy(), lower=True, trans='T' if backward else 'N')))
 
     def block_chol(self, A, blk_off, shift_rel, D):
         a = A.numpy()

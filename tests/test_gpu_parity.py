@@ -1069,3 +1069,89 @@ def test_two_ranks_over_rccl_when_two_gpus_are_visible():
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                         '127.0.0.1', '--master-port', str(port), script], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'RCCL-TWO-RANK OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_occ_pair_space_kernels(be):
+    """isdf_gram_prod / isdf_pair_prod_rows / isdf_factor_solve_half against numpy: the Gram products of the (AO x occupied)
+    pair space (fft_jk.py:206-210,235-238), with row counts and column counts that are not multiples of any tile and more
+    columns than one chunk of the second factor (the chunk is at least 1024 columns).  1e-13 relative (plain GEMMs)."""
+    rng = np.random.default_rng(5)
+    P, nao, nocc, G = 77, 23, 6, 70001
+    ao = rng.standard_normal((nao, G)) * np.exp(-2.0 * rng.random(G))
+    psi = rng.standard_normal((nocc, nao)).dot(ao)
+    ip = rng.permutation(G)[:P]
+    aoP, psiP = np.ascontiguousarray(ao[:, ip].T), np.ascontiguousarray(psi[:, ip].T)
+    d_aoP, d_psiP, d_ao, d_psi = (be.to_device(x) for x in (aoP, psiP, ao, psi))
+    A = be.empty((P, P))
+    be.gram_prod(d_aoP, d_psiP, A)
+    refA = aoP.dot(aoP.T) * psiP.dot(psiP.T)
+    assert abs(be.to_host(A) - refA).max() < 1e-13 * abs(refA).max()
+    B = be.empty((P, G))
+    be.pair_prod_rows(d_aoP, d_psiP, d_ao, d_psi, G, B)
+    refB = aoP.dot(ao) * psiP.dot(psi)
+    assert abs(be.to_host(B) - refB).max() < 1e-13 * abs(refB).max()
+    # a row slice of the points against a column range (what the paneled build asks for)
+    B2 = be.empty((30, 5000))
+    be.pair_prod_rows(d_aoP[10:40], d_psiP[10:40], d_ao, d_psi, 5000, B2)
+    assert abs(be.to_host(B2) - refB[10:40, :5000]).max() < 1e-13 * abs(refB).max()
+    # Cholesky halves: L^-1 X and L^-T X for the factor of the regularised Gram matrix
+    be.shift_diag(A, 1e-6)
+    reg = be.chol_inplace(A, 0.0)
+    assert reg == 0.0
+    Lr = np.linalg.cholesky(refA + 1e-6 * refA.diagonal().max() * np.eye(P))
+    X = rng.standard_normal((P, 3001))
+    dX = be.to_device(X)
+    be.factor_solve_half(A, False, dX)
+    import scipy.linalg
+    Y = scipy.linalg.solve_triangular(Lr, X, lower=True)
+    assert abs(be.to_host(dX) - Y).max() < 1e-9 * abs(Y).max()
+    be.factor_solve_half(A, True, dX)
+    Z = scipy.linalg.solve_triangular(Lr, Y, lower=True, trans='T')
+    assert abs(be.to_host(dX) - Z).max() < 1e-8 * abs(Z).max()
+
+
+@pytest.mark.parametrize('route', ['cholesky', 'blockjacobi', 'paneled'])
+def test_occ_pair_space_end_to_end_matches_oracle_pipeline(route):
+    """pair_space='occ' on the GPU == the same host driver over the CPU oracle: identical points from the product Gram matrix
+    of the candidates, K within 1e-9 relative, for the Cholesky route, the block-Jacobi route and the paneled block-Jacobi
+    build (rows recomputed panel by panel in the (AO x occupied) pair space); the fit follows the density (second density:
+    refit) and K of the fitted density is closer to the exact exchange than the AO x AO fit's at equal points."""
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(3)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao); occ[:2] = 2
+    dm = (c * occ).dot(c.T)
+
+    class Tagged(np.ndarray):
+        pass
+    tdm = dm.view(Tagged)
+    tdm.mo_coeff, tdm.mo_occ = c, occ
+    out = {}
+    for name, backend in (('gpu', None), ('cpu', OracleBackend())):
+        df = ISDF(cell, c_isdf=2, select='refined', backend=backend)
+        df.pair_space = 'occ'
+        df.refine_over = 2.0
+        df.fit_route = 'blockjacobi' if route == 'paneled' else route
+        if route == 'paneled':
+            df.max_resident_rows = 8
+            df.fft_batch = 4
+        vk = df.get_jk(tdm, with_j=False)[1]
+        if route == 'paneled':
+            assert df.n_panels >= 2
+        out[name] = (vk, df.ip.copy())
+        if name == 'gpu':
+            occ2 = np.zeros(nao); occ2[2:4] = 2
+            t2 = (c * occ2).dot(c.T).view(Tagged)
+            t2.mo_coeff, t2.mo_occ = c, occ2
+            vk_b = df.get_jk(t2, with_j=False)[1]
+            aoT = _oracle_ao(cell)[0]
+            k_ex = fftdf.get_k(np.ascontiguousarray(aoT.T), np.asarray(t2), cell.lattice_vectors(), cell.mesh)
+            ref = ISDF(cell, c_isdf=2, select='refined')
+            ref.fit_route = df.fit_route
+            vk_ao = ref.get_jk(np.asarray(t2), with_j=False)[1]
+            assert abs(vk_b - k_ex).max() < abs(vk_ao - k_ex).max()
+    assert np.array_equal(out['gpu'][1], out['cpu'][1])
+    assert abs(out['gpu'][0] - out['cpu'][0]).max() < 1e-9 * abs(out['cpu'][0]).max()

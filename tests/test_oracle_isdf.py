@@ -370,3 +370,103 @@ def test_vcut_sph_exchange_host_logic_with_checker_backend():
     assert abs(df.get_jk(dm, with_j=False)[1] - vk0).max() < 1e-13           # the plain W is still in place
     df.build()
     assert df._W_omega == {}
+
+
+def _diamond_case(nocc=4, c_isdf=4, mesh=(12, 12, 12)):
+    cell = cells.cell_diamond_prim('gth-szv', mesh)
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(1)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao); occ[:nocc] = 2
+    dm = (c * occ).dot(c.T)
+    rcut = gto.estimate_rcut_per_shell(cell)
+    coords = cell.get_uniform_grids()
+    ao = oao.eval_ao(cell._atm, cell._bas, cell._env, coords, gto.get_lattice_Ls(cell, rcut=rcut.max()), rcut, rule='point')
+    return cell, ao, np.ascontiguousarray(ao.T), dm, c, occ
+
+
+def _tag(dm, mo_coeff, mo_occ):
+    class Tagged(np.ndarray):
+        pass
+    t = np.asarray(dm).view(Tagged)
+    t.mo_coeff, t.mo_occ = mo_coeff, mo_occ
+    return t
+
+
+@pytest.mark.parametrize('route', ['cholesky', 'blockjacobi'])
+def test_occ_pair_space_host_logic_with_checker_backend(route):
+    """pair_space='occ' through the host driver (no GPU): build() stops after the candidate stage; get_jk with an MO-tagged
+    density (the tag of pyscf/pbc/df/fft_jk.py:206-210) picks the points from the product Gram matrix
+    (phi^T phi) o (psi^T psi) of the candidates, fits in that pair space and returns the oracle's K for the same points;
+    the same density again does not refit, another density does; an untagged positive semidefinite density gives the
+    same fit through its eigenvectors."""
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    from pyscf_isdf_amd._common import partition_grid_by_atom
+    cell, ao, aoT, dm, c, occ = _diamond_case(nocc=2)
+    nao = cell.nao_nr()
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    df = ISDF(cell, c_isdf=4, select='refined', backend=OracleBackend())
+    df.pair_space = 'occ'
+    df.fit_route = route
+    df.build()
+    assert df._fit_pending and df.W is None and df.ip is None
+    vk = df.get_jk(_tag(dm, c, occ), with_j=False)[1]
+    assert not df._fit_pending and len(set(df.ip)) == len(df.ip) <= 4 * nao      # the pair space of 2 orbitals x 8 AOs has rank <= 16
+    # the oracle's restatement of the two stages and of the fit
+    coords = cell.get_uniform_grids()
+    owner = partition_grid_by_atom(coords, cell.atom_coords(), a)
+    perm = np.argsort(owner, kind='stable')
+    off = np.append(0, np.cumsum(np.bincount(owner, minlength=cell.natm)))
+    cand = np.concatenate([perm[off[b]:off[b + 1]][oisdf.select_ip(aoT[:, perm[off[b]:off[b + 1]]], 2 * 4 * 4)[0]]
+                           for b in range(cell.natm)])
+    psi = oisdf.occupied_on_grid(aoT, c, occ)
+    chosen = oisdf.refine_selection_occ(aoT, psi, cand, 4 * nao)
+    assert sorted(chosen) == sorted(df.ip)
+    ip = df.ip
+    if route == 'cholesky':
+        theta = oisdf.fit_theta_occ_chol(aoT, psi, ip, reg_rel=df.reg_rel)
+        W = oisdf.build_W(theta, a, mesh)
+    else:
+        cnt = np.bincount(owner[ip], minlength=cell.natm)
+        W = oisdf.build_W_blockjacobi_occ(aoT, psi, ip, np.append(0, np.cumsum(cnt)), a, mesh, reg_rel=df.reg_rel)
+    k_or = oisdf.get_k(np.ascontiguousarray(aoT[:, ip].T), W, dm)
+    assert abs(vk - k_or).max() < 1e-8 * abs(k_or).max()
+    # same density again: no refit (the W buffer is not rewritten); untagged: same occupied space through the eigenvectors
+    Wid = df.W.data_ptr()
+    serial = dict(df.timings)
+    vk2 = df.get_jk(dm, with_j=False)[1]
+    assert df.W.data_ptr() == Wid and df.timings.get('S3_fit') == serial.get('S3_fit')
+    assert abs(vk2 - vk).max() < 1e-12
+    # another occupied space: refit, and the fit is the better one for ITS density
+    occ2 = np.zeros(nao); occ2[2:4] = 2
+    dm2 = (c * occ2).dot(c.T)
+    k_exact2 = fftdf.get_k(ao, dm2, a, mesh)
+    k_stale = oisdf.get_k(np.ascontiguousarray(aoT[:, ip].T), W, dm2)
+    vk3 = df.get_jk(_tag(dm2, c, occ2), with_j=False)[1]
+    assert df.timings['S3_fit'] > serial['S3_fit']
+    assert abs(vk3 - k_exact2).max() < abs(k_stale - k_exact2).max()
+    # occ_refit = 'once' keeps the fit
+    df.occ_refit = 'once'
+    vk4 = df.get_jk(_tag(dm, c, occ), with_j=False)[1]
+    assert abs(vk4 - oisdf.get_k(np.ascontiguousarray(aoT[:, df.ip].T), df.backend.to_host(df.W), dm)).max() < 1e-12
+    t_fit = df.timings['S3_fit']
+    df.get_jk(_tag(dm2, c, occ2), with_j=False)
+    assert df.timings['S3_fit'] == t_fit
+
+
+def test_occ_pair_space_beats_ao_pair_space_at_equal_points():
+    """The (AO x occupied) pair space is what K needs (fft_jk.py:235-238): at equal numbers of points its fit reproduces the
+    exact exchange of THAT density better than the AO x AO fit (oracle arithmetic, diamond primitive cell)."""
+    cell, ao, aoT, dm, c, occ = _diamond_case(nocc=1)
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    k_exact = fftdf.get_k(ao, dm, a, mesh)
+    P = 20
+    piv_a, L_a = oisdf.select_ip(aoT, P, tol=0.0)
+    th_a = oisdf.fit_theta(L_a, piv_a)
+    err_ao = abs(oisdf.get_k(np.ascontiguousarray(aoT[:, piv_a].T), oisdf.build_W(th_a, a, mesh), dm) - k_exact).max()
+    psi = oisdf.occupied_on_grid(aoT, c, occ)
+    ip = oisdf.refine_selection_occ(aoT, psi, np.arange(aoT.shape[1]), P, tol=0.0)
+    th_o = oisdf.fit_theta_occ_chol(aoT, psi, ip, reg_rel=1e-13)
+    err_occ = abs(oisdf.get_k(np.ascontiguousarray(aoT[:, ip].T), oisdf.build_W(th_o, a, mesh), dm) - k_exact).max()
+    assert err_occ < 0.2 * err_ao

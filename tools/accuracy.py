@@ -11,19 +11,31 @@ selects = sys.argv[3].split(',') if len(sys.argv) > 3 else ['local']
 cell = workloads.make_cell(name)
 dm, c, occ = workloads.make_dm(cell)
 nocc = int((occ > 0).sum())
+
+
+class Tagged(np.ndarray):
+    pass
+
+
+tdm = dm.view(Tagged)
+tdm.mo_coeff, tdm.mo_occ = c, occ
 print(name, 'nao', cell.nao_nr(), 'nocc', nocc, 'ngrids', int(np.prod(cell.mesh)), flush=True)
 ref = None
 for sel in selects:
     for cc in cs:
         over = None
         cut = None
-        if ':' in sel:                      # 'refined:3' = refined selection with refine_over = 3; 'refined:2:7': + cand_ao_cutoff 7 Bohr
-            parts = sel.split(':')
+        space = 'ao'
+        sel_full = sel
+        sel_ = sel
+        if '@' in sel:                      # 'refined@occ' = the (AO x occupied) pair space of the density (pair_space='occ')
+            sel_, space = sel.split('@')
+        if ':' in sel_:                      # 'refined:3' = refined selection with refine_over = 3; 'refined:2:7': + cand_ao_cutoff 7 Bohr
+            parts = sel_.split(':')
             sel_, over = parts[0], float(parts[1])
             cut = float(parts[2]) if len(parts) > 2 else None
-        else:
-            sel_ = sel
         df = ISDF(cell, c_isdf=cc, select=sel_)
+        df.pair_space = space
         if over is not None:
             df.refine_over = over
         if cut is not None:
@@ -33,7 +45,7 @@ for sel in selects:
         if os.environ.get('ISDF_FIT_ROUTE'):
             df.fit_route = os.environ['ISDF_FIT_ROUTE']
         t0 = time.perf_counter()
-        vk = df.get_jk(dm, with_j=False)[1]
+        vk = df.get_jk(tdm if space == 'occ' else dm, with_j=False)[1]
         t1 = time.perf_counter()
         nip, route_used = len(df.ip), df.fit_route_used
         if ref is None:
@@ -42,7 +54,7 @@ for sel in selects:
             df.backend.synchronize()
             print('exact K (N*nocc = %d FFT pairs) on the GPU: %.1f s' % (cell.nao_nr() * nocc, time.perf_counter() - t1), flush=True)
         ek, ek0 = np.einsum('ij,ji', vk, dm) / 4, np.einsum('ij,ji', ref, dm) / 4
-        print('select=%-10s c=%2d P=%6d  build+K %.2f s   E_K(ISDF) %.8f  E_K(exact) %.8f  dE_K %.2e Eh (%.1e rel)  max|dK| %.2e  route %s  stages %s'
-              % (sel, cc, nip, t1 - t0, ek, ek0, ek - ek0, abs(ek - ek0) / ek0, abs(vk - ref).max(), route_used, {k: round(v, 2) for k, v in df.timings.items()}), flush=True)
+        print('select=%-14s c=%2d P=%6d  build+K %.2f s   E_K(ISDF) %.8f  E_K(exact) %.8f  dE_K %.2e Eh (%.1e rel)  max|dK| %.2e  route %s  stages %s'
+              % (sel_full, cc, nip, t1 - t0, ek, ek0, ek - ek0, abs(ek - ek0) / ek0, abs(vk - ref).max(), route_used, {k: round(v, 2) for k, v in df.timings.items()}), flush=True)
         df.reset()
         del df
