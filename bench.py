@@ -41,15 +41,15 @@ def parse_args():
     ap.add_argument('--cand-ao-cutoff', type=float, default=None,
                     help="Bohr: the candidate stage of the refined selection sees only the AOs of atoms this close to a block's atom (default: all)")
     ap.add_argument('--no-accuracy', action='store_true',
-                    help="skip the exact-exchange comparison (config.dE_K_vs_exact; 48 s at configs[2], after the timed region)")
+                    help="skip the exact-exchange comparison (config.dE_K_vs_exact; the reference's algorithm on the same GPU, "
+                         "about 40 s at configs[2], evaluated BEFORE the warm-up and timed steps)")
+    ap.add_argument('--pair-space', default='ao', choices=['ao', 'occ'],
+                    help="'occ': fit the (AO x occupied orbital) pairs of the benchmark density (its mo_coeff/mo_occ tag, "
+                         "fft_jk.py:206-210); the fit then runs inside get_jk, still inside the timed step")
     ap.add_argument('--c-isdf', type=int, default=None,
                     help='interpolation points per AO; default: 12 for the headline workload (the accuracy scan of DESIGN.md section 2), else 10')
     ap.add_argument('--fit-route', default=None, choices=['auto', 'cholesky', 'blockjacobi'])
     ap.add_argument('--robust-k', action='store_true', help='time the build + get_jk with the robust exchange (not the headline)')
-    ap.add_argument('--accuracy-budget-s', type=float, default=420.0,
-                    help='if the process has already run longer than this when the timed region ends (many steps), the 48 s exact-'
-                         'exchange evaluation is skipped and E_K(exact) of this workload and density is taken from the committed '
-                         'profiles/r02_bench_cfg3.json (it does not depend on the ISDF settings); stated in accuracy.source')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--stage-report', default=None, help='write the per-kernel table to this file')
     return ap.parse_args()
@@ -202,8 +202,14 @@ def main():
     cell = workloads.make_cell(args.workload)
     kpts = workloads.make_kpts(args.workload, cell)
     if kpts is None:
-        dm = workloads.make_dm(cell)[0]
+        dm, c_mo, occ_mo = workloads.make_dm(cell)
+        if args.pair_space == 'occ':
+            class _Tagged(np.ndarray):          # numpy_helper.tag_array's role: the density carries its orbitals
+                pass
+            dm = dm.view(_Tagged)
+            dm.mo_coeff, dm.mo_occ = c_mo, occ_mo
         df = ISDF(cell, c_isdf=args.c_isdf, select=args.select, comm=comm)
+        df.pair_space = args.pair_space
     else:
         # k-point workload (configs[3]): Hermitian D^k = C^k occ C^k^H with random unitary C^k
         nao = cell.nao_nr()
@@ -244,6 +250,20 @@ def main():
             last_note[0] = now
             print('[bench] %s step %d of %d done, %.0f s since start' % (what, i + 1, n, now - T_PROCESS_START), file=sys.stderr, flush=True)
 
+    # accuracy reference FIRST (outside every timed region): the reference's exact exchange (fft_jk.py:177-302, N*nocc FFT
+    # pairs) for the benchmark density on this GPU - measured in this run, never read from a file
+    vk_exact = None
+    t_exact = 0.0
+    if world == 1 and kpts is None and not args.no_accuracy and not args.robust_k:
+        print('[bench] exact exchange on the GPU for the accuracy entry (about 40 s)', file=sys.stderr, flush=True)
+        ta = time.perf_counter()
+        vk_exact = df.get_k_exact(mo_coeff=c_mo, mo_occ=occ_mo)
+        torch.cuda.synchronize()
+        t_exact = time.perf_counter() - ta
+        df.release_fit_buffers()
+        be.release_workspace()
+        be.empty_cache()
+
     cold_first_step = None
     for i in range(args.warmup):
         torch.cuda.synchronize()
@@ -255,6 +275,7 @@ def main():
         progress('warmup', i, args.warmup)
     be.prof_reset()
     be.prof_enable(True)
+    comm.reset_stats()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -267,6 +288,12 @@ def main():
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     sec_per_step = elapsed.item() / args.steps
+    # what every rank spent where in its last step and what it put on the fabric in the timed steps (bytes always; seconds
+    # when ISDF_COMM_TIMING=1: event pairs around each collective)
+    mine = {'rank': rank, 'stage_seconds_last_step': {k: round(v, 4) for k, v in df.timings.items()},
+            'comm': {k: {'calls': v['calls'], 'GB': round(v['bytes'] / 1e9, 3), 'seconds': round(v['seconds'], 4)}
+                     for k, v in comm.collect_stats().items()}}
+    per_rank = comm.all_gather_object(mine) if world > 1 else [mine]
 
     if rank == 0:
         prof = be.prof_results()
@@ -352,45 +379,28 @@ def main():
             'roofline_hbm_kernels': hbm,
         }
         out['cold_first_step_s'] = None if cold_first_step is None else round(cold_first_step, 3)
+        if world > 1:
+            out['per_rank'] = per_rank
+            out['comm_timing'] = ('event pairs around every collective (ISDF_COMM_TIMING=1)' if comm.timing else
+                                  'bytes only; set ISDF_COMM_TIMING=1 for seconds')
         out['config']['refine_over'] = args.refine_over if args.select == 'refined' else None
         out['config']['cand_ao_cutoff'] = args.cand_ao_cutoff if args.select == 'refined' else None
         out['config']['fit_row_panels'] = int(getattr(df, 'n_panels', 1))
         # accuracy of the timed configuration against the reference's exact exchange (fft_jk.py:177-302 on the GPU,
         # isdf_get_k_exact; outside the timed region).  J is the reference's own formula (fft_jk.py:33-109): no fit error.
         out['config']['dE_K_vs_exact'] = None
-        if world == 1 and kpts is None and not args.no_accuracy and not args.robust_k:
-            ta = time.perf_counter()
-            note = ('exact = the reference algorithm (N*nocc FFT pairs) on the same GPU and grid; J uses the reference formula itself; '
-                    'north-star tolerance 1e-6 Eh: see DESIGN.md section 2 for the c / selection scan')
-            if ta - T_PROCESS_START <= args.accuracy_budget_s:
-                _, c_mo, occ_mo = workloads.make_dm(cell)
-                print('[bench] exact exchange on the GPU for the accuracy entry (about 40 s)', file=sys.stderr, flush=True)
-                df.release_fit_buffers()                # the fit's buffers fill HBM; the exact exchange needs phi and its own batches
-                vk_ex = df.get_k_exact(mo_coeff=c_mo, mo_occ=occ_mo)
-                ek_ex = float(np.einsum('ij,ji', vk_ex, dm) / 4)
-                out['config']['dE_K_vs_exact'] = float(out['energies']['EK'] - ek_ex)
-                out['accuracy'] = {'E_K_exact': ek_ex, 'dE_K_Eh': out['config']['dE_K_vs_exact'],
-                                   'dE_K_Eh_per_atom': out['config']['dE_K_vs_exact'] / cell.natm,
-                                   'max_abs_dK': float(abs(vk - vk_ex).max()), 'source': 'measured in this run',
-                                   'exact_K_seconds_on_this_gpu': round(time.perf_counter() - ta, 1), 'dE_J_Eh': 0.0, 'note': note}
-                del vk_ex
-            else:
-                # a long run (many steps): do not add 48 s; E_K(exact) depends on the cell, the grid and the density only
-                try:
-                    with open(os.path.join(ROOT, 'profiles', 'r02_bench_cfg3.json')) as f:
-                        rec = json.load(f)
-                    same = (rec['config']['workload'] == workloads.WORKLOADS[args.workload][1] and rec['config']['nao'] == nao
-                            and rec['config']['ngrids'] == G and abs(rec['energies']['EJ'] - out['energies']['EJ']) < 1e-8)
-                    if same:
-                        ek_ex = float(rec['accuracy']['E_K_exact'])
-                        out['config']['dE_K_vs_exact'] = float(out['energies']['EK'] - ek_ex)
-                        out['accuracy'] = {'E_K_exact': ek_ex, 'dE_K_Eh': out['config']['dE_K_vs_exact'],
-                                           'dE_K_Eh_per_atom': out['config']['dE_K_vs_exact'] / cell.natm, 'max_abs_dK': None,
-                                           'source': 'E_K(exact) recorded in profiles/r02_bench_cfg3.json for this workload and density '
-                                                     '(same E_J to 1e-8); not re-evaluated: the process had run %.0f s > --accuracy-budget-s'
-                                                     % (ta - T_PROCESS_START), 'dE_J_Eh': 0.0, 'note': note}
-                except (OSError, KeyError, ValueError):
-                    pass
+        out['config']['pair_space'] = args.pair_space
+        if vk_exact is not None:
+            ek_ex = float(np.einsum('ij,ji', vk_exact, np.asarray(dm)) / 4)
+            out['config']['dE_K_vs_exact'] = float(out['energies']['EK'] - ek_ex)
+            out['accuracy'] = {'E_K_exact': ek_ex, 'dE_K_Eh': out['config']['dE_K_vs_exact'],
+                               'dE_K_Eh_per_atom': out['config']['dE_K_vs_exact'] / cell.natm,
+                               'max_abs_dK': float(abs(vk - vk_exact).max()), 'source': 'measured in this run',
+                               'north_star_tol_Eh': 1e-6, 'meets_north_star': bool(abs(out['config']['dE_K_vs_exact']) <= 1e-6),
+                               'exact_K_seconds_on_this_gpu': round(t_exact, 1), 'dE_J_Eh': 0.0,
+                               'note': 'exact = the reference algorithm (N*nocc FFT pairs) on the same GPU and grid, evaluated before '
+                                       'the warm-up steps; J uses the reference formula itself; DESIGN.md section 2 has the scan over '
+                                       'c, the selection and the pair space'}
         if os.environ.get('ISDF_ONE_GPU'):
             out['data'] = 'synthetic; REHEARSAL: %d ranks on one GPU over gloo, not a benchmark' % world
         if world == 1 and not args.no_cpu_baseline and kpts is None:

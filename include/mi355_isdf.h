@@ -389,6 +389,18 @@ int isdf_finish_Wq(isdf_handle h, const double* d_Wre, const double* d_Wim, int 
                    const double* d_phase, double* d_Wc);
 int isdf_get_k_pair(isdf_handle h, const double* d_A1, const double* d_A2, const double* d_D2,
                     const double* d_Wq, int P, int nao, double scale, double* d_vk);
+
+/* The reference's exact k-point exchange for one (k1, k2) pair on the device (pyscf/pbc/df/fft_jk.py:250-292: pair densities
+ * conj(phi^{k1}_p) exp(-i q.r) phi^{k2}_j, kernel get_coulG(cell, k2 - k1), weight 1/nk vol/G) - the verification path of the
+ * k-point ISDF exchange, N * nocc complex FFT pairs per (k1, k2).  In periodic parts the phases cancel:
+ *   vk[p - i0, k'] += weight sum_g { sum_j conv_q[conj(u1_p) m2_j](g) conj(m2_j(g)) } u1_k'(g),   p in [i0, i0 + ni)
+ * d_u1r/d_u1i (nao, ld1): periodic parts of the Bloch AOs at k1 (isdf_eval_ao_k, periodic_part = 1); d_m2r/d_m2i (nocc, ld2):
+ * those of the occupied orbitals at k2 scaled with sqrt(occ); d_coulG (G): isdf_coulG_q of q = k2 - k1; max_rows: FFT rows per
+ * pass (>= nocc); d_vk_re/d_vk_im (ni, nao) row-major are ACCUMULATED into (the caller sums over k2). */
+int isdf_get_k_exact_kpt(isdf_handle h, const double* d_u1r, const double* d_u1i, int nao, int64_t ld1,
+                         const double* d_m2r, const double* d_m2i, int nocc, int64_t ld2, const int32_t mesh[3],
+                         const double* d_coulG, double weight, int i0, int ni, int max_rows, double* d_vk_re,
+                         double* d_vk_im);
 int isdf_rho_k(isdf_handle h, const double* d_ur, const double* d_ui, int nao, int64_t ng, int64_t ld,
                const double* d_DTr, const double* d_DTi, double scale, double* d_rho);
 int isdf_vj_k(isdf_handle h, const double* d_ur, const double* d_ui, int nao, int64_t ng, int64_t ld,

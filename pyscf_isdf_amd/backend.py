@@ -591,6 +591,16 @@ class HipBackend:
         self.handle.call('isdf_get_k_pair', self._p(A1), self._p(A2), self._p(D2), self._p(Wq), A1.shape[0], A1.shape[1],
                          float(scale), self._p(vk))
 
+    def get_k_exact_kpt(self, u1r, u1i, m2r, m2i, mesh, coulG, weight, i0, ni, max_rows, vk_re, vk_im):
+        """vk (ni, nao) += the exact exchange rows i0..i0+ni of one (k1, k2) pair (include/mi355_isdf.h isdf_get_k_exact_kpt)."""
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        assert u1r.stride(1) == 1 and u1r.stride() == u1i.stride() and m2r.stride(1) == 1 and m2r.stride() == m2i.stride()
+        assert vk_re.is_contiguous() and vk_im.is_contiguous() and tuple(vk_re.shape) == (ni, u1r.shape[0])
+        self.handle.call('isdf_get_k_exact_kpt', self._p(u1r), self._p(u1i), u1r.shape[0], u1r.stride(0), self._p(m2r),
+                         self._p(m2i), m2r.shape[0], m2r.stride(0), _np_ptr(mesh), self._p(coulG), float(weight), int(i0), int(ni),
+                         int(max_rows), self._p(vk_re), self._p(vk_im))
+
     def rho_k(self, ur, ui, ng, DTr, DTi, scale, rho):
         self._stream()
         self.handle.call('isdf_rho_k', self._p(ur), self._p(ui), ur.shape[0], int(ng), ur.stride(0), self._p(DTr),

@@ -99,6 +99,36 @@ __global__ void rho_k_reduce_kernel(const double* __restrict__ Tr, const double*
   rho[g] += scale * s;
 }
 
+// Z[(p, j), g] = conj(u1[p, g]) * m2[j, g]   (periodic parts: the Bloch phases of conj(phi^{k1}) exp(-i q.r) phi^{k2} cancel)
+__global__ void pair_rows_cplx_kernel(const double* __restrict__ u1r, const double* __restrict__ u1i, int64_t ld1,
+                                      const double* __restrict__ m2r, const double* __restrict__ m2i, int64_t ld2, int nocc,
+                                      int64_t G, double2* __restrict__ Z) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const int row = blockIdx.y, p = row / nocc, j = row % nocc;
+  const double ar = u1r[(int64_t)p * ld1 + g], ai = -u1i[(int64_t)p * ld1 + g];
+  const double br = m2r[(int64_t)j * ld2 + g], bi = m2i[(int64_t)j * ld2 + g];
+  Z[(int64_t)row * G + g] = make_double2(ar * br - ai * bi, ar * bi + ai * br);
+}
+
+// T[p, g] = sum_j Z[(p, j), g] * conj(m2[j, g])
+__global__ void pair_reduce_cplx_kernel(const double2* __restrict__ Z, const double* __restrict__ m2r,
+                                        const double* __restrict__ m2i, int64_t ld2, int nocc, int64_t G,
+                                        double* __restrict__ Tr, double* __restrict__ Ti) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const int p = blockIdx.y;
+  double sr = 0.0, si = 0.0;
+  for (int j = 0; j < nocc; ++j) {
+    const double2 z = Z[((int64_t)p * nocc + j) * G + g];
+    const double br = m2r[(int64_t)j * ld2 + g], bi = m2i[(int64_t)j * ld2 + g];
+    sr += z.x * br + z.y * bi;
+    si += z.y * br - z.x * bi;
+  }
+  Tr[(int64_t)p * G + g] = sr;
+  Ti[(int64_t)p * G + g] = si;
+}
+
 inline rocblas_operation zop(char c) {
   return c == 'N' ? rocblas_operation_none : (c == 'T' ? rocblas_operation_transpose : rocblas_operation_conjugate_transpose);
 }
@@ -229,6 +259,61 @@ extern "C" int isdf_get_k_pair(isdf_handle h, const double* d_A1, const double* 
   rc = zgemm_rm(h, 'N', 'N', P, nao, P, one, X, P, A1, nao, zero, Y, nao);
   if (rc) return rc;
   return zgemm_rm(h, 'C', 'N', nao, nao, P, make_double2(scale, 0.0), A1, nao, Y, nao, one, (double2*)d_vk, nao);
+}
+
+extern "C" int isdf_get_k_exact_kpt(isdf_handle h, const double* d_u1r, const double* d_u1i, int nao, int64_t ld1,
+                                    const double* d_m2r, const double* d_m2i, int nocc, int64_t ld2, const int32_t mesh[3],
+                                    const double* d_coulG, double weight, int i0, int ni, int max_rows, double* d_vk_re,
+                                    double* d_vk_im) {
+  // The reference's exact k-point exchange for ONE (k1, k2) pair (pyscf/pbc/df/fft_jk.py:250-292), in periodic parts:
+  //   vk[p, k'] += weight sum_g { sum_j conv_q[conj(u1_p) m2_j](g) conj(m2_j(g)) } u1_k'(g),   p in [i0, i0 + ni)
+  // u1 (nao, G): periodic parts of the Bloch AOs at k1 (two real planes), m2 (nocc, G): those of the occupied orbitals at k2
+  // (scaled with sqrt(occ)), d_coulG: the kernel table of q = k2 - k1 (isdf_coulG_q), weight = vol / G / nk.  One complex FFT pair
+  // per (AO, occupied orbital) pair - the verification path for the k-point ISDF exchange.
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_u1r && d_u1i && d_m2r && d_m2i && mesh && d_coulG && d_vk_re && d_vk_im && nao > 0 && nocc > 0);
+  ARG_CHECK(h, i0 >= 0 && ni >= 0 && i0 + ni <= nao && max_rows >= nocc && nocc <= 65535);
+  const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  ARG_CHECK(h, ld1 >= G && ld2 >= G);
+  if (ni == 0) return ISDF_OK;
+  const int bi = std::max(1, std::min(ni, max_rows / nocc));
+  ARG_CHECK(h, (int64_t)bi * nocc <= 65535);
+  double2* Z = (double2*)isdf_ws(h, "kxk_Z", sizeof(double2) * (size_t)bi * nocc * G);
+  double* Tr = (double*)isdf_ws(h, "kxk_T", sizeof(double) * (size_t)2 * bi * G);
+  if (!Z || !Tr) return ISDF_ERR_HIP;
+  double* Ti = Tr + (size_t)bi * G;
+  for (int r = i0; r < i0 + ni; r += bi) {
+    const int nb = std::min(bi, i0 + ni - r);
+    const int rows = nb * nocc;
+    hipfftHandle plan;
+    int rc = get_z2z_plan(h, mesh, rows, &plan);
+    if (rc) return rc;
+    const int64_t total = (int64_t)rows * G;
+    const unsigned nblocks = (unsigned)std::min<int64_t>(cdiv(total, 256), (int64_t)h->num_cu * 16);
+    {
+      ProfScope ps(h, "exact_k_kpt_pairs[byte]", 96.0 * (double)total, 5);
+      hipLaunchKernelGGL(pair_rows_cplx_kernel, dim3((unsigned)cdiv(G, 256), (unsigned)rows), dim3(256), 0, h->stream,
+                         d_u1r + (int64_t)r * ld1, d_u1i + (int64_t)r * ld1, ld1, d_m2r, d_m2i, ld2, nocc, G, Z);
+      FFT_TRY(h, hipfftExecZ2Z(plan, (hipfftDoubleComplex*)Z, (hipfftDoubleComplex*)Z, HIPFFT_FORWARD));
+      hipLaunchKernelGGL(mul_full_kernel, dim3(nblocks), dim3(256), 0, h->stream, Z, d_coulG, G, total, 1.0 / (double)G);
+      FFT_TRY(h, hipfftExecZ2Z(plan, (hipfftDoubleComplex*)Z, (hipfftDoubleComplex*)Z, HIPFFT_BACKWARD));
+      hipLaunchKernelGGL(pair_reduce_cplx_kernel, dim3((unsigned)cdiv(G, 256), (unsigned)nb), dim3(256), 0, h->stream, Z, d_m2r,
+                         d_m2i, ld2, nocc, G, Tr, Ti);
+      KERNEL_CHECK(h);
+    }
+    // vk[r:r+nb] += weight T u1^T (complex, no conjugate):  Re = Tr u1r^T - Ti u1i^T,  Im = Tr u1i^T + Ti u1r^T
+    double* kr = d_vk_re + (int64_t)(r - i0) * nao;
+    double* ki = d_vk_im + (int64_t)(r - i0) * nao;
+    rc = gemm_nt_f64(h, nb, nao, G, weight, Tr, G, d_u1r, ld1, 1.0, kr, nao);
+    if (rc) return rc;
+    rc = gemm_nt_f64(h, nb, nao, G, -weight, Ti, G, d_u1i, ld1, 1.0, kr, nao);
+    if (rc) return rc;
+    rc = gemm_nt_f64(h, nb, nao, G, weight, Tr, G, d_u1i, ld1, 1.0, ki, nao);
+    if (rc) return rc;
+    rc = gemm_nt_f64(h, nb, nao, G, weight, Ti, G, d_u1r, ld1, 1.0, ki, nao);
+    if (rc) return rc;
+  }
+  return ISDF_OK;
 }
 
 extern "C" int isdf_rho_k(isdf_handle h, const double* d_ur, const double* d_ui, int nao, int64_t ng, int64_t ld,

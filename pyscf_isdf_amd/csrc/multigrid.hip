@@ -29,7 +29,8 @@ __device__ inline int dense_index(int i, int n, int N) {
 // i.e. v/2 at f_L and conj(v)/2 at -f_L for an entry whose frequency vector f_L has a proper Nyquist component (every other entry
 // meets its own Hermitian partner and keeps weight 1).  A half spectrum can only hold Hermitian fields, so that symmetrised
 // form is what is stored: weight 1/2, at f_L when its z component is stored (>= 0), else as the conjugate at -f_L; in a
-// self-conjugate z plane (z = 0, or the dense mesh's own Nyquist plane) both f_L and -f_L are stored and both are written.
+// self-conjugate z plane (z = 0, or the dense mesh's own Nyquist plane) both f_L and -f_L are stored and both are written; in an
+// interior z plane the thread also writes for the level's unstored partner entry (see the kernel).
 // The map stays injective: a +n/2 component is produced by these entries only.
 struct NyqInfo { bool pnx, pny, pnz, any; };
 __device__ inline NyqInfo nyq_info(int ix, int iy, int iz, int n0, int n1, int n2, int N0, int N1, int N2) {
@@ -66,8 +67,16 @@ __global__ void spectrum_embed_kernel(const double2* __restrict__ sub, int n0, i
     put(mx, my, iz, w * v.x, -w * v.y);                                      // f_L has z = -n2/2: stored as the conjugate at -f_L
   } else {
     put(jx, jy, iz, w * v.x, w * v.y);
-    const bool self_z = iz == 0 || ((n2 % 2 == 0) && iz == n2 / 2);         // (the second case: N2 == n2 here)
-    if (q.any && self_z) put(mx, my, iz, w * v.x, -w * v.y);
+    if (q.any) {
+      const bool self_z = iz == 0 || ((n2 % 2 == 0) && iz == n2 / 2);       // (the second case: N2 == n2 here)
+      if (self_z) {
+        put(mx, my, iz, w * v.x, -w * v.y);                                  // -f_L lies in the same, self-conjugate, stored plane
+      } else {
+        // an interior z plane: the level's partner entry (-ix, -iy, -iz) is not stored on the level side, so this thread also
+        // places ITS contribution conj(conj(v))/2 - at f_L with the proper Nyquist components flipped to +n/2
+        put(q.pnx ? n0 / 2 : jx, q.pny ? n1 / 2 : jy, iz, w * v.x, w * v.y);
+      }
+    }
   }
 }
 

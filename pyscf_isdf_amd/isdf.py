@@ -246,6 +246,18 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             self._comm = Comm()
         return self._comm
 
+    def collocate(self):
+        """S1 alone: phi on the grid (what get_k_exact needs), without selecting points or fitting."""
+        cell, be = self.cell, self.backend
+        self._drop_build_state()
+        G = int(np.prod(self.mesh))
+        rcut = gto.estimate_rcut_per_shell(cell)
+        Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+        self.ao = self._buffer('ao', (cell.nao_nr(), G))
+        be.eval_ao(np.asarray(cell._atm), np.asarray(cell._bas), np.asarray(cell._env), Ls, rcut,
+                   be.to_device(np.ascontiguousarray(self.grids.coords.T)), self.ao)
+        return self
+
     def build(self):
         self.check_sanity()
         self._drop_build_state()
@@ -255,6 +267,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
             return self._build_kpts()
         if self._sharded:
+            if self.pair_space == 'occ':
+                raise NotImplementedError("pair_space='occ' is implemented for the single-GPU Gamma-point build")
             return self._build_sharded()
         cell, be = self.cell, self.backend
         self.timings = {}
@@ -868,14 +882,16 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             vk = be.to_host(d_vk).reshape(dm_in.shape)
         return vj, vk
 
-    def get_k_exact(self, dm=None, mo_coeff=None, mo_occ=None, max_rows=None):
+    def get_k_exact(self, dm=None, mo_coeff=None, mo_occ=None, max_rows=None, kpts_band=None, rows=None):
         """The reference's exact exchange (FFTDF.get_jk's K, fft_jk.py:177-302) evaluated on the GPU with
         the same device primitives — N*nocc FFT pairs.  Used to measure the ISDF fitting error at full
         size.  Needs the occupied orbitals (mo_coeff, mo_occ) or a positive semidefinite dm."""
-        if not self._is_gamma(self.kpts):
-            raise NotImplementedError
+        if self._sharded:
+            raise NotImplementedError('get_k_exact is a single-GPU verification path')
+        if not self._is_gamma(self.kpts) or not self._is_gamma(kpts_band):
+            return self._get_k_exact_kpts(dm, mo_coeff, mo_occ, kpts_band=kpts_band, rows=rows, max_rows=max_rows)
         if self.ao is None:
-            self.build()
+            self.collocate()
         be = self.backend
         nao = self.cell.nao_nr()
         if mo_coeff is None:
@@ -897,8 +913,6 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         if max_rows is None:
             max_rows = max(nocc, int((4 << 30) // (8 * G)) // nocc * nocc)
         vk = be.empty((nao, nao))
-        if self._sharded:
-            raise NotImplementedError('get_k_exact is a single-GPU verification path')
         be.get_k_exact(self.ao, G, be.to_device(np.ascontiguousarray(c)), mesh, a, 0, nao, max_rows, vk)
         return be.to_host(vk)
 

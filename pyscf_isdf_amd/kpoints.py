@@ -9,6 +9,65 @@ from ._common import partition_grid_by_atom, _monkhorst_pack_size
 
 class KPointMixin:
     # ---- k-points (BASELINE configs[3]); DESIGN.md "k-points" -----------------------------------------
+    def _get_k_exact_kpts(self, dm=None, mo_coeff=None, mo_occ=None, kpts_band=None, rows=None, max_rows=None):
+        """The reference's exact k-point exchange on the device (pyscf/pbc/df/fft_jk.py:250-292; isdf_get_k_exact_kpt): one
+        complex FFT pair per (AO at k1, occupied orbital at k2) for every (k1, k2) - the yardstick the k-point ISDF exchange is
+        measured against.  Occupied orbitals from mo_coeff / mo_occ (per k-point, fft_jk.py:206-210) or from the eigenvectors of
+        Hermitian positive semidefinite density matrices.  rows = (i0, ni): only the AO rows i0..i0+ni of K (a sample, for
+        sizes where all rows take too long).  Returns vk (nband, nao or ni, nao) complex128."""
+        cell, be = self.cell, self.backend
+        kpts = np.asarray(self.kpts, dtype=float).reshape(-1, 3)
+        band = kpts if kpts_band is None else np.asarray(kpts_band, dtype=float).reshape(-1, 3)
+        nk, nao = len(kpts), cell.nao_nr()
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        if mo_coeff is None:
+            mo_coeff, mo_occ = getattr(dm, 'mo_coeff', None), getattr(dm, 'mo_occ', None)
+        orbs = []
+        for k in range(nk):
+            if mo_coeff is not None:
+                occ = np.asarray(mo_occ[k], dtype=float)
+                orbs.append(np.asarray(mo_coeff[k])[:, occ > 0] * np.sqrt(occ[occ > 0]))
+            else:
+                d = np.asarray(dm).reshape(-1, nao, nao)[k]
+                ev, u = np.linalg.eigh(0.5 * (d + d.conj().T))
+                if ev.min() < -1e-10 * abs(ev).max():
+                    raise ValueError('get_k_exact needs occupied orbitals or positive semidefinite density matrices')
+                keep = ev > 1e-12 * ev.max()
+                orbs.append(u[:, keep] * np.sqrt(ev[keep]))
+        i0, ni = (0, nao) if rows is None else (int(rows[0]), int(rows[1]))
+        rcut = gto.estimate_rcut_per_shell(cell)
+        Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+        ao_args = (np.asarray(cell._atm), np.asarray(cell._bas), np.asarray(cell._env), Ls, rcut)
+        coords_soa = be.to_device(np.ascontiguousarray(self.grids.coords.T))
+        u = be.empty((2, nao, G))
+        m2 = []
+        for k in range(nk):                                     # occupied orbitals at k2 as periodic parts: m2 = C^T u
+            be.eval_ao_k(*ao_args, kpts[k], True, coords_soa, u[0], u[1])
+            c = np.ascontiguousarray(orbs[k].T)                 # (nocc, nao)
+            cr, ci = be.to_device(np.ascontiguousarray(c.real)), be.to_device(np.ascontiguousarray(c.imag))
+            m = be.empty((2, c.shape[0], G))
+            be.gemm_nn(cr, u[0], m[0])
+            be.gemm_nn(ci, u[1], m[0], alpha=-1.0, beta=1.0)
+            be.gemm_nn(cr, u[1], m[1])
+            be.gemm_nn(ci, u[0], m[1], alpha=1.0, beta=1.0)
+            m2.append(m)
+        nocc_max = max(m.shape[1] for m in m2)
+        if max_rows is None:
+            max_rows = max(nocc_max, min(int((6 << 30) // (16 * G)), 65535) // nocc_max * nocc_max)
+        weight = cell.vol / G / nk
+        out = np.zeros((len(band), ni, nao), dtype=np.complex128)
+        coulG = be.empty((G,))
+        for b, kb in enumerate(band):
+            be.eval_ao_k(*ao_args, kb, True, coords_soa, u[0], u[1])
+            vr, vi = be.zeros((ni, nao)), be.zeros((ni, nao))
+            for k2 in range(nk):
+                be.coulG_q(mesh, a, kpts[k2] - kb, out=coulG)
+                be.get_k_exact_kpt(u[0], u[1], m2[k2][0], m2[k2][1], mesh, coulG, weight, i0, ni, max_rows, vr, vi)
+            out[b] = be.to_host(vr) + 1j * be.to_host(vi)
+        return out
+
     def _build_kpts(self):
         """Periodic parts u^k of all Bloch AOs -> real points/Theta (complex-mode S2/S3) -> one complex
         W^q per difference vector q = k2 - k1.  The q list is split over the ranks (each rank holds the

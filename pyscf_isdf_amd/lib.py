@@ -77,6 +77,7 @@ SIGNATURES = {
     'isdf_symmetrize_hermitian': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64]),
     'isdf_finish_Wq': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),
     'isdf_get_k_pair': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_dbl, c_vp]),
+    'isdf_get_k_exact_kpt': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_dbl, c_int, c_int, c_int, c_vp, c_vp]),
     'isdf_rho_k': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_dbl, c_vp]),
     'isdf_vj_k': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'isdf_pp_local_potential': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),

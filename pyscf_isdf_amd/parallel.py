@@ -12,6 +12,42 @@ class Comm:
         # always: issue every collective even with one rank (a process group must be initialised).  Lets a ONE-GPU box
         # execute the RCCL code paths (tests/nccl_one_rank.py); with more than one rank it changes nothing.
         self.always = bool(always)
+        # what went over the fabric, per collective kind: calls, payload bytes this rank contributed (all_reduce / broadcast:
+        # the tensor; all_to_all: what this rank sent to OTHER ranks; all_gather: its own block), and - when timing is on -
+        # device time between event pairs recorded around the call on the stream it was issued on (no host synchronisation
+        # until the figures are read: the side-stream overlap of the sharded build is not disturbed)
+        self.stats = {}
+        self.timing = bool(os.environ.get('ISDF_COMM_TIMING'))
+        self._events = []
+
+    def _note(self, kind, nbytes, t=None):
+        st = self.stats.setdefault(kind, {'calls': 0, 'bytes': 0, 'seconds': 0.0})
+        st['calls'] += 1
+        st['bytes'] += int(nbytes)
+        ev = None
+        if self.timing and t is not None and t.is_cuda:
+            ev = (kind, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[1].record(torch.cuda.current_stream(t.device))
+            self._events.append(ev)
+        return ev
+
+    @staticmethod
+    def _done(ev, t):
+        if ev is not None:
+            ev[2].record(torch.cuda.current_stream(t.device))
+
+    def reset_stats(self):
+        self.stats = {}
+        self._events = []
+
+    def collect_stats(self):
+        """{kind: {calls, bytes, seconds}} since the last reset (synchronises the device once to read the event pairs)."""
+        if self._events:
+            torch.cuda.synchronize()
+            for kind, e0, e1 in self._events:
+                self.stats[kind]['seconds'] += e0.elapsed_time(e1) * 1e-3
+            self._events = []
+        return {k: dict(v) for k, v in self.stats.items()}
 
     @property
     def _live(self):
@@ -38,23 +74,27 @@ class Comm:
 
     def all_reduce_sum(self, t):
         if self._live:
+            ev = self._note('all_reduce', t.numel() * t.element_size(), t)
             if self._staged(t):
                 h = t.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
                 t.copy_(h)
             else:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._done(ev, t)
         return t
 
     def broadcast(self, t, src=0):
         """Every rank ends with rank src's tensor."""
         if self._live:
+            ev = self._note('broadcast', t.numel() * t.element_size(), t)
             if self._staged(t):
                 h = t.cpu()
                 dist.broadcast(h, src, group=self.group)
                 t.copy_(h)
             else:
                 dist.broadcast(t, src, group=self.group)
+            self._done(ev, t)
         return t
 
     def agree_max(self, x):
@@ -89,6 +129,7 @@ class Comm:
         mx = max(counts)
         pad = torch.zeros((mx,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
         pad[:t_local.shape[0]] = t_local
+        self._note('all_gather', t_local.numel() * t_local.element_size())
         if self._staged(pad):
             hp = pad.cpu()
             hb = [torch.empty_like(hp) for _ in range(self.size)]
@@ -112,6 +153,7 @@ class Comm:
             recv[0].copy_(send[0])
             return
         send = [s.contiguous() for s in send]
+        ev = self._note('all_to_all', sum(x.numel() * x.element_size() for q, x in enumerate(send) if q != self.rank), send[0])
         if dist.get_backend(self.group) == 'gloo':
             # gloo has no all_to_all: pairwise exchange (CPU tests only)
             reqs = []
@@ -133,6 +175,7 @@ class Comm:
                 recv[q].copy_(h)
         else:
             dist.all_to_all(recv, send, group=self.group)
+        self._done(ev, send[0])
 
     def barrier(self):
         if self._live:

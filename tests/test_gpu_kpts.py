@@ -444,3 +444,45 @@ def test_supercell_kmesh_cross_check_on_gpu():
     ek_k = np.einsum('kij,kji', vk, dms).real / 4 / nk
     ek_s = np.einsum('ij,ji', vks, dm_sc.real) / 4 / nk
     assert abs(ek_k - ek_s) < 1e-5 * abs(ek_s)
+
+
+def test_exact_kpoint_exchange_on_device_reproduces_the_reference_pin():
+    """isdf_get_k_exact_kpt (the reference's k-point exchange loop, fft_jk.py:250-292, in periodic parts on the device) pinned
+    DIRECTLY to the reference's constant for 4 random k-points and 2 band k-points with MO-tagged random density matrices
+    (pyscf/pbc/df/test/test_fft.py:555-557,663-676): fp(vk1) = 10.239828255099447+2.1190549216896182j to 1e-8, and to the
+    oracle's restatement element-wise (1e-10); a row sample (rows=) equals the same rows of the full result; untagged
+    Hermitian positive semidefinite density matrices go through their eigenvectors."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he_c()
+    np.random.seed(1)
+    kpts = np.random.random((4, 3))
+    kpts[3] = kpts[0] - kpts[1] + kpts[2]
+    np.random.seed(1)
+    kpts_band = np.random.random((2, 3))
+    nao, nk = cell.nao_nr(), 4
+    mo_coeff = np.random.random((nk, nao, nao))
+    mo_occ = np.array(np.random.random((nk, nao)) > .6, dtype=np.double)
+    dms = np.einsum('kpi,ki,kqi->kpq', mo_coeff, mo_occ, mo_coeff)
+    df = ISDF(cell, kpts=kpts)
+    vk = df.get_k_exact(dms, mo_coeff=mo_coeff, mo_occ=mo_occ, kpts_band=kpts_band)
+    assert vk.shape == (2, nao, nao)
+    assert abs(otools.fp(vk) - (10.239828255099447 + 2.1190549216896182j)) < 1e-8
+    coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    ao_k = [np.asarray(x, dtype=complex) for x in oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpts=kpts, rule='point')]
+    ao_b = [np.asarray(x, dtype=complex) for x in oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpts=kpts_band, rule='point')]
+    vk_ref = fftdf.get_jk_kpts(ao_k, dms, cell.lattice_vectors(), cell.mesh, coords, kpts, ao_band=ao_b, kpts_band=kpts_band)[1]
+    assert abs(vk - vk_ref).max() < 1e-10 * abs(vk_ref).max()
+    part = df.get_k_exact(dms, mo_coeff=mo_coeff, mo_occ=mo_occ, kpts_band=kpts_band, rows=(1, 3), max_rows=int(mo_occ.sum(axis=1).max()))
+    assert abs(part - vk[:, 1:4]).max() < 1e-12
+    # SCF k-points themselves, orbitals recovered from Hermitian positive semidefinite matrices
+    rng = np.random.default_rng(5)
+    dmh = []
+    for k in range(nk):
+        c = np.linalg.qr(rng.standard_normal((nao, nao)) + 1j * rng.standard_normal((nao, nao)))[0][:, :2]
+        dmh.append(2 * c.dot(c.conj().T))
+    dmh = np.array(dmh)
+    vk2 = df.get_k_exact(dmh)
+    vk2_ref = fftdf.get_jk_kpts(ao_k, dmh, cell.lattice_vectors(), cell.mesh, coords, kpts)[1]
+    assert abs(vk2 - vk2_ref).max() < 1e-10 * abs(vk2_ref).max()

@@ -519,3 +519,71 @@ def test_oracle_kpoint_b88_potential_reproduces_the_reference_constant():
     n, exc, vxc = omg.nr_rks_b88_dense_kpts(ao4, dm, a)
     vj = offt.get_jk_kpts([x[0] for x in ao4], dm, a, mesh, coords, kpts)[0]
     assert abs(otools.fp(vxc + vj) - (-0.05697304864467462 + 0.6990367789096609j)) < 1e-7
+
+
+def _reference_embed_then_real_field(field, n, N):
+    """The reference's embedding of a level field (mesh n) into the dense mesh N: level spectrum at the numpy.fft.fftfreq indices
+    of the dense mesh - Nyquist entries of an even level mesh at -n/2 only (multigrid.py:669-673) - and the REAL part of the
+    inverse transform, which is all the reference ever uses of it (multigrid.py:1096, :915).  Returns the dense real field
+    (numpy ifft normalisation)."""
+    from oracle import multigrid as omg
+    sub = np.fft.fftn(field.reshape(n))
+    raw = np.zeros(N, dtype=complex)
+    gx, gy, gz = omg._freq_index(n, N)
+    raw[gx[:, None, None], gy[:, None], gz] = sub
+    return np.fft.ifftn(raw).real
+
+
+def _reference_restrict_real_field(dense_field, n, N):
+    """The reference's way back (multigrid.py:905-915): spectrum of the dense real field, the entries at the level's fftfreq
+    indices, inverse transform on the level mesh, real part."""
+    from oracle import multigrid as omg
+    gx, gy, gz = omg._freq_index(n, N)
+    sub = np.fft.fftn(dense_field.reshape(N))[gx[:, None, None], gy[:, None], gz]
+    return np.fft.ifftn(sub).real
+
+
+NYQUIST_CASES = [((4, 6, 8), (8, 12, 16)), ((6, 4, 8), (9, 8, 8)), ((4, 4, 4), (4, 4, 10)), ((5, 6, 4), (10, 6, 9)),
+                 ((8, 6, 10), (8, 6, 10))]
+
+
+def _check_nyquist_embed_restrict(be, tol):
+    import torch
+    rng = np.random.default_rng(11)
+    for n, N in NYQUIST_CASES:
+        gc = N[0] * N[1] * (N[2] // 2 + 1)
+        # level field with deliberate Nyquist content (white noise has all of it)
+        f = rng.standard_normal((2, int(np.prod(n))))
+        spec = be.zeros((2, gc), dtype=torch.complex128)
+        be.mg_embed_density(be.to_device(f), n, 1.0, spec, N, accumulate=True)
+        dense = be.empty((2, int(np.prod(N))))
+        be.mg_restrict_potential(spec, N, N, 1.0 / np.prod(N), dense)          # same mesh: the plain inverse transform
+        got = be.to_host(dense)
+        for i in range(2):
+            ref = _reference_embed_then_real_field(f[i], n, N).ravel()
+            assert abs(got[i] - ref).max() < tol * abs(ref).max(), (n, N)
+        # way back: a dense real field (all frequencies present) cut down to the level mesh
+        d = rng.standard_normal((2, int(np.prod(N))))
+        spec2 = be.zeros((2, gc), dtype=torch.complex128)
+        be.mg_embed_density(be.to_device(d), N, 1.0, spec2, N, accumulate=False)
+        lev = be.empty((2, int(np.prod(n))))
+        be.mg_restrict_potential(spec2, N, n, 1.0 / np.prod(n), lev)
+        got = be.to_host(lev)
+        for i in range(2):
+            ref = _reference_restrict_real_field(d[i], n, N).ravel()
+            assert abs(got[i] - ref).max() < tol * abs(ref).max(), (n, N)
+
+
+def test_checker_embed_restrict_follow_the_reference_on_nyquist_planes():
+    """Level fields with full Nyquist content through the checker backend's embed / restrict == the reference's index-list
+    embedding + .real (1e-13): even level meshes in x, y and z, dense meshes that are finer, equal or odd."""
+    from oracle_backend import OracleBackend
+    _check_nyquist_embed_restrict(OracleBackend(), 1e-13)
+
+
+@pytest.mark.gpu
+def test_gpu_embed_restrict_follow_the_reference_on_nyquist_planes():
+    """The same through isdf_mg_embed_density / isdf_mg_restrict_potential (half spectra on the device): the Hermitian form of
+    the reference's placement, weight 1/2 on proper Nyquist entries, +-n/2 averaged on the way back."""
+    from pyscf_isdf_amd.backend import HipBackend
+    _check_nyquist_embed_restrict(HipBackend(0), 1e-13)
