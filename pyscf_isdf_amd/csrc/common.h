@@ -58,6 +58,7 @@ struct isdf_ctx {
   // pair-density rows aoP ao: 0 = rocBLAS dgemm (default: 74 TF/s on that shape), 1 = the own MFMA NN kernel of gemm_f64.hip with
   // the square fused into its epilogue (66-71 TF/s; kept as the library-free route and for A/B runs)
   int gemm_nn_own = 0;
+  int block_apply_reg = 1;   // block apply with the block inverse in registers, persistent over column tiles (trsm.hip)
   // range-separation parameter of the Gamma-point Coulomb kernel table (0 = plain 1/r); isdf_set_coulomb_omega
   double coul_omega = 0.0;
   // spherical truncation radius of the Coulomb kernel (exxdiv='vcut_sph', pbc.py:312-317); 0 = none.  isdf_set_coulomb_cutoff

@@ -207,6 +207,147 @@ __global__ __launch_bounds__(256) void block_apply_mfma_kernel(const double* __r
   }
 }
 
+// Second form of the block apply (round 3): the block inverse lives in REGISTERS and the workgroup walks many column tiles.
+// The kernel above re-reads Dinv_b from L2 for every 32-column tile (6.9 M workgroups at configs[2], 100 KB each: more L2
+// traffic than the rows' own HBM traffic - it ran at 1.64 TB/s, latency-bound).  Here a workgroup owns ONE block and a
+// grid-stride set of 32-column tiles: every wave loads the rows of Dinv_b it needs once (row tiles w and NT-1-w of 16 rows
+// each - the lower triangle makes that pair's k range the same for every w: NT/2 + 1 chunks of 32 - as MFMA A fragments, 8
+// doubles per chunk and lane, k order permuted inside a chunk as above), then streams: the next tile's rows travel from global
+// memory into registers while the current tile's MFMAs run from LDS; one LDS buffer, two barriers per tile.  NCT = column
+// sub-tiles of 16 per tile (2: 32 columns = 256-byte row segments), both handled by every wave; waves = NT / 2 pairs.
+template <int NT, int NCT, bool SQ>
+__global__ __launch_bounds__(64 * ((NT + 1) / 2)) __attribute__((amdgpu_waves_per_eu(1, 2))) void block_apply_reg_kernel(const double* __restrict__ Dinv, int64_t ldd,
+                                                                            const int32_t* __restrict__ blk_off,
+                                                                            double* __restrict__ X, int64_t ldx, int64_t n) {
+  constexpr int TN = 16 * NCT;
+  constexpr int LDB = TN + 2;
+  constexpr int NPAIR = (NT + 1) / 2;
+  constexpr int NTHREADS = 64 * NPAIR;
+  constexpr int NCH = NT / 2 + 1;                       // chunks of 32 k per wave (tile w: (w + 2) / 2, tile NT-1-w: (NT + 1 - w) / 2)
+  constexpr int MP = 16 * NT;                           // padded rows
+  constexpr int NPRE = (MP * TN + NTHREADS - 1) / NTHREADS;
+  extern __shared__ double sB[];
+  const int b = blockIdx.y;
+  const int off = blk_off[b], m = blk_off[b + 1] - off;
+  if (m <= 0) return;
+  const int pair = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int tA = pair, tB = NT - 1 - pair;              // the two row tiles of this wave (tB == tA: the middle tile of an odd NT)
+  const int nchA = (tA + 2) / 2, nchB = (tB == tA) ? 0 : (tB + 2) / 2;
+  // A fragments: chunk c of the wave's list, 8 contiguous doubles of one row of Dinv_b per lane
+  double a[8 * NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const bool isA = c < nchA;
+    const int t = isA ? tA : tB;
+    const int k0 = 32 * (isA ? c : c - nchA) + 8 * fk;
+    const int row = t * 16 + fr;
+    const bool live = (c < nchA + nchB) && row < m;
+    const double* pa = Dinv + (int64_t)(off + (live ? row : 0)) * ldd + off + k0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[8 * c + j] = (live && k0 + j < m) ? pa[j] : 0.0;
+  }
+  const int64_t ntile = (n + TN - 1) / TN;
+  double pre[NPRE];
+  // this thread's elements of a tile: idx = threadIdx.x + i * NTHREADS -> (row idx / TN, column idx % TN)
+  const int r0 = threadIdx.x / TN, cc = threadIdx.x % TN;
+  constexpr int RSTEP = NTHREADS / TN;                  // NTHREADS is a multiple of TN (64 | NTHREADS, TN in {16, 32})
+  double* const Xrow = X + (int64_t)(off + r0) * ldx + cc;
+  auto fetch = [&](int64_t tile) {
+    const int64_t c0 = tile * TN;
+    const bool colok = c0 + cc < n;
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int r = r0 + i * RSTEP;
+      pre[i] = (r < m && colok) ? Xrow[(int64_t)i * RSTEP * ldx + c0] : 0.0;
+    }
+  };
+  int64_t tile = blockIdx.x;
+  if (tile < ntile) fetch(tile);
+  for (; tile < ntile; tile += gridDim.x) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int r = r0 + i * RSTEP;
+      if (r < MP) {
+        const double v = pre[i];
+        sB[r * LDB + cc] = SQ ? v * v : v;
+      }
+    }
+    __syncthreads();
+    if (tile + gridDim.x < ntile) fetch(tile + gridDim.x);            // in flight under the MFMAs below
+    d4v accA[NCT], accB[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) accA[ct] = accB[ct] = (d4v){0.0, 0.0, 0.0, 0.0};
+    const double* pb = sB + (8 * fk) * LDB + fr;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c < nchA) {
+        const double* q = pb + (32 * c) * LDB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+            accA[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[8 * c + j], q[j * LDB + 16 * ct], accA[ct], 0, 0, 0);
+      } else if (c < nchA + nchB) {
+        const double* q = pb + (32 * (c - nchA)) * LDB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+            accB[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[8 * c + j], q[j * LDB + 16 * ct], accB[ct], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);       // keep a chunk's LDS reads with its MFMAs: hoisting all of them costs 100+ VGPRs
+    }
+    const int64_t c0 = tile * TN;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int64_t col = c0 + ct * 16 + fr;
+      if (col < n) {
+        double* Xb = X + (int64_t)off * ldx + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rowA = tA * 16 + fk + 4 * r;
+          if (rowA < m) Xb[(int64_t)rowA * ldx] = accA[ct][r];
+          if (nchB > 0) {
+            const int rowB = tB * 16 + fk + 4 * r;
+            if (rowB < m) Xb[(int64_t)rowB * ldx] = accB[ct][r];
+          }
+        }
+      }
+    }
+    __syncthreads();                                                   // every wave is done with the tile in LDS
+  }
+}
+
+template <int NT, int NCT>
+static int block_apply_reg_launch(isdf_handle h, const double* Dinv, int64_t ldd, int nblk, const int32_t* d_off, double* X,
+                                  int64_t ldx, int64_t n, bool sq) {
+  constexpr int TN = 16 * NCT;
+  constexpr int NTHREADS = 64 * ((NT + 1) / 2);
+  static_assert(NTHREADS % TN == 0 && (16 * NT * TN) % NTHREADS == 0, "tile elements must divide evenly over the threads");
+  const size_t lds = (size_t)16 * NT * (TN + 2) * sizeof(double);
+  const int64_t ntile = (n + TN - 1) / TN;
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntile, ((int64_t)h->num_cu * 4 + nblk - 1) / nblk));
+  if (sq) {
+    if (lds > 64 * 1024)
+      HIP_TRY(h, hipFuncSetAttribute((const void*)&block_apply_reg_kernel<NT, NCT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(block_apply_reg_kernel<NT, NCT, true>), dim3(gx, (unsigned)nblk), dim3(NTHREADS), lds, h->stream,
+                       Dinv, ldd, d_off, X, ldx, n);
+  } else {
+    if (lds > 64 * 1024)
+      HIP_TRY(h, hipFuncSetAttribute((const void*)&block_apply_reg_kernel<NT, NCT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(block_apply_reg_kernel<NT, NCT, false>), dim3(gx, (unsigned)nblk), dim3(NTHREADS), lds, h->stream,
+                       Dinv, ldd, d_off, X, ldx, n);
+  }
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+template <int TN, bool SQ>
+static hipError_t block_apply_lds_attr() {
+  return hipFuncSetAttribute((const void*)&block_apply_mfma_kernel<TN, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 int block_apply_inverse(isdf_handle h, const double* Dinv, int64_t ldd, int nblk, const int32_t* blk_off_host, double* X,
                         int64_t ldx, int64_t n, bool square_input) {
   ARG_CHECK(h, Dinv && X && blk_off_host && nblk > 0 && n > 0 && nblk <= 65535);
@@ -218,10 +359,24 @@ int block_apply_inverse(isdf_handle h, const double* Dinv, int64_t ldd, int nblk
   if (!d_off) return ISDF_ERR_HIP;
   HIP_TRY(h, hipMemcpyAsync(d_off, blk_off_host, sizeof(int32_t) * (size_t)(nblk + 1), hipMemcpyHostToDevice, h->stream));
   ProfScope ps(h, "block_apply_mfma_kernel[byte]", 16.0 * (double)blk_off_host[nblk] * (double)n);
+  // register-resident form for blocks of up to 256 rows (option "block_apply_reg", default on)
+  if (h->block_apply_reg && mmax <= 256) {
+    const int nt = (mmax + 15) / 16;
+    if (nt <= 8) return block_apply_reg_launch<8, 2>(h, Dinv, ldd, nblk, d_off, X, ldx, n, square_input);
+    if (nt <= 10) return block_apply_reg_launch<10, 2>(h, Dinv, ldd, nblk, d_off, X, ldx, n, square_input);
+    if (nt <= 12) return block_apply_reg_launch<12, 1>(h, Dinv, ldd, nblk, d_off, X, ldx, n, square_input);
+    return block_apply_reg_launch<16, 1>(h, Dinv, ldd, nblk, d_off, X, ldx, n, square_input);
+  }
   // 64 columns per workgroup while the block's rows fit 52 KB of LDS (three workgroups per CU), else 32, else 16
+  // more than 64 KB of dynamic LDS needs the attribute raised once per instantiation (per device: kept in the handle's option map)
 #define ISDF_BA_LAUNCH(TN_, SQ_)                                                                                       \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(block_apply_mfma_kernel<TN_, SQ_>), dim3((unsigned)cdiv(n, TN_), (unsigned)nblk),     \
-                     dim3(256), (size_t)mpad * (TN_ + 2) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n)
+  do {                                                                                                                 \
+    if ((size_t)mpad * (TN_ + 2) * sizeof(double) > 64 * 1024) {                                                       \
+      HIP_TRY(h, (block_apply_lds_attr<TN_, SQ_>()));                                                                  \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(block_apply_mfma_kernel<TN_, SQ_>), dim3((unsigned)cdiv(n, TN_), (unsigned)nblk),   \
+                       dim3(256), (size_t)mpad * (TN_ + 2) * sizeof(double), h->stream, Dinv, ldd, d_off, X, ldx, n);  \
+  } while (0)
   if ((size_t)mpad * (64 + 2) * sizeof(double) <= 52 * 1024) {
     if (square_input) ISDF_BA_LAUNCH(64, true); else ISDF_BA_LAUNCH(64, false);
   } else if ((size_t)mpad * (32 + 2) * sizeof(double) <= 80 * 1024) {

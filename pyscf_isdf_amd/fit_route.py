@@ -31,8 +31,8 @@ class FitRouteMixin:
     def _block_inverse(self, Dblk, ip_off):
         """blockdiag(D_b^-1) for the MFMA form of the block solves over the grid (isdf_block_apply); formed once per build
         from the factors every rank holds.  None when block_apply_mfma is off (then: substitution, isdf_block_solve)."""
-        if not self.block_apply_mfma:
-            return None
+        if not self.block_apply_mfma or int(np.diff(np.asarray(ip_off)).max()) > 1100:
+            return None                                  # (the MFMA kernel stages a block's rows in LDS: 160 KB hold 1137 of them)
         key = (Dblk.data_ptr(), getattr(self, '_build_serial', 0), len(ip_off))
         if getattr(self, '_Dinv_key', None) != key:
             Dinv = self._buffer('Dinv', tuple(Dblk.shape))
@@ -250,11 +250,34 @@ class FitRouteMixin:
         return ['blockjacobi', 'cholesky']
 
     def _bj_probe_densities(self, aoT_P):
-        """t_j = diag(phi_P R_j phi_P^T) at the points for the fixed random symmetric probe matrices R_j: (n, P)."""
+        """Probe densities at the points, (n, P): t_j = diag(phi_P R_j phi_P^T) for fixed random symmetric matrices R_j in the
+        AO x AO pair space; t_j = diag(phi_P R_j psi_P^T) with random (N, nocc) matrices R_j in the (AO x occupied) pair space -
+        the probes have to lie in the span the fit represents: outside it t^T W t is dominated by the badly determined
+        directions of the Gram matrix, which the exchange never sees (measured: AO-pair probes read 2e-6 on an
+        (AO x occupied) fit whose K equals the Cholesky route's to 1e-10)."""
         be = self.backend
         planes = aoT_P if isinstance(aoT_P, (list, tuple)) else [aoT_P]
         nao, P = planes[0].shape
         n = int(self.bj_nprobe)
+        if getattr(self, '_psi', None) is not None and len(planes) == 1:
+            psiP = self._psiP
+            nocc = psiP.shape[1]
+            cached = getattr(self, '_probe_Rocc', None)
+            if cached is None or cached[0] != (n, nao, nocc):
+                rng = np.random.default_rng(20240203)
+                self._probe_Rocc = ((n, nao, nocc), be.to_device(rng.standard_normal((n, nao, nocc))))
+            d_R = self._probe_Rocc[1]
+            aoP = planes[0].T.contiguous()                  # (P, nao)
+            ones = be.to_device(np.ones((nocc, 1)))
+            T = be.empty((n, P))
+            tmp = be.empty((P, nocc))
+            col = be.empty((P, 1))
+            for j in range(n):
+                be.gemm_nn(aoP, d_R[j], tmp)
+                be.hadamard_rows(tmp, psiP)
+                be.gemm_nn(tmp, ones, col)
+                T[j].copy_(col[:, 0])
+            return T
         # the probe matrices R_j (random symmetric, fixed seed) are kept on the device: drawing n nao^2 normals
         # costs 0.2 s at nao = 1664
         cached = getattr(self, '_probe_R', None)

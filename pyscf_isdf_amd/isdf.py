@@ -533,35 +533,49 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
     def _build_paneled(self, rank, clusters, d_ip, rows_buf, rows_panel, t0):
         """S3c + S4 + S5 with the fit rows produced panel by panel (more points than HBM holds rows for): block-Jacobi
         route only - its rows depend on their own preconditioner block alone, so a panel can be recomputed at will.  The
-        probe check runs alongside (its combination rows are accumulated panel by panel); there is no second route to fall
-        back to here, a failed check is reported as a warning and in bj_check."""
+        probe check runs alongside (its combination rows are accumulated panel by panel).  There is no Cholesky route to fall
+        back to here (its rows depend on all earlier rows); a failed check rebuilds ONCE with pairs of clusters merged into
+        one preconditioner block (a better-conditioned A', twice the block-solve flops) and raises if that fails too."""
         be = self.backend
         P = len(self.ip)
         nao, G = self.ao.shape
-        ip_off = self._bj_blocks(rank, clusters)
-        Afac, Dblk = self._bj_prepare(self.ao, 0, d_ip, ip_off, self.aoP, scratch=self.W)
-        panels = self._panel_plan(ip_off, min(rows_panel, rows_buf))
-        rows = self._buffer('theta', (rows_buf, G))
-        self._fit_state = dict(kind='blockjacobi-paneled', rows=rows, panels=panels, Afac=Afac, Dblk=Dblk, ip_off=ip_off)
-        t0 = self._tick('S3_fit', t0)
-        probe = None
-        if self.fit_route == 'auto':
-            aoT = be.empty((nao, P))
-            be.gather_cols(self.ao, d_ip, aoT)
-            T0, E = self._bj_probe_vectors(aoT, Afac, Dblk, ip_off)
-            del aoT
-            probe = (E, be.empty((E.shape[0], G)))
-        self._finish_W_paneled(self.W, probe=probe)
-        t0 = self._tick('S4S5_coulomb_W', t0)
-        self.fit_route_used = 'blockjacobi'
-        self.n_panels = len(panels)
-        if probe is not None:
-            self.bj_check = self._bj_probe_energies(T0, probe[1], self.W, None)
-            t0 = self._tick('S5_route_check', t0)
-            if self.bj_check > self.bj_check_tol:
-                warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e) in a paneled build, '
-                              'where the Cholesky route is not available: W carries rounding noise of that relative size'
-                              % (self.bj_check, self.bj_check_tol))
+        group0 = int(self.bj_group)
+        try:
+            for attempt in range(2):
+                ip_off = self._bj_blocks(rank, clusters)
+                Afac, Dblk = self._bj_prepare(self.ao, 0, d_ip, ip_off, self.aoP, scratch=self.W)
+                panels = self._panel_plan(ip_off, min(rows_panel, rows_buf))
+                rows = self._buffer('theta', (rows_buf, G))
+                self._fit_state = dict(kind='blockjacobi-paneled', rows=rows, panels=panels, Afac=Afac, Dblk=Dblk, ip_off=ip_off)
+                t0 = self._tick('S3_fit', t0)
+                probe = None
+                if self.fit_route == 'auto':
+                    aoT = be.empty((nao, P))
+                    be.gather_cols(self.ao, d_ip, aoT)
+                    T0, E = self._bj_probe_vectors(aoT, Afac, Dblk, ip_off)
+                    del aoT
+                    probe = (E, be.empty((E.shape[0], G)))
+                self._finish_W_paneled(self.W, probe=probe)
+                t0 = self._tick('S4S5_coulomb_W', t0)
+                self.fit_route_used = 'blockjacobi'
+                self.n_panels = len(panels)
+                if probe is None:
+                    return
+                self.bj_check = self._bj_probe_energies(T0, probe[1], self.W, None)
+                t0 = self._tick('S5_route_check', t0)
+                if self.bj_check <= self.bj_check_tol:
+                    return
+                if attempt == 0:
+                    warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e) in a paneled build, where '
+                                  'the Cholesky route is not available: rebuilding with pairs of clusters merged into one '
+                                  'preconditioner block' % (self.bj_check, self.bj_check_tol))
+                    self.bj_group = 2 * group0
+            raise RuntimeError('ISDF: the paneled block-Jacobi build failed its probe check twice (mismatch %.2e > bj_check_tol = '
+                               '%.2e): W would carry rounding noise of that relative size.  Use fewer points (c_isdf), more GPUs '
+                               '(the rows then fit and the Cholesky route is available), or raise bj_check_tol knowingly.'
+                               % (self.bj_check, self.bj_check_tol))
+        finally:
+            self.bj_group = group0
 
     def _local_ao_rows(self, ao_sel, out_rows, blk_off, a):
         """Candidate stage with local AOs: for the block of atom b keep only the AO rows of atoms within cand_ao_cutoff of b

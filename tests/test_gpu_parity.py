@@ -892,7 +892,8 @@ def test_block_jacobi_route_building_blocks(be):
     assert abs(be.to_host(W) - Ai.dot(M).dot(Ai)).max() < 1e-9 * abs(Ai.dot(M).dot(Ai)).max()
 
 
-@pytest.mark.parametrize('sizes,n', [([156, 130, 7, 64, 201], 1000), ([16], 33), ([100, 100], 64), ([330, 5], 257)])
+@pytest.mark.parametrize('sizes,n', [([156, 130, 7, 64, 201], 1000), ([16], 33), ([100, 100], 64), ([330, 5], 257), ([280], 100),
+                                     ([500, 40], 70), ([1100], 40)])
 def test_block_invert_and_mfma_block_apply(be, sizes, n):
     """isdf_block_invert + isdf_block_apply (explicit block inverses applied with v_mfma_f64_16x16x4, ragged blocks, ragged
     column tiles, the three column-tile widths) against numpy triangular solves: Dinv exact zeros above the diagonal and
@@ -923,6 +924,14 @@ def test_block_invert_and_mfma_block_apply(be, sizes, n):
     assert np.all(Dinv[~mask] == 0.0)
     be.block_apply(dI, off, dX)
     assert abs(be.to_host(dX) - ref).max() < 1e-12 * abs(ref).max()
+    # the round-2 kernel (Dinv from L2 per column tile) behind the option gives the same answer
+    be.set_option('block_apply_reg', 0)
+    try:
+        dX2 = be.to_device(X)
+        be.block_apply(dI, off, dX2)
+        assert abs(be.to_host(dX2) - ref).max() < 1e-12 * abs(ref).max()
+    finally:
+        be.set_option('block_apply_reg', 1)
     # the fused form: rows <- Dinv_b (aoP ao)^2 with the square applied while the block apply stages its input
     aoP, ao = rng.standard_normal((P, 9)), rng.standard_normal((9, n))
     B = aoP.dot(ao) ** 2

@@ -88,17 +88,37 @@ del df
 for v in variants:
     parts = v.split(':')
     sel, cc, space = parts[0], int(parts[1]), parts[2]
-    robust = len(parts) > 3 and parts[3] == 'robust'
+    flags = parts[3:]
+    robust = 'robust' in flags
     d2 = ISDF(cell, c_isdf=cc, select=sel)
     d2.pair_space = space
     d2.robust_k = robust
+    if 'bj' in flags:                               # force the block-Jacobi route (no Cholesky fallback), report its probe check
+        d2.fit_route = 'blockjacobi'
+    if 'chol' in flags:
+        d2.fit_route = 'cholesky'
+    for f_ in flags:
+        if f_.startswith('g') and f_[1:].isdigit():     # merge this many consecutive atom clusters per preconditioner block
+            d2.bj_group = int(f_[1:])
+        if f_.startswith('reg') :
+            d2.reg_rel = float(f_[3:])
     try:
         t1 = time.perf_counter()
         vk = d2.get_jk(tdm, with_j=False)[1]
         dt = time.perf_counter() - t1
-        print('%-26s P=%6d  build+K %6.2f s  dE_K %+.3e Eh (%.1e per atom)  max|dK| %.2e  route %s panels %d  %s'
+        if 'bj' in flags and d2.n_panels == 1:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                be2 = d2.backend
+                aoT = be2.empty((nao, len(d2.ip)))
+                be2.gather_cols(d2.ao, be2.to_device(d2.ip), aoT)
+                st = d2._fit_state
+                d2.bj_check = d2._bj_probe_mismatch(aoT, st['Afac'], st['Dblk'], st['ip_off'], st['theta'], G, None)
+                del aoT
+        print('%-30s P=%6d  build+K %6.2f s  dE_K %+.3e Eh (%.1e per atom)  max|dK| %.2e  route %s panels %d probe %s  %s'
               % (v, len(d2.ip), dt, np.einsum('ij,ji', vk, dm) / 4 - ek_ex, abs(np.einsum('ij,ji', vk, dm) / 4 - ek_ex) / cell.natm,
-                 abs(vk - vk_ex).max(), d2.fit_route_used, d2.n_panels, {k: round(x, 2) for k, x in d2.timings.items()}), flush=True)
+                 abs(vk - vk_ex).max(), d2.fit_route_used, d2.n_panels, ('%.1e' % d2.bj_check) if d2.bj_check is not None else '-', {k: round(x, 2) for k, x in d2.timings.items()}), flush=True)
     except Exception as ex:                                   # noqa: BLE001 - a variant that does not fit in memory is reported, not fatal
         print('%-26s FAILED: %s' % (v, str(ex)[:300]), flush=True)
     d2.reset()
