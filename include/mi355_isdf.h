@@ -451,6 +451,8 @@ int isdf_hadamard_rows(isdf_handle h, double* d_X, int64_t ldx, const double* d_
  *   isdf_mg_coulomb_kernel:     spec[set] *= coulG of the handle's kernel state (multigrid.py:522-525)
  *   isdf_lda_exchange:          Slater exchange of a spin-unpolarised density: exc per particle and vxc = d(rho exc)/d rho
  *                               ('lda,' of multigrid.py:1104-1106; densities <= 1e-24 give zero)
+ *   isdf_lda_vwn_add:           exc += eps_c, vxc += v_c of the VWN5 correlation (libxc LDA_C_VWN: with isdf_lda_exchange the
+ *                               reference's 'lda,vwn', pinned by pyscf/pbc/dft/test/test_krks.py:91-126; closed shell)
  *   isdf_gga_b88:               Becke-88 exchange ('b88,') of a spin-unpolarised density from rho and grad rho (three planes,
  *                               gstride apart): exc per particle, vrho = de/drho and w = de/d(grad rho) = 2 vsigma grad rho (three
  *                               planes, wstride apart); rho <= 1e-14 gives zero
@@ -466,6 +468,7 @@ int isdf_mg_restrict_potential(isdf_handle h, const double* d_spec, int nset, co
                                const int32_t mesh_sub[3], double scale, double* d_field);
 int isdf_mg_coulomb_kernel(isdf_handle h, double* d_spec, int nset, const int32_t mesh[3], const double a[9]);
 int isdf_lda_exchange(isdf_handle h, const double* d_rho, int64_t n, double* d_exc, double* d_vxc);
+int isdf_lda_vwn_add(isdf_handle h, const double* d_rho, int64_t n, double* d_exc, double* d_vxc);
 int isdf_gga_b88(isdf_handle h, const double* d_rho, const double* d_grad, int64_t gstride, int64_t n, double* d_exc,
                  double* d_vrho, double* d_w, int64_t wstride);
 int isdf_lda_exchange_fxc(isdf_handle h, const double* d_rho, int64_t n, double* d_fxc);

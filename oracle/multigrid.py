@@ -238,8 +238,45 @@ def slater_exchange(rho):
     return e, 4.0 / 3.0 * e
 
 
-def nr_rks_lda(tasks, atm, dm, a, fft_mesh, with_j=False):
-    """(nelec, exc, veff, ecoul) of one density matrix: multigrid.py:1046-1150 with xc = 'lda,' (Slater exchange)."""
+VWN5 = (0.0310907, 3.72744, 12.9352, -0.10498)          # A (Hartree), b, c, x0: Vosko-Wilk-Nusair parametrisation V, paramagnetic
+
+
+def vwn_correlation(rho):
+    """Spin-unpolarised VWN5 correlation (libxc LDA_C_VWN, what the reference's 'lda,vwn' evaluates through
+    pyscf/dft/libxc.py; Vosko, Wilk, Nusair, Can. J. Phys. 58, 1200 (1980), eq. 4.4 with the paramagnetic parameters of fit V):
+        eps_c = A { ln(x^2/X) + 2b/Q atan(Q/(2x+b)) - b x0/X(x0) [ ln((x-x0)^2/X) + 2(b+2x0)/Q atan(Q/(2x+b)) ] },
+        x = sqrt(rs), X(x) = x^2 + b x + c, Q = sqrt(4c - b^2);   v_c = eps_c - (x/6) d eps_c/dx.
+    Returns (eps_c per particle, v_c); rho <= 1e-24 -> 0 like the exchange."""
+    A, b, c, x0 = VWN5
+    e = np.zeros_like(rho)
+    v = np.zeros_like(rho)
+    m = rho > 1e-24
+    rs = np.cbrt(3.0 / (4.0 * np.pi * rho[m]))
+    x = np.sqrt(rs)
+    X = x * x + b * x + c
+    X0 = x0 * x0 + b * x0 + c
+    Q = np.sqrt(4.0 * c - b * b)
+    at = np.arctan(Q / (2.0 * x + b))
+    ec = A * (np.log(x * x / X) + 2.0 * b / Q * at - b * x0 / X0 * (np.log((x - x0) ** 2 / X) + 2.0 * (b + 2.0 * x0) / Q * at))
+    den = Q * Q + (2.0 * x + b) ** 2
+    dec = A * (2.0 / x - (2.0 * x + b) / X - 4.0 * b / den
+               - b * x0 / X0 * (2.0 / (x - x0) - (2.0 * x + b) / X - 4.0 * (b + 2.0 * x0) / den))
+    e[m] = ec
+    v[m] = ec - x / 6.0 * dec
+    return e, v
+
+
+def lda_xc(rho, xc='lda,'):
+    """(exc per particle, vxc) of 'lda,' (Slater exchange) or 'lda,vwn' (+ VWN5 correlation)."""
+    e, v = slater_exchange(rho)
+    if xc.replace(' ', '').lower() in ('lda,vwn', 'lda,vwn5', 'svwn', 'slater,vwn', 'slater,vwn5'):
+        ec, vc = vwn_correlation(rho)
+        e, v = e + ec, v + vc
+    return e, v
+
+
+def nr_rks_lda(tasks, atm, dm, a, fft_mesh, with_j=False, xc='lda,'):
+    """(nelec, exc, veff, ecoul) of one density matrix: multigrid.py:1046-1150 with xc = 'lda,' (Slater exchange) or 'lda,vwn'."""
     a = np.asarray(a, dtype=float)
     nao = np.asarray(dm).shape[-1]
     fft_mesh = np.asarray(fft_mesh)
@@ -253,7 +290,7 @@ def nr_rks_lda(tasks, atm, dm, a, fft_mesh, with_j=False):
     ecoul /= vol
     rhoR = tools.ifft(rhoG.reshape(1, ngrids), fft_mesh).real / weight
     nelec = rhoR[0].sum() * weight
-    exc, vxc = slater_exchange(rhoR[0])
+    exc, vxc = lda_xc(rhoR[0], xc)
     excsum = (rhoR[0] * exc).sum() * weight
     wv_freq = tools.fft((weight * vxc)[None], fft_mesh).reshape(rhoG.shape)
     if with_j:
@@ -262,13 +299,13 @@ def nr_rks_lda(tasks, atm, dm, a, fft_mesh, with_j=False):
     return nelec, excsum, veff, ecoul
 
 
-def nr_rks_lda_dense(aoR, dm, a, fft_mesh):
+def nr_rks_lda_dense(aoR, dm, a, fft_mesh, xc='lda,'):
     """The same quantities on the dense grid alone (role of pyscf.pbc.dft.numint.nr_rks for 'lda,' on uniform grids, which the
     reference's multigrid tests use as their answer: test_multigrid.py:133-142).  aoR (G, nao)."""
     ngrids = len(aoR)
     weight = abs(np.linalg.det(a)) / ngrids
     rho = np.einsum('gi,ij,gj->g', aoR, 0.5 * (dm + dm.T), aoR, optimize=True)
-    exc, vxc = slater_exchange(rho)
+    exc, vxc = lda_xc(rho, xc)
     veff = aoR.T.dot((weight * vxc)[:, None] * aoR)
     return rho.sum() * weight, (rho * exc).sum() * weight, veff
 

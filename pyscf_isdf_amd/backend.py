@@ -499,6 +499,12 @@ class HipBackend:
         assert rho.is_contiguous() and exc.is_contiguous() and vxc.is_contiguous()
         self.handle.call('isdf_lda_exchange', self._p(rho), rho.numel(), self._p(exc), self._p(vxc))
 
+    def lda_vwn_add(self, rho, exc, vxc):
+        """exc += eps_c, vxc += v_c (VWN5 correlation, closed shell)."""
+        self._stream()
+        assert rho.is_contiguous() and exc.is_contiguous() and vxc.is_contiguous()
+        self.handle.call('isdf_lda_vwn_add', self._p(rho), rho.numel(), self._p(exc), self._p(vxc))
+
     def gga_b88(self, rho, grad, exc, vrho, w):
         """rho (G,), grad (3, G) -> exc, vrho (G,), w (3, G) = de/d(grad rho)."""
         self._stream()

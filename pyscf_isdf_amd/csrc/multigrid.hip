@@ -144,6 +144,29 @@ __global__ void lda_exchange_kernel(const double* __restrict__ rho, int64_t n, d
   vxc[i] = (4.0 / 3.0) * e;
 }
 
+// VWN5 correlation of a spin-unpolarised density (libxc LDA_C_VWN, the correlation of the reference's 'lda,vwn'; Vosko, Wilk,
+// Nusair, Can. J. Phys. 58, 1200 (1980), eq. 4.4, paramagnetic parameters of fit V: A = 0.0310907, b = 3.72744, c = 12.9352,
+// x0 = -0.10498), ADDED to exc / vxc:  eps_c = A { ln(x^2/X) + 2b/Q atan(Q/(2x+b)) - b x0/X(x0) [ ln((x-x0)^2/X) +
+// 2(b+2 x0)/Q atan(Q/(2x+b)) ] },  x = sqrt(rs), X = x^2 + b x + c, Q = sqrt(4c - b^2);  v_c = eps_c - (x/6) d eps_c/dx.
+__global__ void lda_vwn_add_kernel(const double* __restrict__ rho, int64_t n, double* __restrict__ exc, double* __restrict__ vxc) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double r = rho[i];
+  if (!(r > 1e-24)) return;
+  const double A = 0.0310907, b = 3.72744, c = 12.9352, x0 = -0.10498;
+  const double rs = cbrt(3.0 / (4.0 * 3.14159265358979323846 * r));
+  const double x = sqrt(rs);
+  const double X = x * x + b * x + c, X0 = x0 * x0 + b * x0 + c;
+  const double Q = sqrt(4.0 * c - b * b);
+  const double at = atan(Q / (2.0 * x + b));
+  const double ec = A * (log(x * x / X) + 2.0 * b / Q * at - b * x0 / X0 * (log((x - x0) * (x - x0) / X) + 2.0 * (b + 2.0 * x0) / Q * at));
+  const double den = Q * Q + (2.0 * x + b) * (2.0 * x + b);
+  const double dec = A * (2.0 / x - (2.0 * x + b) / X - 4.0 * b / den
+                          - b * x0 / X0 * (2.0 / (x - x0) - (2.0 * x + b) / X - 4.0 * (b + 2.0 * x0) / den));
+  exc[i] += ec;
+  vxc[i] += ec - x / 6.0 * dec;
+}
+
 // Becke-88 exchange of a spin-unpolarised density (libxc GGA_X_B88; Becke, PRA 38, 3098): per spin channel
 // f(rho_s, g_s) = rho_s^(4/3) G(x), x = g_s / rho_s^(4/3), G = -C_x - beta x^2 / (1 + 6 beta x asinh x), C_x = (3/2)(3/4pi)^(1/3),
 // beta = 0.0042; e(rho, grad rho) = 2 f(rho/2, |grad rho|/2).  Outputs: exc = e / rho, vrho = de/drho, and the vector
@@ -335,6 +358,14 @@ extern "C" int isdf_lda_exchange(isdf_handle h, const double* d_rho, int64_t n, 
   if (!h) return ISDF_ERR_ARG;
   ARG_CHECK(h, d_rho && d_exc && d_vxc && n > 0);
   hipLaunchKernelGGL(lda_exchange_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, d_rho, n, d_exc, d_vxc);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_lda_vwn_add(isdf_handle h, const double* d_rho, int64_t n, double* d_exc, double* d_vxc) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_rho && d_exc && d_vxc && n > 0);
+  hipLaunchKernelGGL(lda_vwn_add_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, d_rho, n, d_exc, d_vxc);
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

@@ -92,6 +92,7 @@ SIGNATURES = {
     'isdf_mg_restrict_potential': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_dbl, c_vp]),
     'isdf_mg_coulomb_kernel': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp]),
     'isdf_lda_exchange': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    'isdf_lda_vwn_add': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     'isdf_gga_b88': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64]),
     'isdf_lda_exchange_fxc': (c_int, [c_vp, c_vp, c_i64, c_vp]),
     'isdf_dot': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),

@@ -273,11 +273,17 @@ class TaggedArray(np.ndarray):
 
 
 def _xc_kind(xc_code):
-    """'lda' (Slater exchange), 'b88' (Becke-88 exchange, a GGA) or None."""
+    """'lda' (Slater exchange, with or without VWN5 correlation: _has_vwn), 'b88' (Becke-88 exchange, a GGA) or None."""
     code = str(xc_code).replace(' ', '').upper()
     if code in ('B88,', 'B88', 'GGA_X_B88,', 'GGA_X_B88'):
         return 'b88'
-    return 'lda' if _is_slater(xc_code) else None
+    return 'lda' if (_is_slater(xc_code) or _has_vwn(xc_code)) else None
+
+
+def _has_vwn(xc_code):
+    """'lda,vwn' (= Slater exchange + VWN5 correlation, libxc LDA_X + LDA_C_VWN; also spelled 'svwn', 'lda,vwn5')."""
+    code = str(xc_code).replace(' ', '').upper()
+    return code in ('LDA,VWN', 'LDA,VWN5', 'SLATER,VWN', 'SLATER,VWN5', 'SVWN', 'SVWN5', 'LDA_X,LDA_C_VWN', 'LDA,LDA_C_VWN')
 
 
 def _is_slater(xc_code):
@@ -747,8 +753,8 @@ def nr_rks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
     adds the Coulomb potential to veff before the integration pass (one pass for J + XC)."""
     kind = _xc_kind(xc_code)
     if kind is None:
-        raise NotImplementedError("xc=%r: 'lda,' (Slater exchange) and 'b88,' (Becke-88 exchange) are implemented (no libxc in this "
-                                  "tree)" % (xc_code,))
+        raise NotImplementedError("xc=%r: 'lda,' (Slater exchange), 'lda,vwn' (+ VWN5 correlation) and 'b88,' (Becke-88 exchange) are "
+                                  "implemented (no libxc in this tree)" % (xc_code,))
     if kpts is None:
         kpts = mydf.kpts
     be, cell = mydf.backend, mydf.cell
@@ -788,6 +794,8 @@ def nr_rks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
     nelec, excsum, ecoul = np.zeros(nset), np.zeros(nset), np.zeros(nset)
     for i in range(nset):
         be.lda_exchange(rho[i], exc[i], vxc[i])
+        if _has_vwn(xc_code):
+            be.lda_vwn_add(rho[i], exc[i], vxc[i])
         nelec[i] = be.dot(rho[i]) * weight
         excsum[i] = be.dot(rho[i], exc[i]) * weight
         ecoul[i] = 0.5 * be.dot(rho[i], vH[i]) * weight
@@ -861,6 +869,8 @@ def nr_uks(mydf, xc_code, dm_kpts, hermi=1, kpts=None, kpts_band=None, with_j=Fa
     k-points.  Returns (nelec [both spins together], exc, veff (2, ...)); Slater exchange by spin scaling,
     E_x[rho_a, rho_b] = (E_x[2 rho_a] + E_x[2 rho_b]) / 2, v_a = v_x[2 rho_a]; the Coulomb potential of with_j is that of the
     total density."""
+    if _has_vwn(xc_code):
+        raise NotImplementedError("xc=%r: the spin-polarised VWN correlation is not implemented (closed-shell nr_rks only)" % (xc_code,))
     kind = _xc_kind(xc_code)
     if kind is None:
         raise NotImplementedError("xc=%r: 'lda,' (Slater exchange) and 'b88,' (Becke-88 exchange) are implemented (no libxc in this "

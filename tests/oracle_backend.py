@@ -132,6 +132,12 @@ class OracleBackend:
         exc.copy_(torch.from_numpy(e))
         vxc.copy_(torch.from_numpy(v))
 
+    def lda_vwn_add(self, rho, exc, vxc):
+        from oracle import multigrid as omg
+        e, v = omg.vwn_correlation(rho.numpy())
+        exc += torch.from_numpy(e)
+        vxc += torch.from_numpy(v)
+
     def gga_b88(self, rho, grad, exc, vrho, w):
         from oracle import multigrid as omg
         e, vr, ww = omg.b88_exchange(rho.numpy(), grad.numpy())

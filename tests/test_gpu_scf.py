@@ -95,6 +95,28 @@ def test_diamond_rhf_lda_and_b88_rks_total_energies_match_reference():
     assert abs(e_hf - (-10.137043711032916)) < 5e-8             # measured: 6.0e-9
 
 
+def test_diamond_rks_lda_vwn_total_energy_matches_reference():
+    """RKS 'lda,vwn' on the diamond primitive cell, gth-szv / gth-pade, 17^3 (pyscf/pbc/dft/test/test_krks.py:59-71,112-119):
+    e_tot = -10.221426445656439 (places=7 in the reference).  J + the Slater + VWN5 potential from the device's multigrid ladder
+    (isdf_lda_exchange + isdf_lda_vwn_add), get_pp from the device - a full exchange-correlation functional under the
+    multigrid row of SURVEY section 8 (f-3), pinned to a reference constant."""
+    from pyscf_isdf_amd import multigrid as pmg
+    cell = gto.Cell(unit='A', atom='C 0. 0. 0.; C 0.8917 0.8917 0.8917', a=[[0., 1.7834, 1.7834], [1.7834, 0., 1.7834], [1.7834, 1.7834, 0.]],
+                    basis='gth-szv', pseudo='gth-pade', mesh=[17] * 3)
+    S, T = scf_helpers.overlap_kinetic_from_ft(cell)
+    df = pmg.MultiGridFFTDF(cell, c_isdf=6, select='global')
+    df.split = 'all'
+    hcore = T + df.get_pp()
+    e_nuc = scf_helpers.ewald_energy(cell)
+
+    def veff(dm):
+        n, exc, v = pmg.nr_rks(df, 'lda,vwn', dm, with_j=True)
+        assert abs(n - 8.0) < 1e-6
+        return np.asarray(v), float(v.ecoul), float(exc)
+    e_tot, dm = scf_helpers.rks(hcore, S, veff, 4, e_nuc)
+    assert abs(e_tot - (-10.221426445656439)) < 5e-8
+
+
 def test_diamond_krks_lda_and_b88_total_energies_match_reference():
     """KRKS 'lda,' on the same cell with a [2,1,1] k-mesh (pyscf/pbc/scf/test/test_newton.py:135-142): e_tot =
     -10.307756038726733 (places=8).  J + v_xc from the k-point form of the multigrid ladder (periodic parts on stacked planes),

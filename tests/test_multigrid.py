@@ -587,3 +587,67 @@ def test_gpu_embed_restrict_follow_the_reference_on_nyquist_planes():
     the reference's placement, weight 1/2 on proper Nyquist entries, +-n/2 averaged on the way back."""
     from pyscf_isdf_amd.backend import HipBackend
     _check_nyquist_embed_restrict(HipBackend(0), 1e-13)
+
+
+def test_vwn_correlation_closed_form_and_reference_scf_energy():
+    """'lda,vwn' (Slater exchange + VWN5 correlation; libxc is absent, the closed form of Vosko-Wilk-Nusair eq. 4.4 stands in):
+    (i) v_c = d(rho eps_c)/d rho by central differences; (ii) the all-oracle RKS on the diamond primitive cell of
+    pyscf/pbc/dft/test/test_krks.py:59-71,112-119 (gth-szv / gth-pade, 17^3) reproduces the reference's
+    e_tot = -10.221426445656439 (places=7 there; measured 2.9e-9)."""
+    import scf_helpers
+    from oracle import pp as opp
+    rho = np.array([1e-6, 1e-3, 0.05, 0.3, 1.7, 20.0])
+    e, v = omg.vwn_correlation(rho)
+    h = 1e-6
+    fd = ((rho * (1 + h)) * omg.vwn_correlation(rho * (1 + h))[0] - (rho * (1 - h)) * omg.vwn_correlation(rho * (1 - h))[0]) / (2 * h * rho)
+    assert abs(fd - v).max() < 1e-9
+    assert np.all(e < 0) and omg.vwn_correlation(np.array([0.0, 1e-30]))[0].max() == 0.0
+    cell = gto.Cell(unit='A', atom='C 0. 0. 0.; C 0.8917 0.8917 0.8917', a=[[0., 1.7834, 1.7834], [1.7834, 0., 1.7834], [1.7834, 1.7834, 0.]],
+                    basis='gth-szv', pseudo='gth-pade', mesh=[17] * 3)
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    S, T = scf_helpers.overlap_kinetic_from_ft(cell)
+    ao4 = dense_ao4(cell)
+    ps = [cell._pseudo.get(cell.atom_symbol(i)) for i in range(cell.natm)]
+    vpp = opp.get_pp(cell._atm, cell._bas, cell._env, cell.atom_coords(), cell.atom_charges(), ps, a, mesh,
+                     cell.get_uniform_grids(), [ao4[0]], np.zeros((1, 3)))[0].real
+    e_nuc = scf_helpers.ewald_energy(cell)
+
+    def veff(dm):
+        vj = offt.get_j(ao4[0], dm, a, mesh)
+        n, exc, vxc = omg.nr_rks_lda_dense(ao4[0], dm, a, mesh, xc='lda,vwn')
+        return vj + vxc, 0.5 * np.einsum('ij,ji', vj, dm), exc
+    e_tot = scf_helpers.rks(T + vpp, S, veff, 4, e_nuc)[0]
+    assert abs(e_tot - (-10.221426445656439)) < 5e-8
+
+
+def _check_vwn(df, cell, tol):
+    """nr_rks('lda,vwn') of the product against the oracle on the same ladder and against the dense-grid quadrature (1e-7)."""
+    a, mesh = cell.lattice_vectors(), cell.mesh
+    dm = make_dm(cell)
+    n, e, veff = pmg.nr_rks(df, 'lda,vwn', dm, with_j=True)
+    n0, e0, v0, ec0 = omg.nr_rks_lda(as_tasks(df.tasks), cell._atm, dm, a, mesh, with_j=True, xc='lda,vwn')
+    assert abs(n - n0) < tol * 100 and abs(e - e0) < tol * 100 and abs(veff - v0).max() < tol * 10
+    vxc = pmg.nr_rks(df, 'LDA,VWN', dm)[2]
+    nd, ed, vd = omg.nr_rks_lda_dense(dense_ao4(cell)[0], dm, a, mesh, xc='lda,vwn')
+    assert abs(e - ed) < 1e-7 and abs(vxc - vd).max() < 1e-7
+    # it is a different functional from the exchange alone, and the open-shell form is refused, not silently wrong
+    assert abs(e - pmg.nr_rks(df, 'lda,', dm)[1]) > 1e-3
+    with pytest.raises(NotImplementedError):
+        pmg.nr_uks(df, 'lda,vwn', np.stack([dm, dm]) * .5)
+
+
+def test_product_vwn_on_checker_backend():
+    from oracle_backend import OracleBackend
+    cell = cell_he_split()
+    df = pmg.MultiGridFFTDF(cell, backend=OracleBackend())
+    df.split = 'all'
+    _check_vwn(df, cell, 1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mk', [cell_he_split, cell_c2_orth])
+def test_gpu_multigrid_lda_vwn(mk):
+    cell = mk()
+    df = pmg.MultiGridFFTDF(cell)
+    df.split = 'all'
+    _check_vwn(df, cell, 1e-9)
