@@ -267,8 +267,6 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
             return self._build_kpts()
         if self._sharded:
-            if self.pair_space == 'occ':
-                raise NotImplementedError("pair_space='occ' is implemented for the single-GPU Gamma-point build")
             return self._build_sharded()
         cell, be = self.cell, self.backend
         self.timings = {}
@@ -527,7 +525,10 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             if abs(proj - self._fit_dm).max() <= 1e-12 * abs(proj).max():
                 return
         self._fit_dm = None if orb is None else orb.dot(orb.T)
-        self._pick_and_fit(orb)
+        if self._sel.get('sharded'):
+            self._pick_and_fit_sharded(orb)
+        else:
+            self._pick_and_fit(orb)
         self._fit_pending = False
 
     def _build_paneled(self, rank, clusters, d_ip, rows_buf, rows_panel, t0):

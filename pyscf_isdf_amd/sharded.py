@@ -45,6 +45,8 @@ class ShardedMixin:
         S4  rows of Theta assembled by all-to-all, FFT convolution, scattered back by all-to-all
         S5  W_r = w V[:, S_r] Theta[:, S_r]^T                       all_reduce(W)  (RCCL over xGMI)
         Streaming over row batches bounds memory at any rank count.
+        pair_space='occ': stops after the candidate stage like the single-GPU build; get_jk makes the pick and the fit for its
+        density (_ensure_fit -> _pick_and_fit_sharded).
         """
         cell, be, comm = self.cell, self.backend, self.comm
         if self.select not in ('local', 'refined'):
@@ -99,16 +101,48 @@ class ShardedMixin:
         merged = {}
         for d in all_ips:
             merged.update(d)
+        self._tick('S2_select_candidates' if self.select == 'refined' else 'S2_select_ip', t0)
+        # the fit rows of this rank's slice have to fit next to phi, W and the factors (the paneled build is single-GPU: with
+        # R ranks a slice holds c_isdf up to about 10 R at configs[2])
+        Pmax = int(nip_final.sum())
+        need = 8 * Pmax * ng + 4 * 8 * Pmax * Pmax
+        have = be.free_bytes() + sum(int(b.numel()) * 8 for k, b in self._bufs.items() if k in ('theta', 'W', 'factor', 'Dblk', 'Dinv'))
+        if need > have:
+            raise MemoryError('ISDF: %d fit rows of %d grid columns (%.0f GB with the P x P matrices) do not fit on rank %d '
+                              '(%.0f GB obtainable); use more ranks or fewer points' % (Pmax, ng, need / 1e9, rk, have / 1e9))
+        self._sel = dict(sharded=True, owner=owner, merged=merged, nip_final=nip_final)
+        if self.pair_space == 'occ':
+            self._fit_pending = True
+            self._built = True
+            return self
+        return self._pick_and_fit_sharded()
+
+    def _pick_and_fit_sharded(self, orbitals=None):
+        """S2 second stage + S3 + S4 + S5 of the grid-sharded build from the candidates in self._sel; orbitals: see
+        isdf.ISDF._pick_and_fit (the occupied orbitals on this rank's slice are psi = C^T phi[:, S_r], no communication)."""
+        cell, be, comm, sel = self.cell, self.backend, self.comm, self._sel
+        owner, merged, nip_final = sel['owner'], sel['merged'], sel['nip_final']
+        nao, ng = self.ao.shape
+        g0, g1 = self._slice
+        t0 = time.perf_counter()
+        self._fit_state = None
+        self._W_omega = {}
+        self._V = None
+        self._psi = self._psiP = None
+        if orbitals is not None:
+            self._psi = self._buffer('psi', (orbitals.shape[1], ng))
+            be.gemm_nn(be.to_device(np.ascontiguousarray(orbitals.T)), self.ao, self._psi)
+            t0 = self._tick('S2_occupied_on_grid', t0)
         none = np.zeros(0, dtype=np.int64)                 # an atom that owns no grid points / no AOs selects nothing
         if self.select == 'refined':
-            t0 = self._tick('S2_select_candidates', t0)
             # phi at the candidates from the slice collocations (zero-padded all_reduce, 8 m N bytes); the pivoted
             # Cholesky of the candidate Gram matrix runs on rank 0 and its answer is shared: one decision for all ranks
             cand = np.concatenate([merged.get(b, none) for b in range(cell.natm)]).astype(np.int64)
             aoC = self._slice_columns(cand, g0, g1).T.contiguous()
-            chosen = comm.run_on_root(lambda: self._refine_pick(aoC, cand, int(nip_final.sum())))
+            psiC = None if self._psi is None else self._slice_columns(cand, g0, g1, src=self._psi).T.contiguous()
+            chosen = comm.run_on_root(lambda: self._refine_pick(aoC, cand, int(nip_final.sum()), psiC=psiC))
             chosen = comm.all_gather_object(chosen)[0]
-            del aoC
+            del aoC, psiC
             own = owner[chosen]
             merged = {b: chosen[own == b] for b in range(cell.natm)}
         clusters = self._bj_clusters()
@@ -122,6 +156,9 @@ class ShardedMixin:
         # the fit amplifies by cond(A)).  P x P factorisations replicated, rows of the fit on the slice.
         aoP_T = self._slice_columns(self.ip, g0, g1)
         self.aoP = self._buffer('aoP', (P, nao))
+        if self._psi is not None:
+            self._psiP = self._buffer('psiP', (P, self._psi.shape[0]))
+            self._psiP.copy_(self._slice_columns(self.ip, g0, g1, src=self._psi).T)
         theta = self._buffer('theta', (P, ng))
         ar = be.to_device(np.arange(P, dtype=np.int64))
         ip_off = self._bj_blocks([len(merged.get(b, none)) for b in range(cell.natm)], clusters)
@@ -137,18 +174,33 @@ class ShardedMixin:
                 reg = comm.run_on_root(root_factorise)
                 if comm.rank != 0:
                     be.gather_aoP(aoP_T, ar, self.aoP)
+                    self._Dinv_key = None
                 comm.broadcast(Afac)
                 comm.broadcast(Dblk)
                 self.reg_used = comm.agree_max(reg or 0.0)
                 self._bj_rows(self.aoP, 0, self.ao, ng, Dblk, ip_off, theta)
             else:
                 chol = self._buffer('factor', (P, P))
-                reg = comm.run_on_root(lambda: be.fit_prepare(aoP_T, ar, self.reg_rel, self.aoP, chol))
+                if self._psi is None:
+                    reg = comm.run_on_root(lambda: be.fit_prepare(aoP_T, ar, self.reg_rel, self.aoP, chol))
+                else:
+                    def root_chol():
+                        be.gather_aoP(aoP_T, ar, self.aoP)
+                        be.gram_prod(self.aoP, self._psiP, chol)
+                        be.shift_diag(chol, self.reg_rel)
+                        return self.reg_rel + be.chol_inplace(chol, 0.0, scratch=self._buffer('W', (P, P)))
+                    reg = comm.run_on_root(root_chol)
                 if comm.rank != 0:
                     be.gather_aoP(aoP_T, ar, self.aoP)
                 comm.broadcast(chol)
                 self.reg_used = comm.agree_max(reg or 0.0)
-                be.fit_apply(chol, self.aoP, self.ao, ng, theta, forward_only=not self._want_theta)
+                if self._psi is None:
+                    be.fit_apply(chol, self.aoP, self.ao, ng, theta, forward_only=not self._want_theta)
+                else:
+                    be.pair_prod_rows(self.aoP, self._psiP, self.ao, self._psi, ng, theta)
+                    be.factor_solve_half(chol, False, theta)
+                    if self._want_theta:
+                        be.factor_solve_half(chol, True, theta)
             t0 = self._tick('S3_fit', t0)
 
             self._fit_state = dict(kind=route if route == 'blockjacobi' else ('explicit' if self._want_theta else 'cholesky'),
@@ -172,16 +224,17 @@ class ShardedMixin:
         self._built = True
         return self
 
-    def _slice_columns(self, idx, g0, g1):
-        """phi at the grid points idx, (nao, len(idx)), on every rank: each point lies in exactly one rank's slice
-        [g0, g1) of the collocation self.ao; zero-padded all_reduce of 8 nao len(idx) bytes."""
+    def _slice_columns(self, idx, g0, g1, src=None):
+        """phi (or the rows of ``src``, e.g. the occupied orbitals on the slice) at the grid points idx, (rows, len(idx)), on
+        every rank: each point lies in exactly one rank's slice [g0, g1); zero-padded all_reduce of 8 rows len(idx) bytes."""
         be, comm = self.backend, self.comm
+        src = self.ao if src is None else src
         idx = np.asarray(idx, dtype=np.int64)
-        out = be.zeros((self.ao.shape[0], len(idx)))
+        out = be.zeros((src.shape[0], len(idx)))
         mine = np.nonzero((idx >= g0) & (idx < g1))[0]
         if len(mine):
-            loc = be.empty((self.ao.shape[0], len(mine)))
-            be.gather_cols(self.ao, be.to_device(idx[mine] - g0), loc)
+            loc = be.empty((src.shape[0], len(mine)))
+            be.gather_cols(src, be.to_device(idx[mine] - g0), loc)
             out[:, be.to_device(mine)] = loc
             del loc
         comm.all_reduce_sum(out)

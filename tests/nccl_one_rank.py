@@ -41,6 +41,24 @@ def main():
         vkl = df.get_jk(dm, omega=0.3, with_j=False)[1] if not robust else None
         if vkl is not None:
             assert abs(vkl - ref.get_jk(dm, omega=0.3, with_j=False)[1]).max() < 1e-7 * abs(vk0).max()
+    # the (AO x occupied) pair space through the sharded code path (fit inside get_jk from the MO-tagged density) and the
+    # headline's setting (refined selection, c = 12, block-Jacobi behind its probe check)
+    c0 = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao); occ[:3] = 2
+
+    class Tagged(np.ndarray):
+        pass
+    tdm = (c0 * occ).dot(c0.T).view(Tagged)
+    tdm.mo_coeff, tdm.mo_occ = c0, occ
+    for space, c_isdf, route in (('occ', 3, 'cholesky'), ('ao', 12, 'auto')):
+        ref = ISDF(cell, c_isdf=c_isdf, select='refined', comm=Comm())
+        ref.pair_space, ref.fit_route, ref.bj_check_tol = space, route, 1e-6
+        k0 = ref.get_jk(tdm, with_j=False)[1]
+        df = ISDF(cell, c_isdf=c_isdf, select='refined', comm=live)
+        df.pair_space, df.fit_route, df.bj_check_tol, df.fft_batch = space, route, 1e-6, 7
+        k1 = df.get_jk(tdm, with_j=False)[1]
+        assert df._fit_state.get('sharded') and np.array_equal(df.ip, ref.ip) and df.fit_route_used == ref.fit_route_used
+        assert abs(k1 - k0).max() < 1e-7 * abs(k0).max(), (space, abs(k1 - k0).max())
     # q-sharded k-point build
     cellk = cells.cell_he2_triclinic()
     cellk.mesh = np.array([10, 10, 10])

@@ -27,15 +27,33 @@ def main():
     dm = rng.standard_normal((2, nao, nao))
     dm = dm + dm.transpose(0, 2, 1)
     ok = True
-    for select, route in (('local', 'auto'), ('refined', 'cholesky')):
-        df = ISDF(cell, c_isdf=4, select=select, comm=comm)
+    # local + auto, refined + Cholesky, and what the headline runs: refined selection, c = 12, block-Jacobi route behind its probe check
+    for select, route, c_isdf in (('local', 'auto', 4), ('refined', 'cholesky', 4), ('refined', 'auto', 12)):
+        df = ISDF(cell, c_isdf=c_isdf, select=select, comm=comm)
         df.fit_route, df.bj_check_tol, df.fft_batch = route, 1e-6, 7
         vj, vk = df.get_jk(dm)
         if rank == 0:
-            ref = ISDF(cell, c_isdf=4, select=select, comm=Comm())
+            ref = ISDF(cell, c_isdf=c_isdf, select=select, comm=Comm())
             ref.fit_route, ref.bj_check_tol = route, 1e-6
             vj0, vk0 = ref.get_jk(dm)
             ok = ok and np.array_equal(df.ip, ref.ip) and abs(vj - vj0).max() < 1e-10 and abs(vk - vk0).max() < 1e-7 * abs(vk0).max()
+            ok = ok and df.fit_route_used == ref.fit_route_used
+    # the (AO x occupied) pair space through the sharded build: the fit is made inside get_jk from the tagged density
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao); occ[:3] = 2
+
+    class Tagged(np.ndarray):
+        pass
+    tdm = (c * occ).dot(c.T).view(Tagged)
+    tdm.mo_coeff, tdm.mo_occ = c, occ
+    df = ISDF(cell, c_isdf=3, select='refined', comm=comm)
+    df.pair_space, df.fit_route, df.fft_batch = 'occ', 'cholesky', 7
+    vk = df.get_jk(tdm, with_j=False)[1]
+    if rank == 0:
+        ref = ISDF(cell, c_isdf=3, select='refined', comm=Comm())
+        ref.pair_space, ref.fit_route = 'occ', 'cholesky'
+        vk0 = ref.get_jk(tdm, with_j=False)[1]
+        ok = ok and np.array_equal(df.ip, ref.ip) and abs(vk - vk0).max() < 1e-7 * abs(vk0).max()
     dist.barrier()
     if rank == 0:
         print('RCCL-TWO-RANK OK' if ok else 'RCCL-TWO-RANK MISMATCH', flush=True)
