@@ -9,8 +9,9 @@ interpolation points c_isdf * nao and their selection (DESIGN.md section 2 has t
     the scalable path (refined selection) is asserted at 1e-6 Eh PER ATOM at the same c (this cell's grid is denser per atom
     than the headline's, 32000 against 13500 points: it needs c = 15 where the headline needs 12);
   * configs[2] (128 atoms, the headline): the configuration bench.py times (refined selection, c = 12, fit rows in two
-    panels) is asserted at 1e-6 Eh PER ATOM (measured 2.8e-7 Eh/atom = 3.6e-5 Eh) and max|dK| <= 1e-4; the literal 1e-6 Eh
-    is NOT reached at this size inside 30 s (c = 15: 9.3e-6 Eh in 26.3 s) and no test pretends otherwise;
+    panels) has hard regression bounds (|dE_K| <= 5e-5 Eh, measured 3.6e-5; max|dK| <= 1e-4) and the LITERAL 1e-6 Eh as an
+    expected-failure test next to it: it is NOT reached at this size inside 30 s on one GPU (c = 15: 9.3e-6 Eh in 26.3 s);
+  * SCF orbitals (configs[1] size): the (AO x occupied) pair space + robust K meets the literal 1e-6 Eh - asserted;
   * configs[4] (64 H2O) at the largest single-GPU mesh: 1e-5 Eh per atom class with the block-Jacobi clusters (see the test);
   * configs[0], configs[3]: see the tests below.
 """
@@ -84,11 +85,15 @@ def test_config1_diamond222_accuracy_vs_exact_exchange():
     assert abs(vk2 - k_exact).max() < 0.5 * abs(vk3 - k_exact).max()
 
 
+_CFG2 = {}
+
+
 def test_config2_headline_diamond444_accuracy_vs_exact_exchange():
     """configs[2] (diamond 4x4x4, gth-dzvp, 120^3: N = 1664, G = 1 728 000) exactly as bench.py times it - refined selection,
-    c = 12 (P = 19968), block-Jacobi route with the fit rows in two panels - against the exact exchange on the benchmark
-    density (48 s on the GPU): |dE_K| <= 1e-6 Eh per atom (1.28e-4 Eh; measured 3.6e-5), max|dK| <= 1e-4 (measured 6.1e-5);
-    size-independent properties on top (symmetry, linearity, the route's probe check passed)."""
+    c = 12 (P = 19968), AO x AO pair space, block-Jacobi route with the fit rows in two panels - against the exact exchange on
+    the benchmark density (random orthogonal orbitals; 38 s on the GPU).  Hard bounds (regressions fail): |dE_K| <= 5e-5 Eh
+    (measured 3.6e-5 in rounds 2 and 3), max|dK| <= 1e-4 (measured 6.1e-5); size-independent properties on top (symmetry,
+    linearity, the route's probe check passed).  The north star's literal 1e-6 Eh is the NEXT test."""
     import torch
     from pyscf_isdf_amd.isdf import ISDF
     if torch.cuda.get_device_properties(0).total_memory < 270 * 2 ** 30:
@@ -103,11 +108,66 @@ def test_config2_headline_diamond444_accuracy_vs_exact_exchange():
     vk_half = df.get_jk(-0.5 * dm, with_j=False)[1]
     assert abs(vk_half + 0.5 * vk).max() < 1e-9
     assert abs(np.einsum('ij,ji', vj, dm) / 2 - 12.140270972643) < 1e-7           # E_J: the exact formula, same as round 1
+    df.release_fit_buffers()
     k_exact = df.get_k_exact(mo_coeff=c, mo_occ=occ)
     assert abs(_ek(k_exact, dm) - 123.18058922) < 1e-6                           # the exact exchange itself is stable
-    assert abs(_ek(vk, dm) - _ek(k_exact, dm)) < PER_ATOM_TOL * cell.natm
+    _CFG2['dE_K'] = _ek(vk, dm) - _ek(k_exact, dm)
+    assert abs(_CFG2['dE_K']) < 5e-5
     assert abs(vk - k_exact).max() < 1e-4
     df.reset()
+
+
+@pytest.mark.xfail(strict=False, reason="north star 'K within 1e-6 Eh' at configs[2] inside 30 s on ONE GPU: not reached for the "
+                   "benchmark density (random orthogonal orbitals) - measured -3.6e-5 Eh at c = 12 / 16.6 s, -9.3e-6 Eh at c = 15 / "
+                   "26.3 s; the (AO x occupied) pair space does not help random orbitals (-7.9e-5 Eh at c = 12); with SCF orbitals "
+                   "it reaches +9.6e-6 (plain) / -4.9e-6 Eh (robust, c = 10): DESIGN.md section 2, profiles/r03_*")
+def test_config2_headline_meets_the_literal_north_star_tolerance():
+    """The literal tolerance of BASELINE.json for the configuration bench.py times, on the measurement of the test above (which
+    has to run first; alone, this test evaluates nothing and is skipped)."""
+    if 'dE_K' not in _CFG2:
+        pytest.skip('runs after test_config2_headline_diamond444_accuracy_vs_exact_exchange')
+    assert abs(_CFG2['dE_K']) < NORTH_STAR_TOL
+
+
+def test_config1_scf_orbitals_occ_pair_space_and_robust_k_meet_the_north_star():
+    """Physical orbitals (an RHF on diamond 2x2x2 / gth-dzvp / 80^3 converged with the ISDF object itself: get_pp, J, K from the
+    device; S and T by plane-wave quadrature of the AO values - test-side plumbing) against the exact exchange AT those
+    orbitals.  The AO x AO fit at c = 12 is off by 1e-4 Eh; the (AO x occupied) pair space (pair_space='occ': the reduction
+    the reference's K makes with mo_coeff-tagged densities, fft_jk.py:206-210,235-238) brings the plain ISDF K to 2e-5 Eh
+    at the same number of points, and with Dunlap's robust correction on top (error quadratic in the fit error) the LITERAL
+    north-star 1e-6 Eh holds: asserted at c = 15 (at c = 12 the two SCF solutions measured so far gave 8.6e-8 and 1.5e-6 Eh
+    with max|dK| 1.5e-8 / 7.8e-8: profiles/r03_scf_orbital_scan_diamond222.log, gpurun of this test)."""
+    import torch
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = workloads.make_cell('diamond-222-dzvp-80')
+    nao, nocc = cell.nao_nr(), cell.nelectron // 2
+    mesh = [int(x) for x in cell.mesh]
+    G = int(np.prod(mesh))
+    df = ISDF(cell, c_isdf=10, select='refined')
+    df.collocate()
+    F = torch.fft.fftn(df.ao.reshape(nao, *mesh), dim=(1, 2, 3)).reshape(nao, G)
+    b = 2 * np.pi * np.linalg.inv(cell.lattice_vectors().T)
+    fr = [np.fft.fftfreq(n, 1. / n) for n in mesh]
+    Gv = (fr[0][:, None, None, None] * b[0] + fr[1][None, :, None, None] * b[1] + fr[2][None, None, :, None] * b[2]).reshape(-1, 3)
+    g2 = df.backend.to_device(np.einsum('gi,gi->g', Gv, Gv))
+    T = ((0.5 * cell.vol / G ** 2) * torch.matmul(F.conj() * g2, F.T).real).cpu().numpy()
+    S = ((cell.vol / G ** 2) * torch.matmul(F.conj(), F.T).real).cpu().numpy()
+    del F
+    hcore = T + df.get_pp()
+    import scf_helpers
+    e_tot, dm = scf_helpers.rhf(hcore, S, lambda d: df.get_jk(d), nocc, 0.0, max_cycle=40, conv=1e-8)
+    assert abs(np.einsum('ij,ji', dm, S) - 2 * nocc) < 1e-8
+    k_exact = df.get_k_exact(dm)
+    errs = {}
+    for tag, space, robust, cc in (('ao', 'ao', False, 12), ('occ', 'occ', False, 12), ('occ+robust', 'occ', True, 15)):
+        d2 = ISDF(cell, c_isdf=cc, select='refined')
+        d2.pair_space, d2.robust_k = space, robust
+        vk = d2.get_jk(dm, with_j=False)[1]
+        errs[tag] = (abs(_ek(vk, dm) - _ek(k_exact, dm)), abs(vk - k_exact).max())
+        print('diamond 2x2x2 SCF orbitals, c = %d, %s: |dE_K| %.2e Eh, max|dK| %.2e' % ((cc, tag) + errs[tag]))
+        d2.reset()
+    assert errs['occ'][1] < 0.2 * errs['ao'][1] and errs['occ'][0] < 3e-5
+    assert errs['occ+robust'][0] < NORTH_STAR_TOL and errs['occ+robust'][1] < 1e-6
 
 
 def test_config4_water64_largest_single_gpu_mesh_vs_exact_exchange():
@@ -173,6 +233,34 @@ def test_config3_mgo_kmesh_accuracy_vs_exact_kpoint_exchange_reduced_cell():
         df.reset()
     assert errs[2][0] < 2e-5 and errs[4][0] < 2e-5
     assert errs[2][1] < 1e-4 and errs[4][1] < 2e-5
+
+
+def test_config3_mgo333_kmesh_full_size_properties_and_sampled_exact_rows():
+    """configs[3] at FULL size on one GPU: MgO 3x3x3 (54 atoms, N = 729), gth-dzvp, 96^3, 2x2x2 k-mesh, refined selection, c = 10
+    with the default k_ip_factor = 2 (P = 14580, 14 W^q) - about two minutes.  Asserted: shapes, Hermiticity of J and K at every
+    k, linearity, and the ISDF K against the reference's exact k-point exchange on a SAMPLE of 8 AO rows of every k-point (the
+    full exact exchange is 64 x 729 x 216 complex FFT pairs of 96^3: an hour; the sample takes seconds): max|dK| on the rows
+    <= 2e-4 (measured value in profiles/r03_kpoint_accuracy_mgo333_rows.log)."""
+    import torch
+    from pyscf_isdf_amd.isdf import ISDF
+    if torch.cuda.get_device_properties(0).total_memory < 270 * 2 ** 30:
+        pytest.skip('needs a 288 GB device')
+    name = 'mgo-333-dzvp-k222'
+    cell, kpts, dms, cs, occs = _mgo_density(name)
+    nk, nao = len(kpts), cell.nao_nr()
+    assert nao == 729 and nk == 8
+    df = ISDF(cell, kpts=kpts, c_isdf=10, select='refined')
+    rows = (360, 8)
+    vk_rows = df.get_k_exact(dms, mo_coeff=cs, mo_occ=occs, rows=rows)
+    vj, vk = df.get_jk(dms, kpts=kpts)
+    assert vj.shape == vk.shape == (nk, nao, nao) and len(df.ip) == 14580
+    assert abs(vj - vj.conj().transpose(0, 2, 1)).max() < 1e-9 and abs(vk - vk.conj().transpose(0, 2, 1)).max() < 1e-8 * abs(vk).max()
+    err = abs(vk[:, rows[0]:rows[0] + rows[1]] - vk_rows).max()
+    print('MgO 3x3x3 k222 c=10 P=%d: max|dK| on %d sampled rows per k-point %.2e (max|K| there %.3f)' % (len(df.ip), rows[1], err, abs(vk_rows).max()))
+    assert err < 2e-4
+    vk2 = df.get_jk(-0.5 * dms, kpts=kpts, with_j=False)[1]
+    assert abs(vk2 + 0.5 * vk).max() < 1e-9 * abs(vk).max()
+    df.reset()
 
 
 def test_config3_mgo_kmesh_properties_reduced_cell():
