@@ -28,6 +28,12 @@ D_XY = 1.0925484305920792
 D_Z2_ZZ = 0.6307831305050401
 D_Z2_XXYY = 0.31539156525252005
 D_X2Y2 = 0.5462742152960396
+# f shells, libcint's real-spherical combination (m = -3 .. 3): sqrt(35/32pi), sqrt(105/4pi), sqrt(21/32pi), sqrt(7/16pi), sqrt(105/16pi)
+F_3 = 0.5900435899266435
+F_2M = 2.890611442640554
+F_1 = 0.4570457994644658
+F_0 = 0.3731763325901154
+F_2 = 1.445305721320277
 
 
 def ao_loc(bas):
@@ -45,7 +51,15 @@ def _angular(l, dx, dy, dz):
         return [D_XY * dx * dy, D_XY * dy * dz,
                 D_Z2_ZZ * dz * dz - D_Z2_XXYY * (dx * dx + dy * dy),
                 D_XY * dx * dz, D_X2Y2 * (dx * dx - dy * dy)]
-    raise NotImplementedError('l > 2: libcint cart2sph coefficients are not pinned by the reference tree')
+    if l == 3:
+        # libcint 6.1.1 cart2sph table for f shells (m = -3 .. 3), restated from its published coefficients
+        # (1.7701307697799305 x^2 y - 0.5900435899266435 y^3, 2.890611442640554 xyz, ...): PARITY UNPINNED - the reference
+        # tree holds no fixture with f shells on this path; pinned here by orthonormality only (tests/test_oracle_pins.py)
+        x2, y2, z2 = dx * dx, dy * dy, dz * dz
+        return [F_3 * dy * (3.0 * x2 - y2), F_2M * dx * dy * dz, F_1 * dy * (4.0 * z2 - x2 - y2),
+                F_0 * dz * (2.0 * z2 - 3.0 * x2 - 3.0 * y2), F_1 * dx * (4.0 * z2 - x2 - y2),
+                F_2 * dz * (x2 - y2), F_3 * dx * (x2 - 3.0 * y2)]
+    raise NotImplementedError('l > 3')
 
 
 def eval_ao(atm, bas, env, coords, Ls, rcut, kpts=None, rule='point'):
@@ -133,7 +147,16 @@ def _angular_grad(l, dx, dy, dz):
         return [(D_XY * dy, D_XY * dx, z), (z, D_XY * dz, D_XY * dy),
                 (-2 * D_Z2_XXYY * dx, -2 * D_Z2_XXYY * dy, 2 * D_Z2_ZZ * dz),
                 (D_XY * dz, z, D_XY * dx), (2 * D_X2Y2 * dx, -2 * D_X2Y2 * dy, z)]
-    raise NotImplementedError('l > 2')
+    if l == 3:
+        x2, y2, z2 = dx * dx, dy * dy, dz * dz
+        return [(F_3 * 6.0 * dx * dy, F_3 * 3.0 * (x2 - y2), z),
+                (F_2M * dy * dz, F_2M * dx * dz, F_2M * dx * dy),
+                (-2.0 * F_1 * dx * dy, F_1 * (4.0 * z2 - x2 - 3.0 * y2), 8.0 * F_1 * dy * dz),
+                (-6.0 * F_0 * dx * dz, -6.0 * F_0 * dy * dz, F_0 * (6.0 * z2 - 3.0 * x2 - 3.0 * y2)),
+                (F_1 * (4.0 * z2 - 3.0 * x2 - y2), -2.0 * F_1 * dx * dy, 8.0 * F_1 * dx * dz),
+                (2.0 * F_2 * dx * dz, -2.0 * F_2 * dy * dz, F_2 * (x2 - y2)),
+                (F_3 * 3.0 * (x2 - y2), -6.0 * F_3 * dx * dy, z)]
+    raise NotImplementedError('l > 3')
 
 
 def eval_ao_deriv1(atm, bas, env, coords, Ls, rcut, kpt=None):

@@ -1,4 +1,4 @@
-// S1: periodic AO collocation on gfx950 (Γ point, real spherical GTOs, l <= 2).
+// S1: periodic AO collocation on gfx950 (Γ point, real spherical GTOs, l <= 3).
 //
 // One workgroup = 256 consecutive grid points x one atom.  The workgroup first culls the lattice
 // translations against the bounding box of its points (LDS list), then every lane walks only the
@@ -29,6 +29,68 @@ constexpr double D_XY = 1.0925484305920792;
 constexpr double D_Z2_ZZ = 0.6307831305050401;
 constexpr double D_Z2_XXYY = 0.31539156525252005;
 constexpr double D_X2Y2 = 0.5462742152960396;
+// f shells: libcint's real-spherical combination, m = -3 .. 3 (cart2sph table of libcint 6.1.1; the reference tree holds no
+// fixture with f shells on this path: parity unpinned, orthonormality tested)
+constexpr double F_3 = 0.5900435899266435;      // y (3x^2 - y^2), x (x^2 - 3y^2)
+constexpr double F_2M = 2.890611442640554;      // x y z
+constexpr double F_1 = 0.4570457994644658;      // y (4z^2 - x^2 - y^2), x (4z^2 - x^2 - y^2)
+constexpr double F_0 = 0.3731763325901154;      // z (2z^2 - 3x^2 - 3y^2)
+constexpr double F_2 = 1.445305721320277;       // z (x^2 - y^2)
+
+// real-spherical angular polynomials of a shell (without the radial part)
+template <int L>
+__device__ inline void angular(double dx, double dy, double dz, double* __restrict__ ang) {
+  if (L == 0) {
+    ang[0] = 1.0;
+  } else if (L == 1) {
+    ang[0] = dx; ang[1] = dy; ang[2] = dz;
+  } else if (L == 2) {
+    ang[0] = D_XY * dx * dy;
+    ang[1] = D_XY * dy * dz;
+    ang[2] = D_Z2_ZZ * dz * dz - D_Z2_XXYY * (dx * dx + dy * dy);
+    ang[3] = D_XY * dx * dz;
+    ang[4] = D_X2Y2 * (dx * dx - dy * dy);
+  } else {
+    const double x2 = dx * dx, y2 = dy * dy, z2 = dz * dz;
+    ang[0] = F_3 * dy * (3.0 * x2 - y2);
+    ang[1] = F_2M * dx * dy * dz;
+    ang[2] = F_1 * dy * (4.0 * z2 - x2 - y2);
+    ang[3] = F_0 * dz * (2.0 * z2 - 3.0 * x2 - 3.0 * y2);
+    ang[4] = F_1 * dx * (4.0 * z2 - x2 - y2);
+    ang[5] = F_2 * dz * (x2 - y2);
+    ang[6] = F_3 * dx * (x2 - 3.0 * y2);
+  }
+}
+
+// the same with Cartesian gradients gang[m][x]
+template <int L>
+__device__ inline void angular_grad(const double* __restrict__ d, double* __restrict__ ang, double (*gang)[3]) {
+  const double dx = d[0], dy = d[1], dz = d[2];
+  angular<L>(dx, dy, dz, ang);
+  if (L == 0) {
+    gang[0][0] = gang[0][1] = gang[0][2] = 0.0;
+  } else if (L == 1) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) gang[m][x] = (m == x) ? 1.0 : 0.0;
+  } else if (L == 2) {
+    gang[0][0] = D_XY * dy;  gang[0][1] = D_XY * dx;  gang[0][2] = 0.0;
+    gang[1][0] = 0.0;        gang[1][1] = D_XY * dz;  gang[1][2] = D_XY * dy;
+    gang[2][0] = -2.0 * D_Z2_XXYY * dx;  gang[2][1] = -2.0 * D_Z2_XXYY * dy;  gang[2][2] = 2.0 * D_Z2_ZZ * dz;
+    gang[3][0] = D_XY * dz;  gang[3][1] = 0.0;        gang[3][2] = D_XY * dx;
+    gang[4][0] = 2.0 * D_X2Y2 * dx;  gang[4][1] = -2.0 * D_X2Y2 * dy;  gang[4][2] = 0.0;
+  } else {
+    const double x2 = dx * dx, y2 = dy * dy, z2 = dz * dz;
+    gang[0][0] = 6.0 * F_3 * dx * dy;   gang[0][1] = 3.0 * F_3 * (x2 - y2);              gang[0][2] = 0.0;
+    gang[1][0] = F_2M * dy * dz;        gang[1][1] = F_2M * dx * dz;                     gang[1][2] = F_2M * dx * dy;
+    gang[2][0] = -2.0 * F_1 * dx * dy;  gang[2][1] = F_1 * (4.0 * z2 - x2 - 3.0 * y2);   gang[2][2] = 8.0 * F_1 * dy * dz;
+    gang[3][0] = -6.0 * F_0 * dx * dz;  gang[3][1] = -6.0 * F_0 * dy * dz;               gang[3][2] = F_0 * (6.0 * z2 - 3.0 * x2 - 3.0 * y2);
+    gang[4][0] = F_1 * (4.0 * z2 - 3.0 * x2 - y2);  gang[4][1] = -2.0 * F_1 * dx * dy;   gang[4][2] = 8.0 * F_1 * dx * dz;
+    gang[5][0] = 2.0 * F_2 * dx * dz;   gang[5][1] = -2.0 * F_2 * dy * dz;               gang[5][2] = F_2 * (x2 - y2);
+    gang[6][0] = 3.0 * F_3 * (x2 - y2); gang[6][1] = -6.0 * F_3 * dx * dy;               gang[6][2] = 0.0;
+  }
+}
 
 __device__ inline double wave_min(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
@@ -71,17 +133,7 @@ __device__ inline void shell_eval(const ShellDev sh, const double* __restrict__ 
           if (c < sh.nctr) rad[c] += cs[c * sh.nprim + p] * e;
       }
       double ang[DEG];
-      if (L == 0) {
-        ang[0] = 1.0;
-      } else if (L == 1) {
-        ang[0] = dx; ang[1] = dy; ang[2] = dz;
-      } else {
-        ang[0] = D_XY * dx * dy;
-        ang[1] = D_XY * dy * dz;
-        ang[2] = D_Z2_ZZ * dz * dz - D_Z2_XXYY * (dx * dx + dy * dy);
-        ang[3] = D_XY * dx * dz;
-        ang[4] = D_X2Y2 * (dx * dx - dy * dy);
-      }
+      angular<L>(dx, dy, dz, ang);
 #pragma unroll
       for (int c = 0; c < NCMAX; ++c)
 #pragma unroll
@@ -160,7 +212,8 @@ __global__ __launch_bounds__(TPB) void eval_ao_kernel(
     switch (sh.l) {
       case 0: shell_eval<0>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, g); break;
       case 1: shell_eval<1>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, g); break;
-      default: shell_eval<2>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, g); break;
+      case 2: shell_eval<2>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, g); break;
+      default: shell_eval<3>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, g); break;
     }
   }
 }
@@ -202,17 +255,7 @@ __device__ inline void shell_eval_k(const ShellDev sh, const double* __restrict_
           if (c < sh.nctr) rad[c] += cs[c * sh.nprim + p] * e;
       }
       double ang[DEG];
-      if (L == 0) {
-        ang[0] = 1.0;
-      } else if (L == 1) {
-        ang[0] = dx; ang[1] = dy; ang[2] = dz;
-      } else {
-        ang[0] = D_XY * dx * dy;
-        ang[1] = D_XY * dy * dz;
-        ang[2] = D_Z2_ZZ * dz * dz - D_Z2_XXYY * (dx * dx + dy * dy);
-        ang[3] = D_XY * dx * dz;
-        ang[4] = D_X2Y2 * (dx * dx - dy * dy);
-      }
+      angular<L>(dx, dy, dz, ang);
 #pragma unroll
       for (int c = 0; c < NCMAX; ++c)
 #pragma unroll
@@ -300,7 +343,8 @@ __global__ __launch_bounds__(TPB) void eval_ao_k_kernel(
     switch (sh.l) {
       case 0: shell_eval_k<0>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, g); break;
       case 1: shell_eval_k<1>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, g); break;
-      default: shell_eval_k<2>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, g); break;
+      case 2: shell_eval_k<2>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, g); break;
+      default: shell_eval_k<3>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, g); break;
     }
   }
 }
@@ -342,26 +386,7 @@ __device__ inline void shell_eval_d1(const ShellDev sh, const double* __restrict
           }
       }
       double ang[DEG], gang[DEG][3];
-      if (L == 0) {
-        ang[0] = 1.0;
-        gang[0][0] = gang[0][1] = gang[0][2] = 0.0;
-      } else if (L == 1) {
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          ang[m] = d[m];
-#pragma unroll
-          for (int x = 0; x < 3; ++x) gang[m][x] = (m == x) ? 1.0 : 0.0;
-        }
-      } else {
-        const double dx = d[0], dy = d[1], dz = d[2];
-        ang[0] = D_XY * dx * dy;  gang[0][0] = D_XY * dy;  gang[0][1] = D_XY * dx;  gang[0][2] = 0.0;
-        ang[1] = D_XY * dy * dz;  gang[1][0] = 0.0;        gang[1][1] = D_XY * dz;  gang[1][2] = D_XY * dy;
-        ang[2] = D_Z2_ZZ * dz * dz - D_Z2_XXYY * (dx * dx + dy * dy);
-        gang[2][0] = -2.0 * D_Z2_XXYY * dx;  gang[2][1] = -2.0 * D_Z2_XXYY * dy;  gang[2][2] = 2.0 * D_Z2_ZZ * dz;
-        ang[3] = D_XY * dx * dz;  gang[3][0] = D_XY * dz;  gang[3][1] = 0.0;        gang[3][2] = D_XY * dx;
-        ang[4] = D_X2Y2 * (dx * dx - dy * dy);
-        gang[4][0] = 2.0 * D_X2Y2 * dx;  gang[4][1] = -2.0 * D_X2Y2 * dy;  gang[4][2] = 0.0;
-      }
+      angular_grad<L>(d, ang, gang);
 #pragma unroll
       for (int c = 0; c < NCMAX; ++c)
 #pragma unroll
@@ -448,7 +473,8 @@ __global__ __launch_bounds__(TPB) void eval_ao_deriv1_kernel(
     switch (sh.l) {
       case 0: shell_eval_d1<0>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, plane, g); break;
       case 1: shell_eval_d1<1>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, plane, g); break;
-      default: shell_eval_d1<2>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, plane, g); break;
+      case 2: shell_eval_d1<2>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, plane, g); break;
+      default: shell_eval_d1<3>(sh, env, Ls, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, ao, ld, plane, g); break;
     }
   }
 }
@@ -489,24 +515,10 @@ __device__ inline void shell_eval_k_d1(const ShellDev sh, const double* __restri
             if (X > 0) rad1[c] += cs[c * sh.nprim + p] * es[p] * e;
           }
       }
-      double ang[DEG], gang[DEG];
-      const double dx = d[0], dy = d[1], dz = d[2];
-      if (L == 0) {
-        ang[0] = 1.0; gang[0] = 0.0;
-      } else if (L == 1) {
-        ang[0] = dx; ang[1] = dy; ang[2] = dz;
+      double ang[DEG], gang[DEG], g3[DEG][3];
+      angular_grad<L>(d, ang, g3);                  // (the two unused gradient components are dead code after inlining)
 #pragma unroll
-        for (int m = 0; m < 3; ++m) gang[m] = (X == m + 1) ? 1.0 : 0.0;
-      } else {
-        ang[0] = D_XY * dx * dy;
-        ang[1] = D_XY * dy * dz;
-        ang[2] = D_Z2_ZZ * dz * dz - D_Z2_XXYY * (dx * dx + dy * dy);
-        ang[3] = D_XY * dx * dz;
-        ang[4] = D_X2Y2 * (dx * dx - dy * dy);
-        if (X == 1) { gang[0] = D_XY * dy; gang[1] = 0.0; gang[2] = -2.0 * D_Z2_XXYY * dx; gang[3] = D_XY * dz; gang[4] = 2.0 * D_X2Y2 * dx; }
-        else if (X == 2) { gang[0] = D_XY * dx; gang[1] = D_XY * dz; gang[2] = -2.0 * D_Z2_XXYY * dy; gang[3] = 0.0; gang[4] = -2.0 * D_X2Y2 * dy; }
-        else { gang[0] = 0.0; gang[1] = D_XY * dy; gang[2] = 2.0 * D_Z2_ZZ * dz; gang[3] = D_XY * dx; gang[4] = 0.0; }
-      }
+      for (int m = 0; m < DEG; ++m) gang[m] = g3[m][X > 0 ? X - 1 : 0];
 #pragma unroll
       for (int c = 0; c < NCMAX; ++c)
 #pragma unroll
@@ -567,7 +579,8 @@ __global__ __launch_bounds__(TPB) void eval_ao_k_deriv1_kernel(
     switch (sh.l) {
       case 0: shell_eval_k_d1_all<0>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, plane, g); break;
       case 1: shell_eval_k_d1_all<1>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, plane, g); break;
-      default: shell_eval_k_d1_all<2>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, plane, g); break;
+      case 2: shell_eval_k_d1_all<2>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, plane, g); break;
+      default: shell_eval_k_d1_all<3>(sh, env, Ls, phT, img_list, nlist, px, py, pz, at.x, at.y, at.z, valid, pr, pi, out_re, out_im, ld, plane, g); break;
     }
   }
 }
@@ -608,8 +621,8 @@ static int upload_ao_tables(isdf_handle h, const int32_t* atm, int natm, const i
     const int32_t* b = bas + ib * BAS_SLOTS;
     const int ia = b[ATOM_OF];
     ARG_CHECK(h, ia >= 0 && ia < natm);
-    if (b[ANG_OF] > 2)
-      return isdf_fail(h, ISDF_ERR_ARG, "shell %d has l=%d; only l<=2 is supported", ib, b[ANG_OF]);
+    if (b[ANG_OF] > 3)
+      return isdf_fail(h, ISDF_ERR_ARG, "shell %d has l=%d; l <= 3 is supported", ib, b[ANG_OF]);
     if (b[NCTR_OF] > NCMAX)
       return isdf_fail(h, ISDF_ERR_ARG, "shell %d has %d contractions; at most %d supported", ib,
                        b[NCTR_OF], NCMAX);

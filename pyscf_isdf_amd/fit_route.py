@@ -71,13 +71,18 @@ class FitRouteMixin:
             return int(self.max_resident_rows), int(self.max_resident_rows)
         be = self.backend
         have = be.free_bytes() + sum(int(b.numel()) * 8 for k, b in self._bufs.items() if k in ('theta', 'W', 'factor', 'Dblk', 'Dinv', 'rows_scratch'))
+        if self.max_device_memory:
+            # the caller's cap on what the fit may occupy (the role max_memory plays for the reference's grid blocking,
+            # pyscf/pbc/dft/numint.py:1236-1257, fft_jk.py:240-244: fewer rows at once, same result) - minus what phi already holds
+            have = min(have, int(self.max_device_memory) - sum(int(b.numel()) * 8 for k, b in self._bufs.items() if k in ('ao', 'psi')))
         fixed = 4 * 8 * P * P + (3 << 30)
         if getattr(self, 'pair_space', 'ao') == 'occ':
             # occupied orbitals on the grid (nocc <= N/2 rows; the electron count is the usual case) + the product scratch
             nocc = min(self.cell.nao_nr() // 2, int(getattr(self.cell, 'nelectron', 0)) // 2 + 8)
             fixed += 8 * G * nocc + (2 << 30)
-        single = (have - fixed - 24 * 128 * G) // (8 * G)
-        panel = (have - fixed - 40 * 512 * G) // (8 * G)
+        fb = int(self.fft_batch or 0)
+        single = (have - fixed - 24 * (min(128, fb) if fb else 128) * G) // (8 * G)
+        panel = (have - fixed - 40 * (fb or 512) * G) // (8 * G)
         return max(0, int(single)), max(0, int(panel))
 
     def _panel_plan(self, ip_off, nrows_max):

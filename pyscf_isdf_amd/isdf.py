@@ -86,6 +86,9 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         self.block_apply_mfma = True      # block solves over the grid through explicit block inverses on the matrix cores
         self.max_resident_rows = None     # fit rows held in HBM at once (None: from free memory); fewer than the number of
                                           # points -> the rows are produced panel by panel (block-Jacobi route)
+        self.max_device_memory = None     # bytes the build may occupy on the device (None: what is free).  The reference's
+                                          # max_memory (MB of HOST memory, numint.py:1236-1257) sizes its grid blocks; here the
+                                          # blocking unit is the panel of fit rows: a smaller cap means more panels, same W
         self.n_panels = 1
         self._backend = backend
         self._comm = comm
@@ -364,7 +367,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         # how many fit rows HBM can hold next to everything else: above that the rows are produced panel by panel
         # (fit_route.FitRouteMixin._finish_W_paneled; block-Jacobi route only)
         # (decided once per problem size: later builds find the persistent buffers already allocated)
-        key = (Pmax, G, nao, self.max_resident_rows, self.fft_batch, self.pair_space)
+        key = (Pmax, G, nao, self.max_resident_rows, self.fft_batch, self.pair_space, self.max_device_memory)
         if getattr(self, '_rows_plan', (None,))[0] != key:
             self._rows_plan = (key,) + self._resident_rows(G, Pmax)
         rows_single, rows_panel = self._rows_plan[1:]

@@ -43,6 +43,39 @@ def test_eval_ao(be, mk):
     assert abs(got - ref).max() < 1e-12
 
 
+def _cell_spdf():
+    return gto.Cell(atom='He 0.3 0.1 0.2; He 1.9 2.2 1.4', basis={'He': [[0, [1.1, 1.0]], [1, [0.9, 1.0]], [2, [1.3, 1.0]],
+                                                                     [3, [1.2, 0.7], [0.5, 0.4]]]},
+                    a=np.array([[4.2, 0.3, 0.], [0.1, 4.0, 0.2], [0.4, 0., 4.4]]), mesh=[15, 14, 16], unit='B')
+
+
+def test_eval_ao_f_shells_values_derivatives_and_kpoints(be):
+    """l = 3 (f shells, contracted, triclinic cell) through all four collocation kernels against the oracle (1e-12): values,
+    Cartesian first derivatives, Bloch sums at a k-point and their derivatives.  The oracle's f combination is pinned by
+    orthonormality and finite differences (tests/test_oracle_pins.py) - the reference holds no f-shell fixture on this path."""
+    import torch
+    cell = _cell_spdf()
+    assert cell.nao_nr() == 2 * 16
+    ref, coords, Ls, rcut = _oracle_ao(cell)
+    got = be.to_host(_gpu_ao(be, cell, coords, Ls, rcut))
+    assert abs(got - ref).max() < 1e-12
+    G, nao = len(coords), cell.nao_nr()
+    d_c = be.to_device(np.ascontiguousarray(coords.T))
+    ao4 = be.empty((4, nao, G))
+    be.eval_ao_deriv1(cell._atm, cell._bas, cell._env, Ls, rcut, d_c, ao4)
+    ref4 = oao.eval_ao_deriv1(cell._atm, cell._bas, cell._env, coords, Ls, rcut)
+    assert abs(be.to_host(ao4) - ref4.transpose(0, 2, 1)).max() < 1e-11
+    kpt = np.array([0.21, -0.13, 0.34])
+    ur, ui = be.empty((nao, G)), be.empty((nao, G))
+    be.eval_ao_k(cell._atm, cell._bas, cell._env, Ls, rcut, kpt, False, d_c, ur, ui)
+    refk = np.asarray(oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpts=kpt.reshape(1, 3), rule='point')[0])
+    assert abs(be.to_host(ur) + 1j * be.to_host(ui) - refk.T).max() < 1e-12
+    buf = be.empty((2, 4, nao, G))
+    be.eval_ao_k_deriv1(cell._atm, cell._bas, cell._env, Ls, rcut, kpt, False, d_c, buf[0], buf[1])
+    refk4 = oao.eval_ao_deriv1(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpt=kpt)
+    assert abs(be.to_host(buf[0]) + 1j * be.to_host(buf[1]) - refk4.transpose(0, 2, 1)).max() < 1e-11
+
+
 def test_eval_ao_ragged_tail_and_permuted_coords(be):
     """Grid size not a multiple of the workgroup (9261 = 36*256 + 45) and a shuffled point order."""
     cell = cells.cell_he_c()
@@ -1164,3 +1197,27 @@ def test_occ_pair_space_end_to_end_matches_oracle_pipeline(route):
             assert abs(vk_b - k_ex).max() < abs(vk_ao - k_ex).max()
     assert np.array_equal(out['gpu'][1], out['cpu'][1])
     assert abs(out['gpu'][0] - out['cpu'][0]).max() < 1e-9 * abs(out['cpu'][0]).max()
+
+
+def test_max_device_memory_forces_panels_without_changing_the_result():
+    """max_device_memory (the role of the reference's max_memory-driven blocking, numint.py:1236-1257: less memory = more
+    blocks, same numbers): capping the build's device memory makes the block-Jacobi route produce its fit rows in panels; K is
+    the single-pass K to rounding."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_diamond_prim('gth-dzvp', (24, 24, 24))
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(2)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    ref = ISDF(cell, c_isdf=8, select='refined')
+    ref.fit_route = 'blockjacobi'
+    k0 = ref.get_jk(dm, with_j=False)[1]
+    assert ref.n_panels == 1
+    G = int(np.prod(cell.mesh))
+    df = ISDF(cell, c_isdf=8, select='refined')
+    df.fit_route, df.fft_batch = 'blockjacobi', 32
+    P = 8 * nao
+    # room for about half of the rows next to the fixed allowances of FitRouteMixin._resident_rows
+    df.max_device_memory = 8 * nao * G + 4 * 8 * P * P + (3 << 30) + 40 * 32 * G + 8 * G * (P // 2 + 24)
+    k1 = df.get_jk(dm, with_j=False)[1]
+    assert df.n_panels >= 2 and np.array_equal(df.ip, ref.ip)
+    assert abs(k1 - k0).max() < 1e-9 * abs(k0).max()
