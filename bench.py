@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet, MI355X FP64 matrix (the guide's table has no f64 row);
                                # best rocBLAS dgemm measured on the box: 73.8 (profiles/r01_probe_*.log)
-PMC_FILE = 'r02_pmc_bench_cfg3_fetch_write.json'
+PMC_FILE = 'r03_pmc_bench_cfg3_fetch_write.json'
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 

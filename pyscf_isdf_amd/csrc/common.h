@@ -58,6 +58,7 @@ struct isdf_ctx {
   // pair-density rows aoP ao: 0 = rocBLAS dgemm (default: 74 TF/s on that shape), 1 = the own MFMA NN kernel of gemm_f64.hip with
   // the square fused into its epilogue (66-71 TF/s; kept as the library-free route and for A/B runs)
   int gemm_nn_own = 0;
+  int attr_gemm_b = 0, attr_gemm_nn = 0;   // dynamic-LDS attributes raised on this handle's device
   int block_apply_reg = 1;   // block apply with the block inverse in registers, persistent over column tiles (trsm.hip)
   // range-separation parameter of the Gamma-point Coulomb kernel table (0 = plain 1/r); isdf_set_coulomb_omega
   double coul_omega = 0.0;
@@ -73,10 +74,10 @@ int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out
 // (workspace "coulG_half": valid until the next call)
 int get_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9], double extra_scale, double** out);
 // fft_conv.hip: d_out rows = ifft(cg * fft(d_in rows)) with the scaled half-spectrum table cg; zbuf nb * n0 n1 (n2/2+1) complex
-bool conv_rows_own_supported(const int32_t mesh[3]);
+bool conv_rows_own_supported(const int32_t mesh[3], int nb);
 // k-point form (fft_conv.hip): d_re + i d_im rows = ifft(tab * fft(d_in rows)) with a full real table; zhalf nb * n0 n1 (n2/2+1),
 // zfull nb * G complex scratch
-bool conv_rows_q_own_supported(isdf_handle h, const int32_t mesh[3]);
+bool conv_rows_q_own_supported(isdf_handle h, const int32_t mesh[3], int nb);
 int conv_rows_q_own(isdf_handle h, const double* d_in, double* d_re, double* d_im, int nb, const int32_t mesh[3], const double* tab,
                     double2* zhalf, double2* zfull);
 int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, const int32_t mesh[3], const double* cg,

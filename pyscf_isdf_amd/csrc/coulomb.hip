@@ -219,7 +219,7 @@ extern "C" int isdf_coulG_q(isdf_handle h, const int32_t mesh[3], const double a
 static int convolve_rows(isdf_handle h, const double* d_in, double* d_out, int nb, const int32_t mesh[3],
                          const double* cg, double2* zbuf) {
   const int64_t gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
-  if (h->own_fft && conv_rows_own_supported(mesh)) return conv_rows_own(h, d_in, d_out, nb, mesh, cg, zbuf);
+  if (h->own_fft && conv_rows_own_supported(mesh, nb)) return conv_rows_own(h, d_in, d_out, nb, mesh, cg, zbuf);
   FftPlan* plan = nullptr;
   int rc = isdf_get_plan(h, mesh, nb, &plan);
   if (rc) return rc;

@@ -868,8 +868,11 @@ int lines_per_tile(int n, int pad) {
 
 }  // namespace
 
-// Whether conv_rows_own can take this mesh.
-bool conv_rows_own_supported(const int32_t mesh[3]) {
+// Whether conv_rows_own can take this mesh and this many rows at once (the batch-dependent launch limits it checks itself:
+// callers fall back to hipFFT instead of failing).
+bool conv_rows_own_supported(const int32_t mesh[3], int nb) {
+  if (nb < 1 || (int64_t)nb * mesh[0] * mesh[1] * 4 >= 2147483647LL || (int64_t)nb * mesh[1] * (mesh[2] / 2 + 1) >= 2147483647LL)
+    return false;
   for (int d = 0; d < 3; ++d) {
     Axis ax;
     if (mesh[d] < 1 || mesh[d] > 1024 || !factorise(mesh[d], &ax)) return false;
@@ -917,12 +920,9 @@ int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, cons
                plane_lds ? 3 : 5);
   if (plane_lds) {
     // PLANE path: (z, y) forward per plane, x forward . table . x inverse, (y, z) inverse per plane
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIP_TRY(h, hipFuncSetAttribute((const void*)plane_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_TRY(h, hipFuncSetAttribute((const void*)plane_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
+    // (set on every call: the attribute is per device, a process-wide flag would skip a second device)
+    HIP_TRY(h, hipFuncSetAttribute((const void*)plane_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)plane_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const size_t ldsx = sizeof(double2) * ((size_t)n0 * FX + n0);
     const int ntx = (int)cdiv((int64_t)n1 * n2h, FX);
     const dim3 gp((unsigned)((int64_t)nb * n0)), gx((unsigned)((int64_t)nb * ntx));
@@ -997,8 +997,9 @@ int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, cons
 // k-point convolution of real rows with a FULL real kernel table (n0, n1, n2; no 1/G inside): Vre + i Vim = ifft(tab fft(rows)).
 // zhalf: nb * n0 n1 (n2/2+1) complex scratch, zfull: nb * G complex scratch.  Supported: 2-3-5 smooth meshes whose real and
 // complex (y, z) planes fit LDS (up to ~100^2 per plane: the k-point configs of BASELINE.json); the caller falls back to hipFFT.
-bool conv_rows_q_own_supported(isdf_handle h, const int32_t mesh[3]) {
+bool conv_rows_q_own_supported(isdf_handle h, const int32_t mesh[3], int nb) {
   if (!h->own_fft) return false;
+  if (nb < 1 || nb > 65535 || (int64_t)nb * mesh[0] >= 2147483647LL) return false;
   Axis ax[3];
   for (int d = 0; d < 3; ++d)
     if (mesh[d] < 2 || mesh[d] > 1024 || !factorise(mesh[d], &ax[d]) || !smooth235(ax[d])) return false;
@@ -1033,12 +1034,8 @@ int conv_rows_q_own(isdf_handle h, const double* d_in, double* d_re, double* d_i
   const size_t lds_r = plane_lds_bytes(n1, n2, &Lz, &bufsz), lds_c = plane_c2c_lds_bytes(n1, n2, &Lc, &bufc);
   const int FX = fast_lines(n0);
   ARG_CHECK(h, lds_r && lds_c && FX >= 1 && (int64_t)nb * n0 < 2147483647LL && nb <= 65535);
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(h, hipFuncSetAttribute((const void*)plane_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)plane_c2c_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  HIP_TRY(h, hipFuncSetAttribute((const void*)plane_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(h, hipFuncSetAttribute((const void*)plane_c2c_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // algorithmic bytes as the hipFFT form's label counts them: 8 G in, 16 G out per row and the table
   ProfScope ps(h, "coulomb_conv_q_own[byte]", 64.0 * (double)G * nb, 5);
   hipStream_t st = h->stream;

@@ -758,11 +758,10 @@ int gemm_nt_f64_scaled(isdf_handle h, int M, int N, int64_t K, double alpha, con
       else hipLaunchKernelGGL(gemm_nt_mfma_kernel_d<false>, dim3((unsigned)g.nunits_pad), dim3(TPBD), 0, h->stream, g);
     } else if (useB) {
       const size_t lds = sizeof(double) * 2 * (BM2 + BN) * LDT;
-      static bool attr_set = false;
-      if (!attr_set) {
+      if (!h->attr_gemm_b) {                       // per handle (= per device), not per process
         HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nt_mfma_kernel_b<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nt_mfma_kernel_b<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        h->attr_gemm_b = 1;
       }
       if (kscale) hipLaunchKernelGGL(gemm_nt_mfma_kernel_b<true>, dim3((unsigned)g.nunits_pad), dim3(TPB2), lds, h->stream, g);
       else hipLaunchKernelGGL(gemm_nt_mfma_kernel_b<false>, dim3((unsigned)g.nunits_pad), dim3(TPB2), lds, h->stream, g);
@@ -816,11 +815,10 @@ int gemm_nn_f64(isdf_handle h, int64_t M, int64_t N, int64_t K, const double* A,
   g.nunits_pad = cdiv(g.nunits, 8) * 8;
   ARG_CHECK(h, g.nunits_pad < 2147483647LL);
   const size_t lds = sizeof(double) * 2 * (BM2 * LDT + BK * LDN);
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!h->attr_gemm_nn) {
     HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nn_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(h, hipFuncSetAttribute((const void*)gemm_nn_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    h->attr_gemm_nn = 1;
   }
   ProfScope ps(h, square ? "gemm_nn_mfma_kernel<true>[flop]" : "gemm_nn_mfma_kernel<false>[flop]", 2.0 * M * N * (double)K);
   if (square) hipLaunchKernelGGL(gemm_nn_mfma_kernel<true>, dim3((unsigned)g.nunits_pad), dim3(TPB2), lds, h->stream, g);

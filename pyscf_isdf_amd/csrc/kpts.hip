@@ -177,7 +177,7 @@ extern "C" int isdf_coulomb_Wq(isdf_handle h, const double* d_theta, int P, int6
   if (!Z || !Vre || !Vim) return ISDF_ERR_HIP;
   // own FFT (fft_conv.hip: real-input forward through the half spectrum, table-expanding multiply, complex inverse) where the
   // mesh allows, hipFFT Z2Z otherwise
-  const bool own = conv_rows_q_own_supported(h, mesh);
+  const bool own = conv_rows_q_own_supported(h, mesh, batch);
   double2* Zh = nullptr;
   if (own) {
     Zh = (double2*)isdf_ws(h, "coul_Z", sizeof(double2) * (size_t)batch * mesh[0] * mesh[1] * (mesh[2] / 2 + 1));

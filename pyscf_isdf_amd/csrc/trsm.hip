@@ -275,42 +275,36 @@ __global__ __launch_bounds__(64 * ((NT + 1) / 2)) __attribute__((amdgpu_waves_pe
     }
     __syncthreads();
     if (tile + gridDim.x < ntile) fetch(tile + gridDim.x);            // in flight under the MFMAs below
-    d4v accA[NCT], accB[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) accA[ct] = accB[ct] = (d4v){0.0, 0.0, 0.0, 0.0};
-    const double* pb = sB + (8 * fk) * LDB + fr;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      if (c < nchA) {
-        const double* q = pb + (32 * c) * LDB;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct)
-            accA[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[8 * c + j], q[j * LDB + 16 * ct], accA[ct], 0, 0, 0);
-      } else if (c < nchA + nchB) {
-        const double* q = pb + (32 * (c - nchA)) * LDB;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct)
-            accB[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[8 * c + j], q[j * LDB + 16 * ct], accB[ct], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);       // keep a chunk's LDS reads with its MFMAs: hoisting all of them costs 100+ VGPRs
-    }
     const int64_t c0 = tile * TN;
+    // the column sub-tiles one after the other: one accumulator pair live at a time (both at once cost 16 more VGPRs per
+    // sub-tile and spilled for NT >= 12)
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
+      d4v accA = (d4v){0.0, 0.0, 0.0, 0.0}, accB = (d4v){0.0, 0.0, 0.0, 0.0};
+      const double* pb = sB + (8 * fk) * LDB + 16 * ct + fr;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c < nchA) {
+          const double* q = pb + (32 * c) * LDB;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) accA = __builtin_amdgcn_mfma_f64_16x16x4f64(a[8 * c + j], q[j * LDB], accA, 0, 0, 0);
+        } else if (c < nchA + nchB) {
+          const double* q = pb + (32 * (c - nchA)) * LDB;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) accB = __builtin_amdgcn_mfma_f64_16x16x4f64(a[8 * c + j], q[j * LDB], accB, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);       // keep a chunk's LDS reads with its MFMAs: hoisting all of them costs 100+ VGPRs
+      }
       const int64_t col = c0 + ct * 16 + fr;
       if (col < n) {
         double* Xb = X + (int64_t)off * ldx + col;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rowA = tA * 16 + fk + 4 * r;
-          if (rowA < m) Xb[(int64_t)rowA * ldx] = accA[ct][r];
+          if (rowA < m) Xb[(int64_t)rowA * ldx] = accA[r];
           if (nchB > 0) {
             const int rowB = tB * 16 + fk + 4 * r;
-            if (rowB < m) Xb[(int64_t)rowB * ldx] = accB[ct][r];
+            if (rowB < m) Xb[(int64_t)rowB * ldx] = accB[r];
           }
         }
       }
@@ -364,7 +358,7 @@ int block_apply_inverse(isdf_handle h, const double* Dinv, int64_t ldd, int nblk
     const int nt = (mmax + 15) / 16;
     if (nt <= 8) return block_apply_reg_launch<8, 2>(h, Dinv, ldd, nblk, d_off, X, ldx, n, square_input);
     if (nt <= 10) return block_apply_reg_launch<10, 2>(h, Dinv, ldd, nblk, d_off, X, ldx, n, square_input);
-    if (nt <= 12) return block_apply_reg_launch<12, 1>(h, Dinv, ldd, nblk, d_off, X, ldx, n, square_input);
+    if (nt <= 12) return block_apply_reg_launch<12, 2>(h, Dinv, ldd, nblk, d_off, X, ldx, n, square_input);
     return block_apply_reg_launch<16, 1>(h, Dinv, ldd, nblk, d_off, X, ldx, n, square_input);
   }
   // 64 columns per workgroup while the block's rows fit 52 KB of LDS (three workgroups per CU), else 32, else 16

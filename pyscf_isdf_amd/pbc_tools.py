@@ -23,7 +23,10 @@ def unique_q(kpts, kpts_band=None, tol=1e-9):
 
 def wigner_seitz_kernel(a, nk):
     """The tabulated part of exxdiv='vcut_ws' (PRB 87, 165122; the role of pyscf/pbc/tools/pbc.py:422-480).  For a k-mesh of
-    nk = (n1, n2, n3) points the exchange hole lives in the nk-fold cell with lattice A = diag(nk) a.  The Coulomb kernel is
+    nk = (n1, n2, n3) points the exchange hole lives in the nk-fold cell with lattice A = diag(nk) a (ROWS scaled: a_i -> nk_i a_i.
+    Deliberate deviation: the reference writes `cell.lattice_vectors() * Nk` (pbc.py:434), which scales COLUMNS; the two agree
+    for orthogonal cells and isotropic k-meshes - the only case the reference pins - and differ for an anisotropic mesh on a
+    non-orthogonal cell, which is parity unpinned).  The Coulomb kernel is
     split as erfc(alpha r)/r + erf(alpha r)/r; the first part is short-ranged and keeps its analytic transform, the second is
     cut at the Wigner-Seitz cell of A: it is tabulated on a real-space mesh of A as erf(alpha r_min)/r_min with r_min the
     distance to the nearest lattice point (the corners of the parallelepiped, by periodicity) and Fourier transformed once.

@@ -47,7 +47,7 @@ for sel in selects:
         t0 = time.perf_counter()
         vk = df.get_jk(tdm if space == 'occ' else dm, with_j=False)[1]
         t1 = time.perf_counter()
-        nip, route_used = len(df.ip), df.fit_route_used
+        nip, route_used = len(df.ip), '%s, %d panel(s), probe %s' % (df.fit_route_used, df.n_panels, ('%.1e' % df.bj_check) if df.bj_check is not None else '-')
         if ref is None:
             df.release_fit_buffers()            # the fit's buffers fill HBM at large c; the exact exchange needs phi only
             ref = df.get_k_exact(mo_coeff=c, mo_occ=occ)

@@ -5,7 +5,7 @@
 #   3. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (they do not fit one pass on gfx950)
 # then tools/pmc_summarise.py folds 3 into one JSON.  Copy what is to be judged from gpurun_out/$TAG into profiles/.
 set -o pipefail
-TAG=${1:-r02_prof}
+TAG=${1:-r03_prof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1

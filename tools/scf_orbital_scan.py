@@ -106,6 +106,11 @@ for v in variants:
         t1 = time.perf_counter()
         vk = d2.get_jk(tdm, with_j=False)[1]
         dt = time.perf_counter() - t1
+        if os.environ.get('SCAN_WARM'):               # second build + K with the buffers in place: what a repeated caller pays
+            t1 = time.perf_counter()
+            d2.build()
+            vk = d2.get_jk(tdm, with_j=False)[1]
+            dt = time.perf_counter() - t1
         if 'bj' in flags and d2.n_panels == 1:
             import warnings
             with warnings.catch_warnings():
