@@ -50,6 +50,10 @@ def parse_args():
                     help='interpolation points per AO; default: 12 for the headline workload (the accuracy scan of DESIGN.md section 2), else 10')
     ap.add_argument('--fit-route', default=None, choices=['auto', 'cholesky', 'blockjacobi'])
     ap.add_argument('--robust-k', action='store_true', help='time the build + get_jk with the robust exchange (not the headline)')
+    ap.add_argument('--density', default='random', choices=['random', 'scf'],
+                    help="'random': BASELINE.json's benchmark density (random orthogonal orbitals; the headline); 'scf': physical "
+                         "orbitals - an RHF converged with the ISDF object itself before anything is timed (hcore from the device, S and T "
+                         "by plane-wave quadrature of the AO values); Gamma-point workloads, one GPU")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--stage-report', default=None, help='write the per-kernel table to this file')
     return ap.parse_args()
@@ -162,6 +166,64 @@ def cpu_baseline_exact_fftdf(cell, nocc):
                    'grid contraction (%.4f s per pair) to N*nocc = %d pairs' % (npair, t_fft, nrow, t_dot, pairs))
 
 
+def scf_density(cell, c_isdf=10):
+    """Physical orbitals for the accuracy entry: a closed-shell RHF driven by an AO-pair ISDF object (get_pp, J, K from the device;
+    S and T by plane-wave quadrature of the collocated AOs with torch.fft - plumbing, outside every timed region).  Returns
+    (dm, C_occ, occ)."""
+    import scipy.linalg
+    import torch
+    from pyscf_isdf_amd.isdf import ISDF
+    nao, nocc = cell.nao_nr(), cell.nelectron // 2
+    mesh = [int(x) for x in cell.mesh]
+    G = int(np.prod(mesh))
+    df = ISDF(cell, c_isdf=c_isdf, select='refined')
+    df.collocate()
+    b = 2 * np.pi * np.linalg.inv(cell.lattice_vectors().T)
+    fr = [np.fft.fftfreq(n, 1. / n) for n in mesh]
+    Gv = (fr[0][:, None, None, None] * b[0] + fr[1][None, :, None, None] * b[1] + fr[2][None, None, :, None] * b[2]).reshape(-1, 3)
+    g2 = df.backend.to_device(np.einsum('gi,gi->g', Gv, Gv))
+    F = torch.empty((nao, G), dtype=torch.complex128, device=df.backend.device)
+    for r0 in range(0, nao, 64):
+        r1 = min(nao, r0 + 64)
+        F[r0:r1] = torch.fft.fftn(df.ao[r0:r1].reshape(r1 - r0, *mesh), dim=(1, 2, 3)).reshape(r1 - r0, G)
+    T = ((0.5 * cell.vol / G ** 2) * torch.matmul(F.conj() * g2, F.T).real).cpu().numpy()
+    S = ((cell.vol / G ** 2) * torch.matmul(F.conj(), F.T).real).cpu().numpy()
+    del F, g2
+    df.reset()
+    torch.cuda.empty_cache()
+    hcore = T + df.get_pp()
+    torch.cuda.empty_cache()
+    e, c = scipy.linalg.eigh(hcore, S)
+    dm = 2 * c[:, :nocc].dot(c[:, :nocc].T)
+    errs, focks, e_last = [], [], 0.0
+    for it in range(30):
+        vj, vk = df.get_jk(dm)
+        f = hcore + vj - 0.5 * vk
+        e_el = 0.5 * np.einsum('ij,ji', hcore + f, dm)
+        err = f.dot(dm).dot(S) - S.dot(dm).dot(f)
+        focks.append(f); errs.append(err); focks, errs = focks[-8:], errs[-8:]
+        n = len(focks)
+        if n > 1:
+            B = -np.ones((n + 1, n + 1)); B[n, n] = 0
+            for i in range(n):
+                for j in range(n):
+                    B[i, j] = np.vdot(errs[i], errs[j])
+            rhs = np.zeros(n + 1); rhs[n] = -1
+            f = sum(ci * fi for ci, fi in zip(np.linalg.lstsq(B, rhs, rcond=None)[0][:n], focks))
+        if abs(e_el - e_last) < 1e-8 and abs(err).max() < 1e-5:
+            break
+        e_last = e_el
+        e, c = scipy.linalg.eigh(f, S)
+        dm = 2 * c[:, :nocc].dot(c[:, :nocc].T)
+    print('[bench] SCF orbitals ready after %d iterations (E_el %.8f)' % (it + 1, e_el), file=sys.stderr, flush=True)
+    df.reset()
+    del df
+    torch.cuda.empty_cache()
+    occ = np.zeros(nao)
+    occ[:nocc] = 2
+    return dm, np.ascontiguousarray(c), occ
+
+
 def spawn_ranks(n):
     """python bench.py --gpus N with no launcher around it: start the N ranks as a fresh child (torch.distributed.run, one
     rank per GPU) BEFORE this process touches torch or the GPU, relay its output and return its exit code."""
@@ -202,7 +264,12 @@ def main():
     cell = workloads.make_cell(args.workload)
     kpts = workloads.make_kpts(args.workload, cell)
     if kpts is None:
-        dm, c_mo, occ_mo = workloads.make_dm(cell)
+        if args.density == 'scf':
+            if world != 1:
+                raise SystemExit('--density scf is a one-GPU option')
+            dm, c_mo, occ_mo = scf_density(cell)
+        else:
+            dm, c_mo, occ_mo = workloads.make_dm(cell)
         if args.pair_space == 'occ':
             class _Tagged(np.ndarray):          # numpy_helper.tag_array's role: the density carries its orbitals
                 pass
@@ -254,7 +321,7 @@ def main():
     # pairs) for the benchmark density on this GPU - measured in this run, never read from a file
     vk_exact = None
     t_exact = 0.0
-    if world == 1 and kpts is None and not args.no_accuracy and not args.robust_k:
+    if world == 1 and kpts is None and not args.no_accuracy:
         print('[bench] exact exchange on the GPU for the accuracy entry (about 40 s)', file=sys.stderr, flush=True)
         ta = time.perf_counter()
         vk_exact = df.get_k_exact(mo_coeff=c_mo, mo_occ=occ_mo)
@@ -390,6 +457,8 @@ def main():
         # isdf_get_k_exact; outside the timed region).  J is the reference's own formula (fft_jk.py:33-109): no fit error.
         out['config']['dE_K_vs_exact'] = None
         out['config']['pair_space'] = args.pair_space
+        out['config']['density'] = ('random orthogonal orbitals (BASELINE.json)' if args.density == 'random' else
+                                    'SCF orbitals (RHF converged with the ISDF object before the timed steps)')
         if vk_exact is not None:
             ek_ex = float(np.einsum('ij,ji', vk_exact, np.asarray(dm)) / 4)
             out['config']['dE_K_vs_exact'] = float(out['energies']['EK'] - ek_ex)

@@ -403,6 +403,16 @@ int isdf_get_k_exact_kpt(isdf_handle h, const double* d_u1r, const double* d_u1i
                          const double* d_m2r, const double* d_m2i, int nocc, int64_t ld2, const int32_t mesh[3],
                          const double* d_coulG, double weight, int i0, int ni, int max_rows, double* d_vk_re,
                          double* d_vk_im);
+
+/* Robust K at k-points (Dunlap's correction with V^q = conv_q(Theta)): building blocks next to isdf_gemm_nn /
+ * isdf_gemm_nt on the real / imaginary planes.
+ *   isdf_coulomb_rows_q:   (d_re + i d_im)[r] = ifft(coulG(q) fft(rows[r])) for nrows real rows of G = prod(mesh) points (ld == G);
+ *                          d_coulG from isdf_coulG_q; the convolution step of isdf_coulomb_Wq on its own
+ *   isdf_zhadamard_planes: (Ar + i Ai) .*= (Br + i Bi) on `rows` x `cols` planes */
+int isdf_coulomb_rows_q(isdf_handle h, const double* d_rows, int nrows, int64_t ld, const int32_t mesh[3],
+                        const double* d_coulG, double* d_re, double* d_im);
+int isdf_zhadamard_planes(isdf_handle h, double* d_Ar, double* d_Ai, int64_t lda, const double* d_Br, const double* d_Bi,
+                          int64_t ldb, int rows, int64_t cols);
 int isdf_rho_k(isdf_handle h, const double* d_ur, const double* d_ui, int nao, int64_t ng, int64_t ld,
                const double* d_DTr, const double* d_DTi, double scale, double* d_rho);
 int isdf_vj_k(isdf_handle h, const double* d_ur, const double* d_ui, int nao, int64_t ng, int64_t ld,

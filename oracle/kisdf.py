@@ -135,3 +135,35 @@ def build(ao_kpts, coords, kpts, a, mesh, nip, kpts_band=None, reg_rel=0.0, tie_
     r_ip = coords[piv]
     Ws = [build_Wq(theta, a, mesh, q, r_ip) for q in qs]
     return dict(ip=piv, theta=theta, qs=qs, qindex=qindex, W=Ws, aoP=[np.ascontiguousarray(ao[piv]) for ao in ao_kpts])
+
+
+def get_k_robust_kpts(ao_kpts, coords, kpts, a, mesh, ip, theta, dms, ao_band=None, kpts_band=None):
+    """K at k-points with Dunlap's robust correction: K = K1 + K1^H - K_isdf (Hermitian density matrices), where K_isdf is
+    get_k_kpts with the W^q of ``theta`` and (in periodic parts u = exp(-i k.r) phi, q = k2 - k1)
+        K1^{k1}_{pq} = w/nk sum_{k2} sum_P conj(u1_p(r_P)) sum_g V^q_P(g) [sum_ls u2_l(r_P) D^{k2}_ls conj(u2_s(g))] u1_q(g),
+    V^q_P = conv_q(Theta_P): the fitted pair density on one side of the reference's exchange integral
+    (pyscf/pbc/df/fft_jk.py:250-292), the exact one on the other; the error becomes quadratic in the fit error."""
+    kpts = np.reshape(kpts, (-1, 3))
+    band = kpts if kpts_band is None else np.reshape(kpts_band, (-1, 3))
+    ao_band = ao_kpts if ao_band is None else ao_band
+    nk = len(kpts)
+    G = theta.shape[1]
+    w = abs(np.linalg.det(a)) / G
+    u2s = [(np.asarray(ao) * np.exp(-1j * coords.dot(k))[:, None]).T for ao, k in zip(ao_kpts, kpts)]      # (nao, G)
+    u1s = [(np.asarray(ao) * np.exp(-1j * coords.dot(k))[:, None]).T for ao, k in zip(ao_band, band)]
+    qs, qindex = unique_q(kpts, kpts_band)
+    r_ip = coords[ip]
+    Ws = [build_Wq(theta, a, mesh, q, r_ip) for q in qs]
+    aoP = [np.ascontiguousarray(np.asarray(ao)[ip]) for ao in ao_kpts]
+    aoPb = [np.ascontiguousarray(np.asarray(ao)[ip]) for ao in ao_band]
+    k_isdf = get_k_kpts(aoP, Ws, qindex, dms, aoP_band=aoPb)
+    out = []
+    for i1, u1 in enumerate(u1s):
+        k1 = 0
+        for i2, u2 in enumerate(u2s):
+            V = coulomb_Vq(theta, a, mesh, kpts[i2] - band[i1])                     # (P, G) complex
+            F = u2[:, ip].T.dot(dms[i2]).dot(u2.conj())                             # (P, G)
+            k1 = k1 + u1[:, ip].conj().dot((V * F).dot(u1.T))
+        k1 = k1 * (w / nk)
+        out.append(k1 + k1.conj().T - k_isdf[i1])
+    return np.array(out)

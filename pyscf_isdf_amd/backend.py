@@ -607,6 +607,21 @@ class HipBackend:
                          self._p(m2i), m2r.shape[0], m2r.stride(0), _np_ptr(mesh), self._p(coulG), float(weight), int(i0), int(ni),
                          int(max_rows), self._p(vk_re), self._p(vk_im))
 
+    def coulomb_rows_q(self, rows, mesh, coulG, out_re, out_im):
+        """out_re + i out_im <- ifft(coulG fft(rows)) for real rows (n, G) contiguous."""
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        assert rows.is_contiguous() and out_re.is_contiguous() and out_im.is_contiguous()
+        self.handle.call('isdf_coulomb_rows_q', self._p(rows), rows.shape[0], rows.stride(0), _np_ptr(mesh), self._p(coulG),
+                         self._p(out_re), self._p(out_im))
+
+    def zhadamard_planes(self, Ar, Ai, Br, Bi):
+        """(Ar + i Ai) .*= (Br + i Bi)."""
+        self._stream()
+        assert Ar.stride() == Ai.stride() and Br.stride() == Bi.stride() and Ar.stride(1) == 1 and Br.stride(1) == 1
+        self.handle.call('isdf_zhadamard_planes', self._p(Ar), self._p(Ai), Ar.stride(0), self._p(Br), self._p(Bi), Br.stride(0),
+                         Ar.shape[0], Ar.shape[1])
+
     def rho_k(self, ur, ui, ng, DTr, DTi, scale, rho):
         self._stream()
         self.handle.call('isdf_rho_k', self._p(ur), self._p(ui), ur.shape[0], int(ng), ur.stride(0), self._p(DTr),

@@ -129,6 +129,17 @@ __global__ void pair_reduce_cplx_kernel(const double2* __restrict__ Z, const dou
   Ti[(int64_t)p * G + g] = si;
 }
 
+// (Ar + i Ai) *= (Br + i Bi), element-wise on planes of `cols` columns
+__global__ void zhadamard_planes_kernel(double* __restrict__ Ar, double* __restrict__ Ai, int64_t lda, const double* __restrict__ Br,
+                                        const double* __restrict__ Bi, int64_t ldb, int64_t cols) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (c >= cols) return;
+  const double ar = Ar[r * lda + c], ai = Ai[r * lda + c], br = Br[r * ldb + c], bi = Bi[r * ldb + c];
+  Ar[r * lda + c] = ar * br - ai * bi;
+  Ai[r * lda + c] = ar * bi + ai * br;
+}
+
 inline rocblas_operation zop(char c) {
   return c == 'N' ? rocblas_operation_none : (c == 'T' ? rocblas_operation_transpose : rocblas_operation_conjugate_transpose);
 }
@@ -214,6 +225,46 @@ extern "C" int isdf_coulomb_Wq(isdf_handle h, const double* d_theta, int P, int6
                      d_Wim + (int64_t)r * ldw + c0, ldw);
     if (rc) return rc;
   }
+  return ISDF_OK;
+}
+
+extern "C" int isdf_coulomb_rows_q(isdf_handle h, const double* d_rows, int nrows, int64_t ld, const int32_t mesh[3],
+                                   const double* d_coulG, double* d_re, double* d_im) {
+  // (d_re + i d_im)[r] = ifft(coulG(q) fft(rows[r])): the k-point convolution of real rows with a full real kernel table, rows of
+  // G contiguous (ld == G) - V^q = conv_q(Theta) for the robust K at k-points; the convolution step of isdf_coulomb_Wq on its own
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_rows && mesh && d_coulG && d_re && d_im && nrows > 0);
+  const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  ARG_CHECK(h, ld == G);
+  double2* Z = (double2*)isdf_ws(h, "coul_Zfull", sizeof(double2) * (size_t)nrows * G);
+  if (!Z) return ISDF_ERR_HIP;
+  if (conv_rows_q_own_supported(h, mesh, nrows)) {
+    double2* Zh = (double2*)isdf_ws(h, "coul_Z", sizeof(double2) * (size_t)nrows * mesh[0] * mesh[1] * (mesh[2] / 2 + 1));
+    if (!Zh) return ISDF_ERR_HIP;
+    return conv_rows_q_own(h, d_rows, d_re, d_im, nrows, mesh, d_coulG, Zh, Z);
+  }
+  hipfftHandle plan;
+  int rc = get_z2z_plan(h, mesh, nrows, &plan);
+  if (rc) return rc;
+  const int64_t total = (int64_t)nrows * G;
+  const unsigned nblocks = (unsigned)std::min<int64_t>(cdiv(total, 256), (int64_t)h->num_cu * 16);
+  ProfScope ps(h, "coulomb_conv_z2z[byte]", 64.0 * (double)total, 5);
+  hipLaunchKernelGGL(pack_real_to_complex_kernel, dim3(nblocks), dim3(256), 0, h->stream, d_rows, Z, total);
+  FFT_TRY(h, hipfftExecZ2Z(plan, (hipfftDoubleComplex*)Z, (hipfftDoubleComplex*)Z, HIPFFT_FORWARD));
+  hipLaunchKernelGGL(mul_full_kernel, dim3(nblocks), dim3(256), 0, h->stream, Z, d_coulG, G, total, 1.0 / (double)G);
+  FFT_TRY(h, hipfftExecZ2Z(plan, (hipfftDoubleComplex*)Z, (hipfftDoubleComplex*)Z, HIPFFT_BACKWARD));
+  hipLaunchKernelGGL(unpack_complex_kernel, dim3(nblocks), dim3(256), 0, h->stream, Z, d_re, d_im, total);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_zhadamard_planes(isdf_handle h, double* d_Ar, double* d_Ai, int64_t lda, const double* d_Br, const double* d_Bi,
+                                     int64_t ldb, int rows, int64_t cols) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_Ar && d_Ai && d_Br && d_Bi && rows > 0 && rows <= 65535 && cols > 0 && lda >= cols && ldb >= cols);
+  hipLaunchKernelGGL(zhadamard_planes_kernel, dim3((unsigned)cdiv(cols, 256), (unsigned)rows), dim3(256), 0, h->stream, d_Ar, d_Ai,
+                     lda, d_Br, d_Bi, ldb, cols);
+  KERNEL_CHECK(h);
   return ISDF_OK;
 }
 

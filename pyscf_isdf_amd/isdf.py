@@ -264,9 +264,6 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
     def build(self):
         self.check_sanity()
         self._drop_build_state()
-        if self.robust_k:
-            if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
-                raise NotImplementedError('robust_k is implemented at the Gamma point')
         if not self._is_gamma(self.kpts) or not self._is_gamma(self.kpts_band):
             return self._build_kpts()
         if self._sharded:

@@ -89,6 +89,7 @@ class KPointMixin:
                 kall.append(kb)
                 self._band_index.append(len(kall) - 1)
         kpts = np.array(kall)
+        self._kstack = kpts.copy()           # k-vectors of the stacked periodic parts (SCF k-points, then extra band k-points)
         nk = len(kpts)                       # size of the stack; the first len(kpts_scf) entries carry density
         mesh = np.asarray(self.mesh, dtype=np.int32)
         G = int(np.prod(mesh))
@@ -178,7 +179,7 @@ class KPointMixin:
         # Jacobi, verified on W^{q=0}, Cholesky when the check fails (the fit is replicated, so every rank takes the
         # agreed decision after its share of the q list)
         routes = self._fit_routes() if self.select != 'global' else ['cholesky']
-        if self.fit_route == 'auto' and not self.bj_auto_kpts:
+        if (self.fit_route == 'auto' and not self.bj_auto_kpts) or self._want_theta:
             routes = ['cholesky']
         for route in routes:
             if route == 'blockjacobi':
@@ -188,7 +189,7 @@ class KPointMixin:
             else:
                 chol = self._buffer('factor', (P, P))
                 self.reg_used = be.fit_prepare_cplx(X, nh, ip_dev, self.reg_rel, aoP_X, chol)
-                be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=not self.explicit_theta)
+                be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=not self._want_theta)
             t0 = self._tick('S3_fit', t0)
             self._kfit_state = dict(route=route, Y=Y, primary=primary, r_ip=r_ip, batch=batch, nao=nao, nh=nh, aoP_X=aoP_X,
                                     chol=None if route == 'blockjacobi' else chol,
@@ -248,7 +249,7 @@ class KPointMixin:
                     check = self._bj_probe_mismatch(planes, Afac, Dblk, ip_off, Y, G, None, W=Wre)
                     del planes
                     t0 = self._tick('S5_route_check', t1)
-            elif not self.explicit_theta:
+            elif not self._want_theta:
                 be.W_from_factor(st['chol'], 0, Wre)
                 be.W_from_factor(st['chol'], 0, Wim)
             Wc = be.empty((P, P), dtype=torch.complex128)
@@ -382,6 +383,12 @@ class KPointMixin:
                 flat = torch.view_as_real(d_vk)
                 comm.all_reduce_sum(flat)
             vk = be.to_host(d_vk)
+            if self.robust_k:
+                if Wq_set is not self._Wq or ex in ('vcut_sph', 'vcut_ws'):
+                    raise NotImplementedError('robust_k at k-points: plain kernel only (exxdiv None or ewald, no omega)')
+                if not herm_dm:
+                    raise NotImplementedError('robust_k at k-points needs Hermitian density matrices')
+                vk = self._robust_k_kpts(dms, vk, bidx, kpts, self._nk_stack)
             if ex == 'ewald':
                 # vk[k] += madelung * S^k D^k S^k (pyscf/pbc/df/df_jk.py:1446-1465) for the band k-points that are
                 # k-points of the density; S^k by quadrature on the grid from the periodic parts (the phases cancel)
@@ -398,6 +405,67 @@ class KPointMixin:
             t0 = self._tick('S7_get_k', t0)
             vk = vk.reshape(out_shape)
         return vj, vk
+
+    def _robust_k_kpts(self, dms, vk_isdf, bidx, kpts, nks):
+        """K <- K1 + K1^H - K_isdf at k-points (Dunlap's robust form; Hermitian density matrices):
+            K1^{k1}_{pq} = w/nk sum_{k2} sum_P conj(u1_p(r_P)) sum_g V^q_P(g) [u2_P D^{k2} conj(u2(g))] u1_q(g),   q = k2 - k1,
+        V^q_P = conv_q(Theta_P) recomputed per call, batch of points by batch (keeping it for all q would take nq x 16 P G bytes:
+        2.9 TB at configs[3]); per (k1, k2) and batch two complex (batch, N, G) products on the real / imaginary planes
+        (isdf_gemm_nn, isdf_zhadamard_planes, isdf_gemm_nt).  Cost 16 nk^2 P N G flop per K: a small-cell, high-accuracy path.
+        Single process."""
+        cell, be, comm = self.cell, self.backend, self.comm
+        if comm.size > 1:
+            raise NotImplementedError('robust_k at k-points is a single-process path')
+        st = self._kfit_state
+        theta, aoP_X, nao, nh = st['Y'], st['aoP_X'], st['nao'], st['nh']     # Theta itself (build with robust_k: both solves)
+        P, G = theta.shape
+        nk = len(kpts)
+        nset, nband = vk_isdf.shape[0], len(bidx)
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        a = np.asarray(cell.lattice_vectors(), dtype=float)
+        w = cell.vol / G
+        X = self.ao
+
+        def planes(k):
+            return X[k * nao:(k + 1) * nao], X[nh + k * nao:nh + (k + 1) * nao]
+        uP = be.to_host(aoP_X)                                                 # periodic parts at the points, (P, 2 nh)
+        uPk = [uP[:, k * nao:(k + 1) * nao] + 1j * uP[:, nh + k * nao:nh + (k + 1) * nao] for k in range(nks)]
+        band_vec = [self._kstack[b] for b in bidx]
+        nb = max(1, min(P, int((3 << 30) // (16 * G))))
+        Vr, Vi = be.empty((nb, G)), be.empty((nb, G))
+        Fr, Fi = be.empty((nb, G)), be.empty((nb, G))
+        Kr, Ki = be.empty((nb, nao)), be.empty((nb, nao))
+        coulG = be.empty((G,))
+        out = vk_isdf.reshape(nset, nband, nao, nao).copy()
+        k1acc = np.zeros((nset, nband, nao, nao), dtype=np.complex128)
+        for i1, b1 in enumerate(bidx):
+            u1r, u1i = planes(b1)
+            for k2 in range(nk):
+                be.coulG_q(mesh, a, kpts[k2] - band_vec[i1], out=coulG)
+                u2r, u2i = planes(k2)
+                for r0 in range(0, P, nb):
+                    r1 = min(P, r0 + nb)
+                    n = r1 - r0
+                    be.coulomb_rows_q(theta[r0:r1], mesh, coulG, Vr[:n], Vi[:n])
+                    for s in range(nset):
+                        T = uPk[k2][r0:r1].dot(dms[s, k2])                    # (n, N) complex: u2_P D
+                        Tr, Ti = be.to_device(np.ascontiguousarray(T.real)), be.to_device(np.ascontiguousarray(T.imag))
+                        # F = T conj(u2) = (Tr u2r + Ti u2i) + i (Ti u2r - Tr u2i)
+                        be.gemm_nn(Tr, u2r, Fr[:n])
+                        be.gemm_nn(Ti, u2i, Fr[:n], beta=1.0)
+                        be.gemm_nn(Ti, u2r, Fi[:n])
+                        be.gemm_nn(Tr, u2i, Fi[:n], alpha=-1.0, beta=1.0)
+                        be.zhadamard_planes(Fr[:n], Fi[:n], Vr[:n], Vi[:n])   # F <- V o F
+                        # (V o F) u1^T = (Fr u1r^T - Fi u1i^T) + i (Fr u1i^T + Fi u1r^T)
+                        be.gemm_nt(Fr[:n], u1r, Kr[:n])
+                        be.gemm_nt(Fi[:n], u1i, Kr[:n], alpha=-1.0, beta=1.0)
+                        be.gemm_nt(Fr[:n], u1i, Ki[:n])
+                        be.gemm_nt(Fi[:n], u1r, Ki[:n], beta=1.0)
+                        Kt = be.to_host(Kr[:n]) + 1j * be.to_host(Ki[:n])
+                        k1acc[s, i1] += uPk[b1][r0:r1].conj().T.dot(Kt)
+        k1acc *= w / nk
+        out = k1acc + k1acc.conj().transpose(0, 1, 3, 2) - out
+        return out.reshape(vk_isdf.shape)
 
     def _get_ao_eri_kpts(self, kpts, mo_coeffs=None):
         """(i^{k1} j^{k2} | k^{k3} l^{k4}) = sum_PQ conj(phi^{k1}_i) phi^{k2}_j (P)  W^{q}_PQ  conj(phi^{k3}_k) phi^{k4}_l (Q),

@@ -469,6 +469,16 @@ class OracleBackend:
         X = a2.dot(D2.numpy()).dot(a2.conj().T) * Wq.numpy()
         vk += torch.from_numpy(scale * a1.conj().T.dot(X).dot(a1))
 
+    def coulomb_rows_q(self, rows, mesh, coulG, out_re, out_im):
+        v = tools.ifft(tools.fft(rows.numpy(), mesh) * coulG.numpy(), mesh)
+        out_re.copy_(torch.from_numpy(np.ascontiguousarray(v.real)))
+        out_im.copy_(torch.from_numpy(np.ascontiguousarray(v.imag)))
+
+    def zhadamard_planes(self, Ar, Ai, Br, Bi):
+        z = (Ar.numpy() + 1j * Ai.numpy()) * (Br.numpy() + 1j * Bi.numpy())
+        Ar.copy_(torch.from_numpy(np.ascontiguousarray(z.real)))
+        Ai.copy_(torch.from_numpy(np.ascontiguousarray(z.imag)))
+
     def rho_k(self, ur, ui, ng, DTr, DTi, scale, rho):
         u = ur.numpy()[:, :ng] + 1j * ui.numpy()[:, :ng]
         T = (DTr.numpy() + 1j * DTi.numpy()).dot(u)

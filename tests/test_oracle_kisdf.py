@@ -223,3 +223,34 @@ def test_ao2mo_7d_matches_per_quartet_pair_transforms():
                 ref = (pij.T * coulG).dot(plk.conj()).reshape(nao, nao, nao, nao).transpose(0, 1, 3, 2)
                 worst = max(worst, abs(out[ki, kj, kk] - ref).max())
     assert worst < 1e-10
+
+
+def test_robust_k_at_kpoints_host_logic_and_error_reduction():
+    """robust_k at k-points through the host driver on the checker backend (no GPU): K = K1 + K1^H - K_isdf with
+    V^q = conv_q(Theta) equals the oracle's direct formula (oracle.kisdf.get_k_robust_kpts) on the same points, and it is much
+    closer to the reference's exact k-point exchange (fft_jk.py:250-292, oracle/fftdf.py) than the plain ISDF K at the same P."""
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he2_triclinic()
+    cell.mesh = np.array([9, 9, 9])
+    kpts = cell.make_kpts([2, 1, 1])
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(2)
+    c = rng.standard_normal((2, nao, nao)) + 1j * rng.standard_normal((2, nao, nao))
+    dms = np.einsum('kpi,kqi->kpq', c[:, :, :2], c[:, :, :2].conj())
+    coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    ao_k = [np.asarray(x, dtype=complex) for x in oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpts=kpts, rule='point')]
+    k_exact = fftdf.get_jk_kpts(ao_k, dms, cell.lattice_vectors(), cell.mesh, coords, kpts)[1]
+    plain = ISDF(cell, kpts=kpts, c_isdf=5, select='global', backend=OracleBackend())
+    vk_plain = plain.get_jk(dms, kpts=kpts, with_j=False)[1]
+    df = ISDF(cell, kpts=kpts, c_isdf=5, select='global', backend=OracleBackend())
+    df.robust_k = True
+    vk = df.get_jk(dms, kpts=kpts, with_j=False)[1]
+    assert np.array_equal(df.ip, plain.ip)
+    theta = kisdf.fit_theta(kisdf.periodic_stack(ao_k, coords, kpts), df.ip, df.reg_used)
+    ref = kisdf.get_k_robust_kpts(ao_k, coords, kpts, cell.lattice_vectors(), cell.mesh, df.ip, theta, dms)
+    assert abs(vk - ref).max() < 1e-8 * abs(ref).max()
+    assert abs(vk - vk.conj().transpose(0, 2, 1)).max() < 1e-10 * abs(vk).max()
+    assert abs(vk - k_exact).max() < 0.1 * abs(vk_plain - k_exact).max()
