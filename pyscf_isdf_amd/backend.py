@@ -42,7 +42,10 @@ class HipBackend:
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
     def to_device(self, a, dtype=None):
-        t = torch.as_tensor(np.ascontiguousarray(a))
+        a = np.ascontiguousarray(a)
+        if not a.flags.writeable:                  # torch refuses to wrap read-only memory silently
+            a = a.copy()
+        t = torch.as_tensor(a)
         if dtype is not None:
             t = t.to(dtype)
         return t.to(self.device)

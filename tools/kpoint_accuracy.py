@@ -37,13 +37,14 @@ df.reset()
 for fac in facs:
     df = ISDF(cell, kpts=kpts, c_isdf=c_isdf, select='refined')
     df.k_ip_factor = fac
+    df.robust_k = bool(os.environ.get('ROBUST'))          # Dunlap's correction at k-points (V^q recomputed per K)
     t0 = time.perf_counter()
     vk = df.get_jk(dms, kpts=kpts, with_j=False)[1]
     dt = time.perf_counter() - t0
     if rows is None:
         de = np.einsum('kij,kji', vk - vk_ex, dms).real / 4 / nk
-        print('c=%d k_ip_factor=%d P=%d  build+K %.1f s  dE_K %+.3e Eh per cell  max|dK| %.2e  (E_K exact %.8f)'
-              % (c_isdf, fac, len(df.ip), dt, de, abs(vk - vk_ex).max(), np.einsum('kij,kji', vk_ex, dms).real / 4 / nk), flush=True)
+        print('%sc=%d k_ip_factor=%d P=%d  build+K %.1f s  dE_K %+.3e Eh per cell  max|dK| %.2e  (E_K exact %.8f)'
+              % ('robust K, ' if df.robust_k else '', c_isdf, fac, len(df.ip), dt, de, abs(vk - vk_ex).max(), np.einsum('kij,kji', vk_ex, dms).real / 4 / nk), flush=True)
     else:
         sub = vk[:, rows[0]:rows[0] + rows[1]]
         print('c=%d k_ip_factor=%d P=%d  build+K %.1f s  max|dK| on the sampled rows %.2e (max|K| there %.3f)'
