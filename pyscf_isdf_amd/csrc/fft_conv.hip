@@ -925,13 +925,22 @@ int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, cons
     HIP_TRY(h, hipFuncSetAttribute((const void*)plane_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const size_t ldsx = sizeof(double2) * ((size_t)n0 * FX + n0);
     const int ntx = (int)cdiv((int64_t)n1 * n2h, FX);
-    const dim3 gp((unsigned)((int64_t)nb * n0)), gx((unsigned)((int64_t)nb * ntx));
     hipStream_t st = h->stream;
-    plane_fwd_kernel<<<gp, dim3(TPBP), plane_lds, st>>>(d_in, zbuf, ax[2], ax[1], Lz, bufsz);
-    with_lines(FX, [&](auto z) {
-      strided_fft_fast_kernel<2, decltype(z)::value><<<gx, dim3(TPB), ldsx, st>>>(zbuf, gc, (int64_t)n1 * n2h, n1 * n2h, ax[0], ntx, cg);
-    });
-    plane_inv_kernel<<<gp, dim3(TPBP), plane_lds, st>>>(zbuf, d_out, ax[2], ax[1], Lz, bufsz);
+    // Sub-batches sized so that the half spectra of a sub-batch stay in the 256 MB Infinity Cache between the three passes
+    // (option "conv_sub_rows": rows per sub-batch; 0 = the whole batch at once, the round-2 behaviour): the middle pass then
+    // reads and writes cache-resident lines and the inverse plane pass reads them back from there - HBM sees the real rows in
+    // and out only.  Every sub-batch still launches >= 256 workgroups (rows x n0 planes).
+    const int sub = h->conv_sub_rows > 0 ? std::min(nb, h->conv_sub_rows) : nb;
+    for (int r0 = 0; r0 < nb; r0 += sub) {
+      const int nr = std::min(sub, nb - r0);
+      const dim3 gp((unsigned)((int64_t)nr * n0)), gx((unsigned)((int64_t)nr * ntx));
+      double2* zb = zbuf + (int64_t)r0 * gc;
+      plane_fwd_kernel<<<gp, dim3(TPBP), plane_lds, st>>>(d_in + (int64_t)r0 * G, zb, ax[2], ax[1], Lz, bufsz);
+      with_lines(FX, [&](auto z) {
+        strided_fft_fast_kernel<2, decltype(z)::value><<<gx, dim3(TPB), ldsx, st>>>(zb, gc, (int64_t)n1 * n2h, n1 * n2h, ax[0], ntx, cg);
+      });
+      plane_inv_kernel<<<gp, dim3(TPBP), plane_lds, st>>>(zb, d_out + (int64_t)r0 * G, ax[2], ax[1], Lz, bufsz);
+    }
     KERNEL_CHECK(h);
     return ISDF_OK;
   }
