@@ -413,6 +413,11 @@ int isdf_get_k_exact_kpt(isdf_handle h, const double* d_u1r, const double* d_u1i
  *   isdf_zhadamard_planes: (Ar + i Ai) .*= (Br + i Bi) on `rows` x `cols` planes */
 int isdf_coulomb_rows_q(isdf_handle h, const double* d_rows, int nrows, int64_t ld, const int32_t mesh[3],
                         const double* d_coulG, double* d_re, double* d_im);
+/* (d_re + i d_im)[r] (mesh[a] x mesh[b] entries, the two axes other than `axis`, C order) = the 3-D DFT of the real row r on the
+ * Nyquist plane of `axis` (mesh[axis] even): what the even-mesh correction of the +-q pairing needs (W^{-q} = conj(W^q) holds
+ * index by index only off the Nyquist planes: pbc.py:272-302 labels index n/2 as -n/2 for both signs of q). */
+int isdf_nyquist_spectra(isdf_handle h, const double* d_rows, int nrows, int64_t ld, const int32_t mesh[3], int axis,
+                         double* d_re, double* d_im);
 int isdf_zhadamard_planes(isdf_handle h, double* d_Ar, double* d_Ai, int64_t lda, const double* d_Br, const double* d_Bi,
                           int64_t ldb, int rows, int64_t cols);
 int isdf_rho_k(isdf_handle h, const double* d_ur, const double* d_ui, int nao, int64_t ng, int64_t ld,

@@ -618,6 +618,14 @@ class HipBackend:
         self.handle.call('isdf_coulomb_rows_q', self._p(rows), rows.shape[0], rows.stride(0), _np_ptr(mesh), self._p(coulG),
                          self._p(out_re), self._p(out_im))
 
+    def nyquist_spectra(self, rows, mesh, axis, out_re, out_im):
+        """out_re + i out_im (n, na * nb) <- the 3-D DFT of the real rows on the Nyquist plane of ``axis`` (mesh[axis] even)."""
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        assert rows.stride(1) == 1 and out_re.is_contiguous() and out_im.is_contiguous()
+        self.handle.call('isdf_nyquist_spectra', self._p(rows), rows.shape[0], rows.stride(0), _np_ptr(mesh), int(axis),
+                         self._p(out_re), self._p(out_im))
+
     def zhadamard_planes(self, Ar, Ai, Br, Bi):
         """(Ar + i Ai) .*= (Br + i Bi)."""
         self._stream()

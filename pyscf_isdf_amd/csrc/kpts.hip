@@ -140,6 +140,24 @@ __global__ void zhadamard_planes_kernel(double* __restrict__ Ar, double* __restr
   Ai[r * lda + c] = ar * bi + ai * br;
 }
 
+// A[r][a][b] = sum_t (-1)^t rows[r][...t...] along `axis` (the Nyquist component of that axis' DFT), written as complex (imag 0)
+__global__ void nyquist_reduce_kernel(const double* __restrict__ rows, int64_t ld, int n0, int n1, int n2, int axis,
+                                      double2* __restrict__ out) {
+  const int na = axis == 0 ? n1 : n0, nb = axis == 2 ? n1 : n2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)na * nb) return;
+  const int ia = (int)(idx / nb), ib = (int)(idx % nb);
+  const double* r = rows + (int64_t)blockIdx.y * ld;
+  const int nt = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
+  int64_t base, stride;
+  if (axis == 0) { base = (int64_t)ia * n2 + ib; stride = (int64_t)n1 * n2; }
+  else if (axis == 1) { base = (int64_t)ia * n1 * n2 + ib; stride = n2; }
+  else { base = ((int64_t)ia * n1 + ib) * n2; stride = 1; }
+  double s = 0.0;
+  for (int t = 0; t < nt; t += 2) s += r[base + (int64_t)t * stride] - r[base + (int64_t)(t + 1) * stride];
+  out[(int64_t)blockIdx.y * na * nb + idx] = make_double2(s, 0.0);
+}
+
 inline rocblas_operation zop(char c) {
   return c == 'N' ? rocblas_operation_none : (c == 'T' ? rocblas_operation_transpose : rocblas_operation_conjugate_transpose);
 }
@@ -254,6 +272,42 @@ extern "C" int isdf_coulomb_rows_q(isdf_handle h, const double* d_rows, int nrow
   hipLaunchKernelGGL(mul_full_kernel, dim3(nblocks), dim3(256), 0, h->stream, Z, d_coulG, G, total, 1.0 / (double)G);
   FFT_TRY(h, hipfftExecZ2Z(plan, (hipfftDoubleComplex*)Z, (hipfftDoubleComplex*)Z, HIPFFT_BACKWARD));
   hipLaunchKernelGGL(unpack_complex_kernel, dim3(nblocks), dim3(256), 0, h->stream, Z, d_re, d_im, total);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
+extern "C" int isdf_nyquist_spectra(isdf_handle h, const double* d_rows, int nrows, int64_t ld, const int32_t mesh[3], int axis,
+                                    double* d_re, double* d_im) {
+  // (d_re + i d_im)[r][ka][kb] = the 3-D DFT of row r on the NYQUIST plane of `axis` (index mesh[axis]/2, mesh[axis] even): the
+  // alternating-sign sum along that axis followed by a 2-D transform over the other two (their natural order, C layout).  Used for
+  // the even-mesh correction of the +-q pairing of the k-point build.
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_rows && mesh && d_re && d_im && nrows > 0 && nrows <= 65535 && axis >= 0 && axis <= 2 && mesh[axis] % 2 == 0);
+  const int n0 = mesh[0], n1 = mesh[1], n2 = mesh[2];
+  ARG_CHECK(h, ld >= (int64_t)n0 * n1 * n2);
+  const int na = axis == 0 ? n1 : n0, nb = axis == 2 ? n1 : n2;
+  const int64_t np = (int64_t)na * nb;
+  double2* Z = (double2*)isdf_ws(h, "nyq_Z", sizeof(double2) * (size_t)nrows * np);
+  if (!Z) return ISDF_ERR_HIP;
+  std::vector<int> key = {na, nb, nrows, -2, 0};
+  auto it = h->plans.find(key);
+  hipfftHandle plan;
+  if (it != h->plans.end()) plan = it->second.fwd;
+  else {
+    FftPlan p;
+    int dims[2] = {na, nb};
+    FFT_TRY(h, hipfftPlanMany(&p.fwd, 2, dims, nullptr, 1, (int)np, nullptr, 1, (int)np, HIPFFT_Z2Z, nrows));
+    FFT_TRY(h, hipfftSetStream(p.fwd, h->stream));
+    p.bwd = 0;
+    h->plans.emplace(key, p);
+    plan = p.fwd;
+  }
+  hipLaunchKernelGGL(nyquist_reduce_kernel, dim3((unsigned)cdiv(np, 256), (unsigned)nrows), dim3(256), 0, h->stream, d_rows, ld, n0, n1,
+                     n2, axis, Z);
+  FFT_TRY(h, hipfftExecZ2Z(plan, (hipfftDoubleComplex*)Z, (hipfftDoubleComplex*)Z, HIPFFT_FORWARD));
+  const int64_t total = (int64_t)nrows * np;
+  hipLaunchKernelGGL(unpack_complex_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), (int64_t)h->num_cu * 16)), dim3(256), 0,
+                     h->stream, Z, d_re, d_im, total);
   KERNEL_CHECK(h);
   return ISDF_OK;
 }

@@ -61,6 +61,10 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         self.reg_rel = 1e-12             # relative diagonal shift of A_PP in the global fit
         self.reg_used = 0.0
         self.k_ip_factor = None           # k-points: points = c_isdf * nao * k_ip_factor (default min(nk, 2))
+        self.kpt_pair_q = 'auto'          # k-points: True = build one W^q per +-q pair and use W^{-q} = conj(W^q) (half the products);
+                                          # exact on odd meshes only - on an even mesh the Nyquist index has no partner and the
+                                          # wrap-around rule zeroes it for one sign of q (MgO 2x2x2 / 64^3: 7e-6 in K); False =
+                                          # every q from its own kernel table; 'auto' = pair on all-odd meshes only
         self.kpts_band = None             # band k-points of the last k-point build (set by get_jk(kpts_band=...))
         self.force_sharded = False       # run the multi-GPU code path even on one rank (tests)
         self.fit_route = 'auto'          # 'cholesky': forward solve over the grid (S3b), always safe;

@@ -167,6 +167,16 @@ class KPointMixin:
             for jq in range(nq):
                 if abs(self._qs[iq] + self._qs[jq]).max() < 1e-9:
                     partner[iq] = jq
+        pair_q = self.kpt_pair_q
+        if pair_q not in ('auto', 'uncorrected', True, False):
+            raise ValueError("kpt_pair_q must be 'auto', 'uncorrected', True or False")
+        if not pair_q:
+            # every W^q from its OWN kernel table (twice the products)
+            partner[:] = -1
+        # the pairing W^{-q} = conj(W^q) assumes coulG_{-q}(G) = coulG_q(-G) index by index, which the Nyquist index of an even mesh
+        # breaks (index n/2 is labelled -n/2 for both signs of q, and the wrap-around rule of pbc.py:272-302 zeroes it for one sign
+        # only): 'auto' / True add the missing Nyquist-plane terms (_nyquist_pair_correction), 'uncorrected' is round 2's behaviour
+        self._pair_correct = pair_q in ('auto', True) and any(int(n) % 2 == 0 for n in mesh)
         primary = [iq for iq in range(nq) if partner[iq] < 0 or partner[iq] >= iq]
         self._q_owner = np.zeros(nq, dtype=int)
         for n, iq in enumerate(primary):
@@ -191,7 +201,7 @@ class KPointMixin:
                 self.reg_used = be.fit_prepare_cplx(X, nh, ip_dev, self.reg_rel, aoP_X, chol)
                 be.fit_apply_cplx(chol, aoP_X, nh, X, G, Y, forward_only=not self._want_theta)
             t0 = self._tick('S3_fit', t0)
-            self._kfit_state = dict(route=route, Y=Y, primary=primary, r_ip=r_ip, batch=batch, nao=nao, nh=nh, aoP_X=aoP_X,
+            self._kfit_state = dict(route=route, Y=Y, primary=primary, partner=partner, r_ip=r_ip, batch=batch, nao=nao, nh=nh, aoP_X=aoP_X,
                                     chol=None if route == 'blockjacobi' else chol,
                                     bj=(Afac, Dblk, ip_off) if route == 'blockjacobi' else None)
             self._Wq, check, t0 = self._build_Wq(None, t0, probe=(route == 'blockjacobi' and self.fit_route == 'auto'))
@@ -237,6 +247,15 @@ class KPointMixin:
             coulG = be.coulG_q(mesh, cell.lattice_vectors(), q, omega=omega)
             be.coulomb_Wq(Y, mesh, coulG, w, 0, P, st['batch'], Wre, Wim, upper_only=True)
             be.symmetrize_hermitian(Wre, Wim)
+            jq = int(st['partner'][iq])
+            twin = None
+            if self._pair_correct and jq >= 0 and jq != iq:
+                # M^{-q} = conj(M^q) + the Nyquist-plane terms the pairing misses on an even mesh; finished like M^q below
+                twin = (be.empty((P, P)), be.empty((P, P)))
+                twin[0].copy_(Wre)
+                twin[1].copy_(Wim)
+                twin[1].neg_()
+                self._nyquist_pair_correction(q, omega, coulG, twin[0], twin[1])
             if st['route'] == 'blockjacobi':
                 Afac, Dblk, ip_off = st['bj']
                 self._bj_finish(Afac, Dblk, ip_off, Wre)
@@ -255,7 +274,74 @@ class KPointMixin:
             Wc = be.empty((P, P), dtype=torch.complex128)
             be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * r_ip.dot(q))), Wc)
             out[iq] = Wc
+            if twin is not None:
+                if st['route'] == 'blockjacobi':
+                    self._bj_finish(Afac, Dblk, ip_off, twin[0])
+                    self._bj_finish(Afac, Dblk, ip_off, twin[1], antisymmetric=True)
+                elif not self._want_theta:
+                    be.W_from_factor(st['chol'], 0, twin[0])
+                    be.W_from_factor(st['chol'], 0, twin[1])
+                Wt = be.empty((P, P), dtype=torch.complex128)
+                be.finish_Wq(twin[0], twin[1], be.to_device(np.exp(1j * r_ip.dot(q))), Wt)      # phases of -q
+                out[jq] = Wt
+                del twin
         return out, check, t0
+
+    def _nyquist_planes(self):
+        """For every even mesh axis: the DFT of the fit rows on that axis' Nyquist plane (P x plane entries, real and imaginary
+        planes), the flat grid index of each plane entry and of its index-negated image, and the mask of the entries an earlier
+        axis' plane has not counted already.  Made once per build (the rows do not depend on q)."""
+        st = self._kfit_state
+        if st.get('nyq') is not None:
+            return st['nyq']
+        be = self.backend
+        Y = st['Y']
+        P, G = Y.shape
+        n = [int(x) for x in self.mesh]
+        ii = [np.arange(m) for m in n]
+        out = []
+        for ax in range(3):
+            if n[ax] % 2:
+                continue
+            oth = [i for i in range(3) if i != ax]
+            A, B = np.meshgrid(ii[oth[0]], ii[oth[1]], indexing='ij')
+            idx3 = [None, None, None]
+            idx3[ax] = np.full(A.shape, n[ax] // 2)
+            idx3[oth[0]], idx3[oth[1]] = A, B
+            flat = ((idx3[0] * n[1] + idx3[1]) * n[2] + idx3[2]).ravel()
+            neg = ((((-idx3[0]) % n[0]) * n[1] + ((-idx3[1]) % n[1])) * n[2] + ((-idx3[2]) % n[2])).ravel()
+            fresh = np.ones(flat.shape, dtype=bool)
+            for prev in range(ax):
+                if n[prev] % 2 == 0:
+                    fresh &= (idx3[prev].ravel() != n[prev] // 2)
+            npl = len(flat)
+            Tr, Ti = be.empty((P, npl)), be.empty((P, npl))
+            nb = max(1, min(P, 65535, int((1 << 30) // (16 * npl))))
+            for r0 in range(0, P, nb):
+                r1 = min(P, r0 + nb)
+                be.nyquist_spectra(Y[r0:r1], np.asarray(n, dtype=np.int32), ax, Tr[r0:r1], Ti[r0:r1])
+            out.append(dict(Tr=Tr, Ti=Ti, flat=be.to_device(flat.astype(np.int64)), neg=be.to_device(neg.astype(np.int64)),
+                            fresh=be.to_device(fresh.astype(np.float64))))
+        st['nyq'] = out
+        return out
+
+    def _nyquist_pair_correction(self, q, omega, tab_q, Mre, Mim):
+        """(Mre + i Mim) += M^{-q} - conj(M^q) = w/G sum_{G on the Nyquist planes} [coulG_{-q}(G) - coulG_q(-G)] Y^_P(G) conj(Y^_Q(G)):
+        what W^{-q} = conj(W^q) leaves out on an even mesh.  3/n of the grid: a few per cent of a full product."""
+        cell, be = self.cell, self.backend
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        w = cell.vol / G
+        tab_m = be.coulG_q(mesh, cell.lattice_vectors(), -np.asarray(q), omega=omega)
+        for pl in self._nyquist_planes():
+            d = ((tab_m[pl['flat']] - tab_q[pl['neg']]) * pl['fresh']).contiguous()
+            Tr, Ti = pl['Tr'], pl['Ti']
+            # sum_G d T_P conj(T_Q): Re = Tr d Tr^T + Ti d Ti^T, Im = Ti d Tr^T - Tr d Ti^T     (the 1/G of the Parseval sum: alpha)
+            be.gemm_nt(Tr, Tr, Mre, alpha=w / G, beta=1.0, kscale=d)
+            be.gemm_nt(Ti, Ti, Mre, alpha=w / G, beta=1.0, kscale=d)
+            be.gemm_nt(Ti, Tr, Mim, alpha=w / G, beta=1.0, kscale=d)
+            be.gemm_nt(Tr, Ti, Mim, alpha=-w / G, beta=1.0, kscale=d)
+        del tab_m
 
     def _get_jk_kpts(self, dm, hermi, kpts, kpts_band, with_j, with_k, exxdiv, omega=None):
         """k-point J and K (pyscf/pbc/df/fft_jk.py:33-109,177-302 semantics).  dm (nk, N, N) or (nset, nk, N, N); with

@@ -474,6 +474,13 @@ class OracleBackend:
         out_re.copy_(torch.from_numpy(np.ascontiguousarray(v.real)))
         out_im.copy_(torch.from_numpy(np.ascontiguousarray(v.imag)))
 
+    def nyquist_spectra(self, rows, mesh, axis, out_re, out_im):
+        n = [int(x) for x in mesh]
+        f = np.fft.fftn(rows.numpy()[:, :int(np.prod(n))].reshape(-1, *n), axes=(1, 2, 3))
+        pl = np.take(f, n[axis] // 2, axis=1 + axis).reshape(len(f), -1)
+        out_re.copy_(torch.from_numpy(np.ascontiguousarray(pl.real)))
+        out_im.copy_(torch.from_numpy(np.ascontiguousarray(pl.imag)))
+
     def zhadamard_planes(self, Ar, Ai, Br, Bi):
         z = (Ar.numpy() + 1j * Ai.numpy()) * (Br.numpy() + 1j * Bi.numpy())
         Ar.copy_(torch.from_numpy(np.ascontiguousarray(z.real)))

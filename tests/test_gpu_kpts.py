@@ -523,3 +523,26 @@ def test_robust_k_at_kpoints_on_device():
     theta_b = okisdf.fit_theta(stack, df.ip, df.reg_used)
     refb = okisdf.get_k_robust_kpts(ao_k, coords, kpts, cell.lattice_vectors(), cell.mesh, df.ip, theta_b, dms, ao_band=ao_b, kpts_band=band)
     assert abs(vkb - refb).max() < 1e-8 * abs(refb).max()
+
+
+def test_even_mesh_pair_correction_on_device():
+    """The +-q pairing with its Nyquist-plane correction (isdf_nyquist_spectra + scaled MFMA products) on an even, anisotropic mesh:
+    K equals the build that makes every W^q from its own kernel table to 1e-10, on both fit routes; the uncorrected pairing of
+    round 2 differs at the level of the Nyquist content."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he2_triclinic()
+    cell.mesh = np.array([12, 10, 9])
+    kpts = cell.make_kpts([2, 2, 1])
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(4)
+    c = rng.standard_normal((4, nao, nao)) + 1j * rng.standard_normal((4, nao, nao))
+    dms = np.einsum('kpi,kqi->kpq', c[:, :, :2], c[:, :, :2].conj())
+    for select, route in (('global', 'auto'), ('local', 'blockjacobi')):
+        res = {}
+        for mode in (False, 'auto', 'uncorrected'):
+            df = ISDF(cell, kpts=kpts, c_isdf=4, select=select)
+            df.kpt_pair_q, df.fit_route, df.bj_auto_kpts = mode, route, route == 'blockjacobi'
+            res[mode] = df.get_jk(dms, kpts=kpts, with_j=False)[1]
+        scale = abs(res[False]).max()
+        assert abs(res['auto'] - res[False]).max() < 1e-10 * scale, (select, abs(res['auto'] - res[False]).max() / scale)
+        assert abs(res['uncorrected'] - res[False]).max() > 1e-8 * scale

@@ -254,3 +254,29 @@ def test_robust_k_at_kpoints_host_logic_and_error_reduction():
     assert abs(vk - ref).max() < 1e-8 * abs(ref).max()
     assert abs(vk - vk.conj().transpose(0, 2, 1)).max() < 1e-10 * abs(vk).max()
     assert abs(vk - k_exact).max() < 0.1 * abs(vk_plain - k_exact).max()
+
+
+def test_even_mesh_pair_correction_host_logic():
+    """W^{-q} = conj(W^q) holds index by index only off the Nyquist planes of an even mesh (the reference's table labels index n/2
+    as -n/2 for both signs of q and zeroes it on the wrap-around edge for one of them, pbc.py:272-302).  With the Nyquist-plane terms
+    added ('auto') the paired build reproduces the build that makes every W^q from its own table (1e-10); the uncorrected pairing
+    of round 2 does not."""
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_he2_triclinic()
+    cell.mesh = np.array([8, 10, 9])
+    kpts = cell.make_kpts([2, 2, 1])
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(4)
+    c = rng.standard_normal((4, nao, nao)) + 1j * rng.standard_normal((4, nao, nao))
+    dms = np.einsum('kpi,kqi->kpq', c[:, :, :2], c[:, :, :2].conj())
+    res = {}
+    for mode in (False, 'auto', 'uncorrected'):
+        df = ISDF(cell, kpts=kpts, c_isdf=4, select='global', backend=OracleBackend())
+        df.kpt_pair_q = mode
+        res[mode] = df.get_jk(dms, kpts=kpts, with_j=False)[1]
+        if mode == 'auto':
+            assert df._pair_correct and len(df._Wq) == len(df._qs)          # every q stored: primaries + corrected twins
+    scale = abs(res[False]).max()
+    assert abs(res['auto'] - res[False]).max() < 1e-10 * scale
+    assert abs(res['uncorrected'] - res[False]).max() > 1e-7 * scale

@@ -15,6 +15,10 @@ c_isdf = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 facs = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [2, 4]
 nrows = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 cell = workloads.make_cell(name)
+if os.environ.get('MESH'):                     # e.g. MESH=75: an odd mesh (no Nyquist planes)
+    from pyscf_isdf_amd import gto as _gto
+    n_ = int(os.environ['MESH'])
+    cell = workloads.mgo_supercell(2 if '222' in name else 3, 'gth-dzvp', (n_, n_, n_))
 kpts = workloads.make_kpts(name, cell)
 nk, nao = len(kpts), cell.nao_nr()
 rng = np.random.default_rng(20240203)
@@ -37,6 +41,8 @@ df.reset()
 for fac in facs:
     df = ISDF(cell, kpts=kpts, c_isdf=c_isdf, select='refined')
     df.k_ip_factor = fac
+    if os.environ.get('PAIR'):                      # PAIR=1: force the +-q pairing (round-2 behaviour); default 'auto'
+        df.kpt_pair_q = True
     df.robust_k = bool(os.environ.get('ROBUST'))          # Dunlap's correction at k-points (V^q recomputed per K)
     t0 = time.perf_counter()
     vk = df.get_jk(dms, kpts=kpts, with_j=False)[1]
