@@ -531,7 +531,7 @@ def test_even_mesh_pair_correction_on_device():
     round 2 differs at the level of the Nyquist content."""
     from pyscf_isdf_amd.isdf import ISDF
     cell = cells.cell_he2_triclinic()
-    cell.mesh = np.array([12, 10, 9])
+    cell.mesh = np.array([8, 10, 9])
     kpts = cell.make_kpts([2, 2, 1])
     nao = cell.nao_nr()
     rng = np.random.default_rng(4)
@@ -545,4 +545,4 @@ def test_even_mesh_pair_correction_on_device():
             res[mode] = df.get_jk(dms, kpts=kpts, with_j=False)[1]
         scale = abs(res[False]).max()
         assert abs(res['auto'] - res[False]).max() < 1e-10 * scale, (select, abs(res['auto'] - res[False]).max() / scale)
-        assert abs(res['uncorrected'] - res[False]).max() > 1e-8 * scale
+        assert abs(res['uncorrected'] - res[False]).max() > 1e-7 * scale
