@@ -228,6 +228,18 @@ class KPointMixin:
         self._nk_stack = nk
         return self
 
+    def _keep_Wq(self, Wc):
+        """A finished W^q stays on the device while there is room for the rest of the build and for get_jk's work areas (about
+        ten P x P matrices); beyond that it moves to pinned host memory and is uploaded when the K loop reaches its q (3.4 GB
+        per matrix at configs[3], where the 27 matrices of the 2x2x2 mesh, Theta and the stacked periodic parts exceed 288 GB)."""
+        be = self.backend
+        P = Wc.shape[0]
+        if not Wc.is_cuda or be.free_bytes() > 10 * 16 * P * P + (8 << 30):
+            return Wc
+        host = torch.empty(Wc.shape, dtype=Wc.dtype, pin_memory=True)
+        host.copy_(Wc)
+        return host
+
     def _build_Wq(self, omega, t0, probe=False):
         """S4 + S5 for this rank's share of the q list from the fit held in self._kfit_state: {iq: W^q (P, P) complex}.
         omega: range separation of the kernel (pyscf/pbc/tools/pbc.py:408-418) - the fit does not depend on it."""
@@ -273,7 +285,8 @@ class KPointMixin:
                 be.W_from_factor(st['chol'], 0, Wim)
             Wc = be.empty((P, P), dtype=torch.complex128)
             be.finish_Wq(Wre, Wim, be.to_device(np.exp(-1j * r_ip.dot(q))), Wc)
-            out[iq] = Wc
+            out[iq] = self._keep_Wq(Wc)
+            del Wc
             if twin is not None:
                 if st['route'] == 'blockjacobi':
                     self._bj_finish(Afac, Dblk, ip_off, twin[0])
@@ -283,8 +296,8 @@ class KPointMixin:
                     be.W_from_factor(st['chol'], 0, twin[1])
                 Wt = be.empty((P, P), dtype=torch.complex128)
                 be.finish_Wq(twin[0], twin[1], be.to_device(np.exp(1j * r_ip.dot(q))), Wt)      # phases of -q
-                out[jq] = Wt
-                del twin
+                out[jq] = self._keep_Wq(Wt)
+                del twin, Wt
         return out, check, t0
 
     def _nyquist_planes(self):
@@ -453,18 +466,26 @@ class KPointMixin:
             vj = vj.reshape(out_shape)
         if with_k:
             d_vk = be.zeros((nset, nband, nao, nao), dtype=torch.complex128)
+            # the (k1, k2) pairs grouped by their difference vector: a W^q that lives in host memory is uploaded once per group
+            groups = {}
+            for i1, k1 in enumerate(bidx):
+                for k2 in range(nk):
+                    iq = int(self._qindex[i1, k2])
+                    if self._q_owner[iq] == comm.rank:
+                        groups.setdefault(iq, []).append((i1, k1, k2))
             for s in range(nset):
                 d_dm = [be.to_device(np.ascontiguousarray(dms[s, k])) for k in range(nk)]
-                for i1, k1 in enumerate(bidx):
-                    for k2 in range(nk):
-                        iq = self._qindex[i1, k2]
-                        if self._q_owner[iq] != comm.rank:
-                            continue
-                        if iq in Wq_set:
-                            Wq = Wq_set[iq]
-                        else:                      # stored as its time-reversal partner: W^{-q} = conj(W^q)
-                            Wq = torch.conj_physical(Wq_set[self._q_partner[iq]])
+                for iq, pairs in groups.items():
+                    if iq in Wq_set:
+                        Wq = Wq_set[iq]
+                        if not Wq.is_cuda:
+                            Wq = Wq.to(be.device, non_blocking=True)
+                    else:                          # stored as its time-reversal partner: W^{-q} = conj(W^q) ('uncorrected' / odd meshes)
+                        Wp = Wq_set[self._q_partner[iq]]
+                        Wq = torch.conj_physical(Wp if Wp.is_cuda else Wp.to(be.device, non_blocking=True))
+                    for i1, k1, k2 in pairs:
                         be.get_k_pair(self._aoP_k[k1], self._aoP_k[k2], d_dm[k2], Wq, 1.0 / nk, d_vk[s, i1])
+                    del Wq
             if comm.size > 1 or getattr(comm, 'always', False):
                 flat = torch.view_as_real(d_vk)
                 comm.all_reduce_sum(flat)
