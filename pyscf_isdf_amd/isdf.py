@@ -33,7 +33,7 @@ from .eri_surface import EriSurfaceMixin
 class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin):
     _keys = {'cell', 'kpts', 'grids', 'mesh', 'blockdim', 'exxdiv', 'c_isdf', 'select', 'tie_rtol'}
 
-    def __init__(self, cell, kpts=np.zeros((1, 3)), c_isdf=10, select='refined', backend=None, comm=None):
+    def __init__(self, cell, kpts=np.zeros((1, 3)), c_isdf=12, select='refined', backend=None, comm=None):
         self.cell = cell
         self.stdout = getattr(cell, 'stdout', None) or sys.stdout
         self.verbose = getattr(cell, 'verbose', 0)
