@@ -75,6 +75,8 @@ class KPointMixin:
         from . import pbc_tools
         cell, be, comm = self.cell, self.backend, self.comm
         self.timings = {}
+        if self.pair_space == 'occ':
+            warnings.warn("ISDF: pair_space='occ' is a Gamma-point option; the k-point build interpolates the Bloch AO pairs")
         t0 = time.perf_counter()
         kpts_scf = np.asarray(self.kpts, dtype=float).reshape(-1, 3)
         # band k-points (kpts_band of get_jk) join the stack: the fit must also represent conj(u^{kb}) u^{k}

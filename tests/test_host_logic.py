@@ -131,3 +131,39 @@ def test_switching_kpoint_sets_does_not_reuse_range_separated_Wq():
     vk = df.get_jk(dB, kpts=kB, omega=0.5, with_j=False)[1]
     fresh = ISDF(cell, kpts=kB, c_isdf=6, select='global', backend=OracleBackend())
     assert abs(vk - fresh.get_jk(dB, kpts=kB, omega=0.5, with_j=False)[1]).max() < 1e-12
+
+
+def test_occupied_orbitals_of_a_density_matrix():
+    """ISDF._occupied_orbitals: the occupied space get_jk fits when pair_space='occ' - from the mo_coeff / mo_occ tag exactly as
+    the reference's K takes it (pyscf/pbc/df/fft_jk.py:206-210: mo_coeff[:, mo_occ > 0] * sqrt(mo_occ)), for one matrix and for a
+    stack (UHF-like tags); from the eigenvectors of an untagged symmetric positive semidefinite matrix; None (-> AO pairs) for
+    anything without such a form."""
+    cell = cells.cell_he_c()
+    df = ISDF(cell)
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(0)
+    c = np.linalg.qr(rng.standard_normal((nao, nao)))[0]
+    occ = np.zeros(nao); occ[:2] = 2
+
+    class Tagged(np.ndarray):
+        pass
+    dm = (c * occ).dot(c.T)
+    t = dm.view(Tagged)
+    t.mo_coeff, t.mo_occ = c, occ
+    o = df._occupied_orbitals(t)
+    assert o.shape == (nao, 2) and abs(o.dot(o.T) - dm).max() < 1e-14
+    assert abs(o - c[:, :2] * np.sqrt(2.0)).max() < 1e-14
+    # a stack of two matrices with their own orbitals: side by side
+    occ_b = np.zeros(nao); occ_b[1:2] = 1
+    pair = np.stack([dm, (c * occ_b).dot(c.T)]).view(Tagged)
+    pair.mo_coeff, pair.mo_occ = np.stack([c, c]), np.stack([occ, occ_b])
+    o2 = df._occupied_orbitals(pair)
+    assert o2.shape == (nao, 3) and abs(o2.dot(o2.T) - (dm + (c * occ_b).dot(c.T))).max() < 1e-14
+    # untagged: eigenvectors; the projector is what matters
+    o3 = df._occupied_orbitals(dm)
+    assert o3.shape == (nao, 2) and abs(o3.dot(o3.T) - dm).max() < 1e-12
+    # no occupied-orbital form: indefinite, non-symmetric, complex, or more than N/2 orbitals
+    assert df._occupied_orbitals(dm - 0.1 * np.eye(nao)) is None
+    assert df._occupied_orbitals(dm + np.triu(np.ones((nao, nao)), 1) * 1e-3) is None
+    assert df._occupied_orbitals(dm + 1e-3j * (c.dot(c.T) > 0)) is None
+    assert df._occupied_orbitals(np.eye(nao)) is None
