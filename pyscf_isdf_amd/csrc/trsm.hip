@@ -321,7 +321,9 @@ static int block_apply_reg_launch(isdf_handle h, const double* Dinv, int64_t ldd
   static_assert(NTHREADS % TN == 0 && (16 * NT * TN) % NTHREADS == 0, "tile elements must divide evenly over the threads");
   const size_t lds = (size_t)16 * NT * (TN + 2) * sizeof(double);
   const int64_t ntile = (n + TN - 1) / TN;
-  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntile, ((int64_t)h->num_cu * 4 + nblk - 1) / nblk));
+  // workgroups per block: `block_apply_waves` (default 16) times the CU count in all - 2.24 TB/s with 4, 2.6-2.7 with 16-32 at
+  // 1.7 M columns (tools/bench_block_apply.py): short serial chains per workgroup matter more than re-reading the block inverse
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntile, ((int64_t)h->num_cu * h->block_apply_waves + nblk - 1) / nblk));
   if (sq) {
     if (lds > 64 * 1024)
       HIP_TRY(h, hipFuncSetAttribute((const void*)&block_apply_reg_kernel<NT, NCT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

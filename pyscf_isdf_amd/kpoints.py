@@ -352,10 +352,15 @@ class KPointMixin:
             d = ((tab_m[pl['flat']] - tab_q[pl['neg']]) * pl['fresh']).contiguous()
             Tr, Ti = pl['Tr'], pl['Ti']
             # sum_G d T_P conj(T_Q): Re = Tr d Tr^T + Ti d Ti^T, Im = Ti d Tr^T - Tr d Ti^T     (the 1/G of the Parseval sum: alpha)
-            be.gemm_nt(Tr, Tr, Mre, alpha=w / G, beta=1.0, kscale=d)
-            be.gemm_nt(Ti, Ti, Mre, alpha=w / G, beta=1.0, kscale=d)
-            be.gemm_nt(Ti, Tr, Mim, alpha=w / G, beta=1.0, kscale=d)
-            be.gemm_nt(Tr, Ti, Mim, alpha=-w / G, beta=1.0, kscale=d)
+            # the correction is Hermitian like M itself: block-upper part only (512-row blocks), mirrored once at the end
+            P = Tr.shape[0]
+            for r0 in range(0, P, 512):
+                r1 = min(P, r0 + 512)
+                be.gemm_nt(Tr[r0:r1], Tr[r0:], Mre[r0:r1, r0:], alpha=w / G, beta=1.0, kscale=d)
+                be.gemm_nt(Ti[r0:r1], Ti[r0:], Mre[r0:r1, r0:], alpha=w / G, beta=1.0, kscale=d)
+                be.gemm_nt(Ti[r0:r1], Tr[r0:], Mim[r0:r1, r0:], alpha=w / G, beta=1.0, kscale=d)
+                be.gemm_nt(Tr[r0:r1], Ti[r0:], Mim[r0:r1, r0:], alpha=-w / G, beta=1.0, kscale=d)
+        be.symmetrize_hermitian(Mre, Mim)
         del tab_m
 
     def _get_jk_kpts(self, dm, hermi, kpts, kpts_band, with_j, with_k, exxdiv, omega=None):

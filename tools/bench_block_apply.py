@@ -20,18 +20,25 @@ dD = be.to_device(D)
 dI = be.empty((P, P))
 be.block_invert(dD, off, dI)
 X0 = torch.randn((P, n), dtype=torch.float64, device=be.device)
-res = {}
-for opt in (0, 1):
+ref = None
+waves = [int(x) for x in os.environ.get('WAVES', '4').split(',')]
+for opt in [0] + [1] * len(waves):
     be.set_option('block_apply_reg', opt)
+    if opt:
+        wv = waves.pop(0)
+        be.set_option('block_apply_waves', wv)
+    X = None
     X = X0.clone()
     be.block_apply(dI, off, X)
     be.synchronize()
-    res[opt] = X
+    if ref is None:
+        ref = X.clone()
+    else:
+        print('   max|difference| to the round-2 kernel: %.2e' % float((X - ref).abs().max()), flush=True)
     ts = []
     for _ in range(5):
         be.synchronize(); t0 = time.perf_counter()
         be.block_apply(dI, off, X)
         be.synchronize(); ts.append(time.perf_counter() - t0)
     t = min(ts)
-    print('block_apply_reg=%d: %d blocks x %d rows x %d columns: %.2f ms  %.2f TB/s algorithmic (16 P n bytes)' % (opt, nblk, mb, n, t * 1e3, 16.0 * P * n / t / 1e12), flush=True)
-print('max|difference| between the two kernels: %.2e (relative %.1e)' % (float((res[0] - res[1]).abs().max()), float((res[0] - res[1]).abs().max() / res[0].abs().max())))
+    print('block_apply_reg=%d%s: %d blocks x %d rows x %d columns: %.2f ms  %.2f TB/s algorithmic (16 P n bytes)' % (opt, (' waves=%d' % wv) if opt else '', nblk, mb, n, t * 1e3, 16.0 * P * n / t / 1e12), flush=True)
