@@ -516,19 +516,26 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         return c
 
     def _ensure_fit(self, dm=None):
-        """pair_space='occ': make the fit (final points, rows, W) for the density ``dm`` unless the current one was made for the
-        same occupied space (or occ_refit = 'once' and a fit exists).  dm = None or a density without occupied-orbital form:
-        the AO x AO pair space, once per build."""
+        """pair_space='occ': make sure the fit (final points, rows, W) suits what is about to be contracted with W.
+        dm with an occupied-orbital form (MO tag, or positive semidefinite low rank): the (AO x occupied) pair space of THAT
+        density - refit when the occupied space differs from the fitted one (occ_refit='always') or keep the first such fit
+        ('once').  dm = None (AO integrals: get_ao_eri / ao2mo) or a density without such a form (a response or difference
+        density): the AO x AO pair space - an (AO x occupied) fit does not represent those pairs, so it is replaced."""
         if self.pair_space != 'occ' or self._sel is None or self.ao is None:
             return
         orb = None if dm is None else self._occupied_orbitals(dm)
+        want = None if orb is None else orb.dot(orb.T)
         if not self._fit_pending:
-            if orb is None or self.occ_refit == 'once' or self._fit_dm is None:
+            have = self._fit_dm
+            if want is None:
+                if have is None:
+                    return                                            # the AO-pair fit is in place
+            elif have is None:
+                if self.occ_refit == 'once':
+                    return                                            # an AO-pair fit came first and is kept
+            elif self.occ_refit == 'once' or abs(want - have).max() <= 1e-12 * abs(want).max():
                 return
-            proj = orb.dot(orb.T)
-            if abs(proj - self._fit_dm).max() <= 1e-12 * abs(proj).max():
-                return
-        self._fit_dm = None if orb is None else orb.dot(orb.T)
+        self._fit_dm = want
         if self._sel.get('sharded'):
             self._pick_and_fit_sharded(orb)
         else:

@@ -470,3 +470,28 @@ def test_occ_pair_space_beats_ao_pair_space_at_equal_points():
     th_o = oisdf.fit_theta_occ_chol(aoT, psi, ip, reg_rel=1e-13)
     err_occ = abs(oisdf.get_k(np.ascontiguousarray(aoT[:, ip].T), oisdf.build_W(th_o, a, mesh), dm) - k_exact).max()
     assert err_occ < 0.2 * err_ao
+
+
+def test_occ_pair_space_switches_back_to_ao_pairs_when_needed():
+    """pair_space='occ': what W is contracted with decides the pair space.  After a fit for an MO-tagged density, AO integrals
+    (get_ao_eri) and a density WITHOUT occupied-orbital form (indefinite: a response / difference density) are served from an
+    AO x AO fit - the (AO x occupied) fit does not represent those pairs - and the next tagged density gets its own fit back."""
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell, ao, aoT, dm, c, occ = _diamond_case(nocc=2)
+    nao = cell.nao_nr()
+    tdm = _tag(dm, c, occ)
+    ref = ISDF(cell, c_isdf=4, select='refined', backend=OracleBackend())
+    ref.fit_route = 'cholesky'
+    eri_ao = ref.get_ao_eri()
+    rng = np.random.default_rng(3)
+    d1 = rng.standard_normal((nao, nao)); d1 = d1 + d1.T                     # indefinite
+    k_ao = ref.get_jk(d1, with_j=False)[1]
+    df = ISDF(cell, c_isdf=4, select='refined', backend=OracleBackend())
+    df.pair_space, df.fit_route = 'occ', 'cholesky'
+    vk_occ = df.get_jk(tdm, with_j=False)[1]
+    assert df._fit_dm is not None
+    assert abs(df.get_ao_eri() - eri_ao).max() < 1e-9 * abs(eri_ao).max() and df._fit_dm is None
+    assert abs(df.get_jk(d1, with_j=False)[1] - k_ao).max() < 1e-9 * abs(k_ao).max()
+    vk_again = df.get_jk(tdm, with_j=False)[1]
+    assert df._fit_dm is not None and abs(vk_again - vk_occ).max() < 1e-10 * abs(vk_occ).max()
