@@ -321,10 +321,10 @@ def main():
     # pairs) for the benchmark density on this GPU - measured in this run, never read from a file
     vk_exact = None
     t_exact = 0.0
-    if world == 1 and kpts is None and not args.no_accuracy:
+    if kpts is None and not args.no_accuracy:
         print('[bench] exact exchange on the GPU for the accuracy entry (about 40 s)', file=sys.stderr, flush=True)
         ta = time.perf_counter()
-        vk_exact = df.get_k_exact(mo_coeff=c_mo, mo_occ=occ_mo)
+        vk_exact = df.get_k_exact(mo_coeff=c_mo, mo_occ=occ_mo)      # N > 1: the AO rows of K are shared out over the ranks
         torch.cuda.synchronize()
         t_exact = time.perf_counter() - ta
         df.release_fit_buffers()

@@ -912,13 +912,11 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         """The reference's exact exchange (FFTDF.get_jk's K, fft_jk.py:177-302) evaluated on the GPU with
         the same device primitives — N*nocc FFT pairs.  Used to measure the ISDF fitting error at full
         size.  Needs the occupied orbitals (mo_coeff, mo_occ) or a positive semidefinite dm."""
-        if self._sharded:
-            raise NotImplementedError('get_k_exact is a single-GPU verification path')
         if not self._is_gamma(self.kpts) or not self._is_gamma(kpts_band):
+            if self._sharded:
+                raise NotImplementedError('the exact k-point exchange is a single-process verification path')
             return self._get_k_exact_kpts(dm, mo_coeff, mo_occ, kpts_band=kpts_band, rows=rows, max_rows=max_rows)
-        if self.ao is None:
-            self.collocate()
-        be = self.backend
+        be, comm = self.backend, self.comm
         nao = self.cell.nao_nr()
         if mo_coeff is None:
             mo_coeff = getattr(dm, 'mo_coeff', None)
@@ -938,6 +936,24 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         nocc = c.shape[1]
         if max_rows is None:
             max_rows = max(nocc, int((4 << 30) // (8 * G)) // nocc * nocc)
+        if self._sharded:
+            # several ranks: every rank collocates the WHOLE grid (the FFTs are over all of it) and takes a share of the AO rows
+            # of K; all-reduce of the zero-padded result.  Lets bench.py --gpus N report the accuracy entry too.
+            cell = self.cell
+            rcut = gto.estimate_rcut_per_shell(cell)
+            Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+            ao = be.empty((nao, G))
+            be.eval_ao(np.asarray(cell._atm), np.asarray(cell._bas), np.asarray(cell._env), Ls, rcut,
+                       be.to_device(np.ascontiguousarray(self.grids.coords.T)), ao)
+            i0, i1 = comm.split_range(nao)
+            vk = be.zeros((nao, nao))
+            if i1 > i0:
+                be.get_k_exact(ao, G, be.to_device(np.ascontiguousarray(c)), mesh, a, i0, i1 - i0, max_rows, vk)
+            del ao
+            comm.all_reduce_sum(vk)
+            return be.to_host(vk)
+        if self.ao is None:
+            self.collocate()
         vk = be.empty((nao, nao))
         be.get_k_exact(self.ao, G, be.to_device(np.ascontiguousarray(c)), mesh, a, 0, nao, max_rows, vk)
         return be.to_host(vk)

@@ -399,6 +399,13 @@ class OracleBackend:
             M = ap[row0:row0 + nrows].dot(dm[i].numpy()).dot(ap.T) * w[row0:row0 + nrows]
             vk[i] = torch.from_numpy(ap[row0:row0 + nrows].T.dot(M).dot(ap))
 
+    def get_k_exact(self, ao, ngrids, C, mesh, a, i0, ni, max_rows, vk):
+        from oracle import fftdf
+        aoR = np.ascontiguousarray(ao.numpy()[:, :ngrids].T)
+        c = C.numpy()
+        k = fftdf.get_k(aoR, c.dot(c.T), a, mesh, mo_coeff=c, mo_occ=np.ones(c.shape[1]))
+        vk[i0:i0 + ni] = torch.from_numpy(np.ascontiguousarray(k[i0:i0 + ni]))
+
     # ---- k-points ----
     def eval_ao_k(self, atm, bas, env, Ls, rcut, kpt, periodic_part, coords_soa, out_re, out_im):
         c = coords_soa.numpy().T
