@@ -132,6 +132,11 @@ int isdf_eval_ao_k(isdf_handle h,
 
 /* Copy columns: d_dst[mu*ld_dst + i] = d_src[mu*ld_src + d_idx[i]], i < n  (block-major regrouping
  * of the grid for local selection; also picks phi at interpolation points). */
+/* d_out (nrow, nblk) = max |d_src[row, d_blk_off[b] .. d_blk_off[b+1])| (d_blk_off: nblk + 1 device int64 offsets): which AO rows
+ * are identically zero on which block of grid points - the collocation truncates every shell at its rcut (eval_gto.py:169-186), so the
+ * candidate selection of a block may skip those rows without changing a bit of its result. */
+int isdf_block_row_absmax(isdf_handle h, const double* d_src, int nrow, int64_t ld, int nblk, const int64_t* d_blk_off,
+                          double* d_out);
 int isdf_gather_cols(isdf_handle h, const double* d_src, int nrow, int64_t ld_src,
                      const int64_t* d_idx, int64_t n, double* d_dst, int64_t ld_dst);
 

@@ -184,6 +184,14 @@ class HipBackend:
         self.handle.call('isdf_gather_cols', self._p(src), src.shape[0], src.stride(0), self._p(idx), idx.numel(),
                          self._p(dst), dst.stride(0))
 
+    def block_row_absmax(self, src, blk_off):
+        """(nrow, nblk) host array: max |src[row, block b's columns]|."""
+        self._stream()
+        d_off = self.to_device(np.ascontiguousarray(blk_off, dtype=np.int64))
+        out = self.empty((src.shape[0], len(blk_off) - 1))
+        self.handle.call('isdf_block_row_absmax', self._p(src), src.shape[0], src.stride(0), len(blk_off) - 1, self._p(d_off), self._p(out))
+        return self.to_host(out)
+
     def partition_by_atom(self, coords, atom_coords, a, tie_atol=1e-9):
         """owner (G,) int32 on the host: nearest atom of every grid point (coords: host (G, 3)); the grid goes to the device
         once, the partition runs there (isdf_partition_by_atom)."""

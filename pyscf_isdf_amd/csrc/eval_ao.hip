@@ -752,3 +752,32 @@ extern "C" int isdf_gather_cols(isdf_handle h, const double* d_src, int nrow, in
   KERNEL_CHECK(h);
   return ISDF_OK;
 }
+
+
+// out[row * nblk + b] = max |src[row, blk_off[b] .. blk_off[b+1])|: which AO rows vanish identically on which block of grid points
+// (the collocation truncates every shell at its rcut, so far AOs are EXACT zeros there and can be left out of a block's selection
+// without changing one bit of it)
+namespace {
+__global__ __launch_bounds__(256) void block_row_absmax_kernel(const double* __restrict__ src, int64_t ld, const int64_t* __restrict__ blk_off,
+                                                               int nblk, double* __restrict__ out) {
+  __shared__ double red[4];
+  const int row = blockIdx.y, b = blockIdx.x;
+  const int64_t c0 = blk_off[b], c1 = blk_off[b + 1];
+  double m = 0.0;
+  for (int64_t c = c0 + threadIdx.x; c < c1; c += 256) m = fmax(m, fabs(src[(int64_t)row * ld + c]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[(int64_t)row * nblk + b] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+}  // namespace
+
+extern "C" int isdf_block_row_absmax(isdf_handle h, const double* d_src, int nrow, int64_t ld, int nblk, const int64_t* d_blk_off,
+                                     double* d_out) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_src && d_blk_off && d_out && nrow > 0 && nrow <= 65535 && nblk > 0);
+  hipLaunchKernelGGL(block_row_absmax_kernel, dim3((unsigned)nblk, (unsigned)nrow), dim3(256), 0, h->stream, d_src, ld, d_blk_off, nblk,
+                     d_out);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}

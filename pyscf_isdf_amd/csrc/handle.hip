@@ -63,7 +63,7 @@ int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out
 
 extern "C" {
 
-int isdf_abi_version(void) { return 17; }
+int isdf_abi_version(void) { return 18; }
 
 int isdf_set_coulomb_omega(isdf_handle h, double omega) {
   if (!h) return ISDF_ERR_ARG;

@@ -54,6 +54,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
                                           # final pick, the fit and W are made in get_jk (Gamma point, select 'local'/'refined')
         self.occ_refit = 'always'         # pair_space='occ': 'always' = refit whenever get_jk sees another occupied space;
                                           # 'once' = keep the first fit until the next build()
+        self.cand_skip_zero_rows = True   # the per-atom selections skip the AO rows that are identically zero on the atom's block of
+                                          # grid points (the collocation truncates every shell at its rcut): same pivots, less traffic
         self.cand_ao_cutoff = None        # 'refined', Bohr: the CANDIDATE stage of an atom's block sees only the AOs of atoms
                                           # within this distance (minimum image); None: all AOs.  The final pick always uses all.
         self.tie_rtol = 1e-10
@@ -380,6 +382,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         be.gather_cols(self.ao, d_perm, ao_sel)
         if self.select == 'refined' and self.cand_ao_cutoff:
             ao_sel = self._local_ao_rows(ao_sel, scratch[nao + kmax:], blk_off, a)
+        elif self.cand_skip_zero_rows:
+            ao_sel = self._nonzero_ao_rows(ao_sel, scratch[nao + kmax:], blk_off)
         piv = be.empty((cell.natm, kmax), dtype=torch.int64)
         rank = be.select_ip(ao_sel, blk_off, nip, self.select_tol, self.tie_rtol, L, piv)
         del ao_sel, L, scratch
@@ -608,6 +612,27 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             s0, s1 = int(blk_off[b]), int(blk_off[b + 1])
             if s1 > s0:
                 loc[:len(rows), s0:s1] = ao_sel[self.backend.to_device(rows.astype(np.int64)), s0:s1]
+        return loc
+
+    def _nonzero_ao_rows(self, ao_sel, out_rows, blk_off):
+        """Per block of grid points keep only the AO rows that are not identically zero there (packed to the front, zero-padded to
+        a common row count, relative order kept): the collocation truncates every shell at its rcut, so for a cell larger than the
+        reach of its AOs a large part of every block's rows are exact zeros - terms fma(0, 0, s) = s of the selection's dot products.
+        ao_sel: (nao, G) block-major; returns a (nloc_max, G) view of out_rows, or ao_sel itself when little would be saved."""
+        be = self.backend
+        natm = len(blk_off) - 1
+        mx = be.block_row_absmax(ao_sel, blk_off)
+        lists = [np.nonzero(mx[:, b] > 0.0)[0] for b in range(natm)]
+        nloc = max([len(x) for x in lists] + [1])
+        self._cand_rows_kept = (nloc, ao_sel.shape[0])
+        if nloc > 0.95 * ao_sel.shape[0]:
+            return ao_sel
+        loc = out_rows[:nloc]
+        loc.zero_()
+        for b, rows in enumerate(lists):
+            s0, s1 = int(blk_off[b]), int(blk_off[b + 1])
+            if s1 > s0 and len(rows):
+                loc[:len(rows), s0:s1] = ao_sel[be.to_device(rows.astype(np.int64)), s0:s1]
         return loc
 
     def _refine_selection(self, perm, blk_off, piv_h, rank, P_target, owner):

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _lib = None
 
@@ -33,6 +33,7 @@ SIGNATURES = {
     'isdf_prof_count': (c_int, [c_vp]),
     'isdf_prof_get': (c_int, [c_vp, c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]),
     'isdf_eval_ao': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_i64]),
+    'isdf_block_row_absmax': (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp]),
     'isdf_gather_cols': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_vp, c_i64]),
     'isdf_partition_by_atom': (c_int, [c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_dbl, c_vp]),
     'isdf_select_ip': (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_i64, c_vp, c_vp]),

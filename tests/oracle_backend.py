@@ -168,6 +168,11 @@ class OracleBackend:
     def gather_cols(self, src, idx, dst):
         dst[:, :idx.numel()] = src[:, idx]
 
+    def block_row_absmax(self, src, blk_off):
+        a = np.abs(src.numpy())
+        return np.array([[a[r, blk_off[b]:blk_off[b + 1]].max() if blk_off[b + 1] > blk_off[b] else 0.0 for b in range(len(blk_off) - 1)]
+                         for r in range(a.shape[0])])
+
     def partition_by_atom(self, coords, atom_coords, a, tie_atol=1e-9):
         from pyscf_isdf_amd._common import partition_grid_by_atom
         return partition_grid_by_atom(np.asarray(coords), np.asarray(atom_coords), np.asarray(a), tie_atol)

@@ -1221,3 +1221,31 @@ def test_max_device_memory_forces_panels_without_changing_the_result():
     k1 = df.get_jk(dm, with_j=False)[1]
     assert df.n_panels >= 2 and np.array_equal(df.ip, ref.ip)
     assert abs(k1 - k0).max() < 1e-9 * abs(k0).max()
+
+
+def test_candidate_stage_skips_rows_that_vanish_on_a_block_without_changing_the_points(be):
+    """The per-atom selections leave out the AO rows that are identically zero on the atom's block of grid points (shells
+    truncated at rcut): exact zeros drop out of every dot product, so points and K are the same to the last bit; and the
+    row maxima behind the decision are the true ones."""
+    from pyscf_isdf_amd.isdf import ISDF
+    atoms = '; '.join('He %g %g %g' % (x, y, z) for x in (0.3, 4.2) for y in (0.1, 4.4) for z in (0.2, 4.1))
+    cell = gto.Cell(atom=atoms, basis={'He': [[0, [2.2, 1]], [0, [1.1, 1]], [1, [1.6, 1]]]}, a=np.eye(3) * 8.0, mesh=[30] * 3)
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(5)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    out = {}
+    for flag in (False, True):
+        df = ISDF(cell, c_isdf=6, select='refined')
+        df.cand_skip_zero_rows = flag
+        vk = df.get_jk(dm, with_j=False)[1]
+        out[flag] = (df.ip.copy(), vk, getattr(df, '_cand_rows_kept', None))
+    kept, total = out[True][2]
+    assert total == nao and kept < 0.8 * nao and out[False][2] is None
+    assert np.array_equal(out[False][0], out[True][0])
+    assert np.array_equal(out[False][1], out[True][1])
+    # the kernel behind it against numpy on ragged blocks (one of them empty)
+    src = rng.standard_normal((37, 1000)); src[5, 100:300] = 0.0; src[:, 700:] *= 1e-3
+    off = np.array([0, 100, 300, 300, 707, 1000], dtype=np.int64)
+    got = be.block_row_absmax(be.to_device(src), off)
+    ref = np.stack([abs(src[:, a:b]).max(axis=1) if b > a else np.zeros(37) for a, b in zip(off[:-1], off[1:])], axis=1)
+    assert got.shape == (37, 5) and np.array_equal(got, ref)
