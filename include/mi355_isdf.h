@@ -63,7 +63,9 @@ int isdf_release_workspace(isdf_handle h);
  * "block_apply_reg": 1 (default) isdf_block_apply keeps the block inverse in registers and walks the grid columns (blocks of up
  * to 256 rows), 0 the round-2 kernel that re-reads the inverse from L2 for every 32-column tile.
  * "conv_sub_rows": rows per sub-batch of the three-pass plane convolution (0, the default: the whole batch per pass); measured
- * neutral to slightly negative (profiles/r03_conv_sub_batches.log) - kept as the record of the experiment. */
+ * neutral to slightly negative (profiles/r03_conv_sub_batches.log) - kept as the record of the experiment.
+ * "gram_pivot_tpb": columns per workgroup of isdf_select_ip_gram's pivot step, 256 (default), 128 or 64; same pivots and
+ * factor for every value, narrower is slower (12.2 / 13.0 / 15.5 us per pivot, profiles/r03_gram_pivot_step_widths.log). */
 int isdf_set_option(isdf_handle h, const char* key, int value);
 /* Range separation of the Gamma-point Coulomb kernel used by isdf_coulomb_W / _rows / _potential / isdf_get_j, as
  * pyscf/pbc/tools/pbc.py:408-418: omega > 0 long range (erf(omega r)/r), omega < 0 short range, 0 (default) plain 1/r.

@@ -60,6 +60,7 @@ struct isdf_ctx {
   int gemm_nn_own = 0;
   int attr_gemm_b = 0, attr_gemm_nn = 0;   // dynamic-LDS attributes raised on this handle's device
   int conv_sub_rows = 0;     // rows per cache-resident sub-batch of the plane convolution (0: whole batch)
+  int gram_pivot_tpb = 256;  // columns per workgroup of the Gram selection's pivot step (64, 128 or 256: measured 15.5 / 13.0 / 12.2 us per pivot)
   int block_apply_waves = 16;// grid of the register block apply: workgroups ~ this many times the CU count
   int block_apply_reg = 1;   // block apply with the block inverse in registers, persistent over column tiles (trsm.hip)
   // range-separation parameter of the Gamma-point Coulomb kernel table (0 = plain 1/r); isdf_set_coulomb_omega

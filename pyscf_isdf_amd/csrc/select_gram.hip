@@ -21,8 +21,8 @@
 
 namespace {
 
-constexpr int TPB = 256;
-constexpr int SW = 2048;       // strip width of the block-lower trailing update (a multiple of TPB)
+constexpr int PANEL_MAX = 256; // most pivots per panel (rows of Lp whose pivot entries are staged in LDS)
+constexpr int SW = 2048;       // strip width of the block-lower trailing update (a multiple of every workgroup width)
 
 struct GramState {
   double tol;
@@ -43,6 +43,7 @@ __device__ inline int wmin(int v) {
 }
 
 // d0[i] = A[i,i]; per-workgroup maxima
+template <int TPB>
 __global__ __launch_bounds__(TPB) void gram_diag_kernel(const double* __restrict__ A, int64_t ldA, int m,
                                                        double* __restrict__ d, double* __restrict__ wgmax) {
   __shared__ double red[TPB / 64];
@@ -61,40 +62,54 @@ __global__ __launch_bounds__(TPB) void gram_diag_kernel(const double* __restrict
   }
 }
 
-// One pivot: j = global pivot index, jl = index inside the current panel (rows of Lp).
+// One pivot: j = global pivot index, jl = index inside the current panel (rows of Lp).  TPB = columns per workgroup; the
+// arithmetic of a column does not depend on it.  Measured at m = 39 936 (profiles/r03_gram_pivot_step_widths.log): a step costs
+// 7 us + 0.04 us per panel row already made - the second term is the panel streaming out of the Infinity Cache at 7.4 TB/s, the
+// first is the launch boundary, the dispatch of the workgroups and three dependent memory round trips.  Narrower workgroups are
+// SLOWER (more of them to dispatch, each repeating the pivot search), so 256 stays the default.
+template <int TPB>
 __global__ __launch_bounds__(TPB) void gram_pivot_step_kernel(
     const double* __restrict__ A, int64_t ldA, int m, double* __restrict__ Lp, int64_t ldL,
     const double* __restrict__ d_old, double* __restrict__ d_new, const double* __restrict__ wg_old,
     double* __restrict__ wg_new, int nwg, int j, int jl, int nip, double tol_in, double tie_rtol,
     GramState* __restrict__ st, int64_t* __restrict__ piv) {
-  __shared__ double s_red[TPB / 64];
-  __shared__ int s_redi[TPB / 64];
-  __shared__ double s_pl[TPB];
-  __shared__ double s_bc[2];
-  __shared__ int s_bci[2];
+  constexpr int NW = TPB / 64;
+  constexpr int CH = 32;           // loads of one chunk of the panel's rows, all issued before the chunk's first fma
+  __shared__ double s_red[NW];
+  __shared__ int s_redi[2][NW];
+  __shared__ double s_pl[PANEL_MAX];
+  __shared__ double s_dp;
   const int tid = threadIdx.x;
   const int wg = blockIdx.x;
   const int i = wg * TPB + tid;
   const bool valid = i < m;
+  // The step is a chain of dependent memory round trips (maxima -> the first workgroup's diagonals -> the pivot's row and
+  // panel entries -> the panel rows of the own column) on a chip where every wave sits alone on its SIMD (m / 64 waves, 1024
+  // SIMDs): everything that does not depend on the pivot is requested up front - the own diagonal, the state, and the first
+  // chunk of the own column's panel rows - and what depends only on the pivot (its row of A, its panel entries) goes out together.
+  const double* __restrict__ pL = Lp + i;
+  const double dold = valid ? d_old[i] : -1.0;
+  const int st_done = st->done;
+  const double st_tol = st->tol;
+  double v0[CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) v0[u] = (valid && u < jl) ? pL[(int64_t)u * ldL] : 0.0;
 
-  // (1) global maximum of the residual diagonal from the per-workgroup maxima of the previous step
+  // (1) global maximum of the residual diagonal from the per-workgroup maxima of the previous step, and (2) the first
+  // workgroup whose maximum is within the tie tolerance (second sweep over the same, now cached, values)
   double gm = 0.0;
   for (int w = tid; w < nwg; w += TPB) gm = fmax(gm, wg_old[w]);
   gm = wmax(gm);
   if ((tid & 63) == 0) s_red[tid >> 6] = gm;
   __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < TPB / 64; ++w) gm = fmax(gm, s_red[w]);
-    s_bc[0] = gm;
-  }
-  __syncthreads();
-  gm = s_bc[0];
-  const double tol = (j == 0) ? (tol_in < 0 ? (double)m * DBL_EPSILON * gm : tol_in) : st->tol;
-  const bool stop = st->done || j >= nip || !(gm > tol);
+#pragma unroll
+  for (int w = 0; w < NW; ++w) gm = fmax(gm, s_red[w]);
+  const double tol = (j == 0) ? (tol_in < 0 ? (double)m * DBL_EPSILON * gm : tol_in) : st_tol;
+  const bool stop = st_done || j >= nip || !(gm > tol);
   if (stop) {
     if (valid) {
       Lp[(int64_t)jl * ldL + i] = 0.0;
-      d_new[i] = d_old[i];
+      d_new[i] = dold;
     }
     if (tid == 0) {
       wg_new[wg] = wg_old[wg];
@@ -102,43 +117,34 @@ __global__ __launch_bounds__(TPB) void gram_pivot_step_kernel(
     }
     return;
   }
-  // (2) first workgroup whose maximum is within the tie tolerance, then the first such column inside it
   const double thr = gm * (1.0 - tie_rtol);
   int wfirst = INT_MAX;
   for (int w = tid; w < nwg; w += TPB)
     if (wg_old[w] >= thr && wg_old[w] > 0.0) { wfirst = w; break; }
   wfirst = wmin(wfirst);
-  if ((tid & 63) == 0) s_redi[tid >> 6] = wfirst;
+  if ((tid & 63) == 0) s_redi[0][tid >> 6] = wfirst;
   __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < TPB / 64; ++w) wfirst = s_redi[w] < wfirst ? s_redi[w] : wfirst;
-    s_bci[0] = wfirst;
-  }
-  __syncthreads();
-  wfirst = s_bci[0];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) wfirst = s_redi[0][w] < wfirst ? s_redi[0][w] : wfirst;
+  // the first column of that workgroup within the tolerance; the lane that holds it publishes sqrt(d_p)
   int cand = INT_MAX;
-  {
-    const int c = wfirst * TPB + tid;
-    if (c < m) {
-      const double dv = d_old[c];
-      if (dv >= thr && dv > 0.0) cand = c;
-    }
+  double dv = 0.0;
+  const int c = wfirst == INT_MAX ? m : wfirst * TPB + tid;
+  if (c < m) {
+    dv = d_old[c];
+    if (dv >= thr && dv > 0.0) cand = c;
   }
+  const int mine = cand;
   cand = wmin(cand);
-  if ((tid & 63) == 0) s_redi[tid >> 6] = cand;
+  if ((tid & 63) == 0) s_redi[1][tid >> 6] = cand;
   __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < TPB / 64; ++w) cand = s_redi[w] < cand ? s_redi[w] : cand;
-    s_bci[1] = cand;
-    s_bc[1] = cand == INT_MAX ? 0.0 : sqrt(d_old[cand]);
-  }
-  __syncthreads();
-  const int p = s_bci[1];
-  const double dp = s_bc[1];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) cand = s_redi[1][w] < cand ? s_redi[1][w] : cand;
+  const int p = cand;
   if (p == INT_MAX) {   // cannot happen while the maxima are consistent with d; never index with it
     if (valid) {
       Lp[(int64_t)jl * ldL + i] = 0.0;
-      d_new[i] = d_old[i];
+      d_new[i] = dold;
     }
     if (tid == 0) {
       wg_new[wg] = wg_old[wg];
@@ -146,13 +152,18 @@ __global__ __launch_bounds__(TPB) void gram_pivot_step_kernel(
     }
     return;
   }
-  // (3) the pivot's entries of the current panel
-  if (tid < jl) s_pl[tid] = Lp[(int64_t)tid * ldL + p];
+  // (3) what depends on the pivot alone: its row of A at the own column (symmetric read from the block-lower part: (p, i) is
+  // current iff p >= first row of i's strip) and its entries of the current panel
+  const bool work = valid && i != p && !(dold < 0.0);
+  double col = 0.0;
+  if (work) col = (p >= (i / SW) * SW) ? A[(int64_t)p * ldA + i] : A[(int64_t)i * ldA + p];
+  for (int t = tid; t < jl; t += TPB) s_pl[t] = Lp[(int64_t)t * ldL + p];
+  if (mine == p) s_dp = sqrt(dv);
   __syncthreads();
-  // (4) this workgroup's columns
+  const double dp = s_dp;
+  // (4) this workgroup's columns: one fixed fma chain per column (t ascending)
   double dnew = 0.0;
   if (valid) {
-    const double dold = d_old[i];
     double row;
     if (i == p) {
       row = dp;
@@ -161,11 +172,25 @@ __global__ __launch_bounds__(TPB) void gram_pivot_step_kernel(
       row = 0.0;
       dnew = -1.0;
     } else {
-      // symmetric read from the block-lower part: (p, i) is current iff p >= first row of i's strip
-      double col = (p >= (i / SW) * SW) ? A[(int64_t)p * ldA + i] : A[(int64_t)i * ldA + p];
-      const double* __restrict__ pL = Lp + i;
-#pragma unroll 8
-      for (int t = 0; t < jl; ++t) col = fma(-pL[(int64_t)t * ldL], s_pl[t], col);
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (u < jl) col = fma(-v0[u], s_pl[u], col);
+      int t = CH;
+      for (; t + CH <= jl; t += CH) {
+        double v[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) v[u] = pL[(int64_t)(t + u) * ldL];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) col = fma(-v[u], s_pl[t + u], col);
+      }
+      if (t < jl) {
+        double v[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) v[u] = (t + u < jl) ? pL[(int64_t)(t + u) * ldL] : 0.0;
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if (t + u < jl) col = fma(-v[u], s_pl[t + u], col);
+      }
       row = col / dp;
       dnew = fma(-row, row, dold);
       if (dnew < 0.0) dnew = 0.0;
@@ -174,10 +199,11 @@ __global__ __launch_bounds__(TPB) void gram_pivot_step_kernel(
     d_new[i] = dnew;
   }
   double mx = wmax(valid ? fmax(dnew, 0.0) : 0.0);
-  if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+  if ((tid & 63) == 0) s_red[tid >> 6] = mx;     // s_red's readers of step (1) are all past the later barriers
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < TPB / 64; ++w) mx = fmax(mx, s_red[w]);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmax(mx, s_red[w]);
     wg_new[wg] = mx;
     if (wg == 0) {
       piv[j] = p;
@@ -195,8 +221,9 @@ extern "C" int isdf_select_ip_gram(isdf_handle h, double* d_A, int m, int64_t ld
   ARG_CHECK(h, d_A && d_piv && rank);
   ARG_CHECK(h, m > 0 && ldA >= m && nip > 0 && tie_rtol >= 0.0 && tie_rtol < 1.0);
   if (panel <= 0) panel = 256;
-  ARG_CHECK(h, panel <= TPB);
+  ARG_CHECK(h, panel <= PANEL_MAX);
   if (nip > m) nip = m;
+  const int TPB = h->gram_pivot_tpb;
   const int nwg = (int)cdiv(m, TPB);
   const int64_t ldL = ((int64_t)m + 31) / 32 * 32;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -214,7 +241,9 @@ extern "C" int isdf_select_ip_gram(isdf_handle h, double* d_A, int m, int64_t ld
   double* d_Lp = (double*)ws;
   HIP_TRY(h, hipMemsetAsync(d_st, 0, sizeof(GramState), h->stream));
   HIP_TRY(h, hipMemsetAsync(d_piv, 0xff, sizeof(int64_t) * (size_t)nip, h->stream));
-  hipLaunchKernelGGL(gram_diag_kernel, dim3(nwg), dim3(TPB), 0, h->stream, d_A, ldA, m, d_d[0], d_w[0]);
+  if (TPB == 64) hipLaunchKernelGGL(gram_diag_kernel<64>, dim3(nwg), dim3(64), 0, h->stream, d_A, ldA, m, d_d[0], d_w[0]);
+  else if (TPB == 128) hipLaunchKernelGGL(gram_diag_kernel<128>, dim3(nwg), dim3(128), 0, h->stream, d_A, ldA, m, d_d[0], d_w[0]);
+  else hipLaunchKernelGGL(gram_diag_kernel<256>, dim3(nwg), dim3(256), 0, h->stream, d_A, ldA, m, d_d[0], d_w[0]);
   KERNEL_CHECK(h);
   int cur = 0;
   for (int k0 = 0; k0 < nip; k0 += panel) {
@@ -222,9 +251,13 @@ extern "C" int isdf_select_ip_gram(isdf_handle h, double* d_A, int m, int64_t ld
     {
       ProfScope ps(h, "gram_pivot_step_kernel[byte]", 8.0 * (double)m * (0.5 * nb * (nb - 1) + 4.0 * nb), nb);
       for (int jl = 0; jl < nb; ++jl) {
-        hipLaunchKernelGGL(gram_pivot_step_kernel, dim3(nwg), dim3(TPB), 0, h->stream, d_A, ldA, m, d_Lp, ldL,
-                           d_d[cur], d_d[cur ^ 1], d_w[cur], d_w[cur ^ 1], nwg, k0 + jl, jl, nip, tol, tie_rtol,
-                           d_st, d_piv);
+#define ISDF_GRAM_STEP(T)                                                                                              \
+  hipLaunchKernelGGL(gram_pivot_step_kernel<T>, dim3(nwg), dim3(T), 0, h->stream, d_A, ldA, m, d_Lp, ldL, d_d[cur],     \
+                     d_d[cur ^ 1], d_w[cur], d_w[cur ^ 1], nwg, k0 + jl, jl, nip, tol, tie_rtol, d_st, d_piv)
+        if (TPB == 64) ISDF_GRAM_STEP(64);
+        else if (TPB == 128) ISDF_GRAM_STEP(128);
+        else ISDF_GRAM_STEP(256);
+#undef ISDF_GRAM_STEP
         cur ^= 1;
       }
       KERNEL_CHECK(h);
