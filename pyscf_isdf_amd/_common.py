@@ -65,3 +65,21 @@ def _default_fft_batch(G, P, free_bytes=None):
     if nb >= 128:
         nb -= nb % 128
     return max(1, nb)
+
+
+class TaggedArray(np.ndarray):
+    """ndarray with attributes (the role of pyscf.lib.tag_array: veff with ecoul / exc / vj / vk, density matrices with
+    mo_coeff / mo_occ)."""
+
+    def __new__(cls, a, **tags):
+        obj = np.asarray(a).view(cls)
+        obj.__dict__.update(tags)
+        return obj
+
+    def __array_finalize__(self, obj):
+        if obj is not None and hasattr(obj, '__dict__'):
+            self.__dict__.update(getattr(obj, '__dict__', {}))
+
+
+def tag_array(a, **tags):
+    return TaggedArray(a, **tags)

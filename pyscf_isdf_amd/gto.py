@@ -376,16 +376,28 @@ class Cell:
               + rz[None, None, :, None] * b[2])
         return Gv.reshape(-1, 3)
 
-    def make_kpts(self, nks, wrap_around=False):
-        """Monkhorst-Pack mesh including Γ (cell.py make_kpts semantics, no symmetry)."""
+    def make_kpts(self, nks, wrap_around=False, with_gamma_point=True, scaled_center=None,
+                  space_group_symmetry=False, time_reversal_symmetry=False, **kwargs):
+        """Monkhorst-Pack mesh (pyscf/pbc/gto/cell.py:815-872): Gamma centred unless with_gamma_point=False; with
+        space_group_symmetry / time_reversal_symmetry a kpts_symm.KPoints object (further keywords, e.g. symmorphic=True, go to
+        its build)."""
         ks_each_axis = []
         for n in nks:
-            ks = np.arange(n, dtype=float) / n
+            if with_gamma_point or scaled_center is not None:
+                ks = np.arange(n, dtype=float) / n
+            else:
+                ks = (np.arange(n) + .5) / n - .5
             if wrap_around:
                 ks[ks >= .5] -= 1
             ks_each_axis.append(ks)
         scaled = cartesian_prod(ks_each_axis)
-        return np.dot(scaled, self.reciprocal_vectors())
+        if scaled_center is not None:
+            scaled = scaled + np.asarray(scaled_center, dtype=float)
+        kpts = np.dot(scaled, self.reciprocal_vectors())
+        if space_group_symmetry or time_reversal_symmetry:
+            from . import kpts_symm
+            return kpts_symm.make_kpts(self, kpts, space_group_symmetry, time_reversal_symmetry, **kwargs)
+        return kpts
 
 
 # ----------------------------------------------------------------------------------------------

@@ -38,6 +38,11 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         self.stdout = getattr(cell, 'stdout', None) or sys.stdout
         self.verbose = getattr(cell, 'verbose', 0)
         self.max_memory = getattr(cell, 'max_memory', 4000)
+        self.kpts_symm = None             # a kpts_symm.KPoints object passed as kpts: get_jk then takes the density matrices on
+                                          # the irreducible k-points and returns J, K there (khf_ksymm.py:210-237)
+        if hasattr(kpts, 'kpts_ibz') and hasattr(kpts, 'transform_dm'):
+            self.kpts_symm = kpts
+            kpts = kpts.kpts
         self.kpts = np.asarray(kpts).reshape(-1, 3)
         self.grids = UniformGrids(cell, cell.mesh)
         self.blockdim = 240
@@ -856,7 +861,17 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
     def get_jk(self, dm, hermi=1, kpts=None, kpts_band=None, with_j=True, with_k=True, omega=None,
                exxdiv=None):
         if kpts is None:
-            kpts = self.kpts
+            kpts = self.kpts_symm if self.kpts_symm is not None else self.kpts
+        if hasattr(kpts, 'kpts_ibz') and hasattr(kpts, 'transform_dm'):
+            # k-point symmetry (pyscf/pbc/scf/khf_ksymm.py:210-237): density matrices on the irreducible k-points, rotated to
+            # the full zone on the host; J and K on the irreducible k-points (or on kpts_band when given)
+            ndm = np.asarray(dm).shape[-3] if np.asarray(dm).ndim >= 3 else 1
+            if ndm != kpts.nkpts_ibz:
+                raise RuntimeError('number of input density matrices does not match the number of irreducible k-points: '
+                                   '%d vs %d' % (ndm, kpts.nkpts_ibz))
+            dm_bz = kpts.transform_dm(dm)
+            band = kpts.kpts_ibz if kpts_band is None else kpts_band
+            return self.get_jk(dm_bz, hermi, kpts.kpts, band, with_j, with_k, omega, exxdiv)
         if omega is not None and abs(omega) > 0:
             if not self._is_gamma(kpts) or not self._is_gamma(self.kpts) or not self._is_gamma(kpts_band):
                 if self._is_gamma(kpts) and np.asarray(dm).ndim == 2:

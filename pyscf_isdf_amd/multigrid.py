@@ -38,6 +38,7 @@ import numpy as np
 import torch
 from . import gto
 from .isdf import ISDF
+from ._common import TaggedArray
 
 MIN_LEVEL_MESH = 12     # no level mesh below this per dimension (the reference's smallest task mesh, multigrid.py:57)
 ANG_OF, NPRIM_OF, NCTR_OF, PTR_EXP, PTR_COEFF = 1, 2, 3, 5, 6
@@ -257,19 +258,6 @@ def _levels_of_runs(cell, ke_prim, tops, meshes, runs):
         Ls = gto.get_lattice_Ls(sub, rcut=rcut.max())
         levels.append(Level(meshes[j - 1], (ke0, ke1), sub._bas, sub._env, len(dense[0]), len(dense[2]), dense[2], sparse[2], Ls, rcut))
     return levels
-
-
-class TaggedArray(np.ndarray):
-    """ndarray with attributes (the role of pyscf.lib.tag_array for nr_rks's veff: ecoul, exc, vj, vk)."""
-
-    def __new__(cls, a, **tags):
-        obj = np.asarray(a).view(cls)
-        obj.__dict__.update(tags)
-        return obj
-
-    def __array_finalize__(self, obj):
-        if obj is not None and hasattr(obj, '__dict__'):
-            self.__dict__.update(getattr(obj, '__dict__', {}))
 
 
 def _xc_kind(xc_code):

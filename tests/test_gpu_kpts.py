@@ -546,3 +546,62 @@ def test_even_mesh_pair_correction_on_device():
         scale = abs(res[False]).max()
         assert abs(res['auto'] - res[False]).max() < 1e-10 * scale, (select, abs(res['auto'] - res[False]).max() / scale)
         assert abs(res['uncorrected'] - res[False]).max() > 1e-7 * scale
+
+
+def test_kpoint_symmetry_jk_on_the_irreducible_kpoints():
+    """A kpts_symm.KPoints object in place of the k-point array (pyscf/pbc/scf/khf_ksymm.py:210-237): density matrices on the
+    irreducible k-points in, J / K on the irreducible k-points out; rotated to the full zone (transform_fock) they are the J / K
+    of the plain call with the full-zone density matrices - J and the exact exchange to rounding (both are symmetric when the
+    FFT mesh is), the ISDF K to its fitting error (the interpolation points are not a symmetric set).  Diamond, 3 x 3 x 3:
+    4 irreducible k-points of 27, 48 operations with fractional translations."""
+    import scipy.linalg
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = gto.diamond_primitive('gth-szv', (16, 16, 16))
+    kp = cell.make_kpts([3, 3, 3], space_group_symmetry=True, time_reversal_symmetry=True)
+    assert kp.nkpts_ibz == 4 and kp.nop == 48
+    nao, nk = cell.nao_nr(), kp.nkpts
+    coords = cell.get_uniform_grids()
+    rcut = gto.estimate_rcut_per_shell(cell)
+    Ls = gto.get_lattice_Ls(cell, rcut=rcut.max())
+    aos = oao.eval_ao(cell._atm, cell._bas, cell._env, coords, Ls, rcut, kpts=kp.kpts)
+    w = cell.vol / len(coords)
+    v = np.zeros(len(coords))
+    for ra in cell.atom_coords():
+        for L in Ls:
+            d = coords - (ra + L)
+            v -= np.exp(-0.8 * np.einsum('gx,gx->g', d, d))
+    mos, occs, dms = [], [], []
+    for ao in aos:                                        # a symmetric model Hamiltonian's two lowest bands, doubly occupied
+        S, V = w * ao.conj().T.dot(ao), w * (ao.conj().T * v).dot(ao)
+        e, c = scipy.linalg.eigh(V, S)
+        occ = np.zeros(nao); occ[:4] = 2.0
+        mos.append(c); occs.append(occ); dms.append((c * occ).dot(c.conj().T))
+    dm_bz = np.array(dms)
+    dm_ibz = dm_bz[kp.ibz2bz]
+    assert abs(kp.transform_dm(dm_ibz) - dm_bz).max() < 1e-9
+    df = ISDF(cell, kpts=kp, c_isdf=25, select='local')
+    df.k_ip_factor = 2
+    assert df.kpts.shape == (27, 3)
+    vj_i, vk_i = df.get_jk(dm_ibz)
+    assert vj_i.shape == vk_i.shape == (4, nao, nao)
+    with pytest.raises(RuntimeError):
+        df.get_jk(dm_bz)
+    ref = ISDF(cell, kpts=kp.kpts, c_isdf=25, select='local')
+    ref.k_ip_factor = 2
+    vj_b, vk_b = ref.get_jk(dm_bz)
+    assert abs(vj_i - vj_b[kp.ibz2bz]).max() < 1e-9 and abs(vk_i - vk_b[kp.ibz2bz]).max() < 1e-8
+    # the device collocation drops shell images below the cell's precision block by block - not a symmetric rule, so the rotated
+    # images agree to that truncation (6e-7 here), not to rounding as with the oracle's distance rule (tests/test_kpts_symm.py)
+    assert abs(kp.transform_fock(vj_i) - vj_b).max() < 5e-6
+    # exact exchange: symmetric to the same level; the ISDF K deviates from it - and from its own rotated images - by the fit error
+    kx_b = ref.get_k_exact(dm_bz, mo_coeff=np.array(mos), mo_occ=np.array(occs))
+    kx_i = ref.get_k_exact(dm_bz, mo_coeff=np.array(mos), mo_occ=np.array(occs), kpts_band=kp.kpts_ibz)
+    assert abs(kx_i - kx_b[kp.ibz2bz]).max() < 1e-9
+    assert abs(kp.transform_fock(kx_i) - kx_b).max() < 5e-6
+    err = abs(vk_b - kx_b).max()
+    assert err < 2e-4 * abs(kx_b).max()
+    assert abs(kp.transform_fock(vk_i) - vk_b).max() < 4 * err
+    # energies through the weights of the irreducible k-points
+    ek_bz = np.einsum('kij,kji', vk_b, dm_bz).real / nk
+    ek_ibz = np.einsum('k,kij,kji', kp.weights_ibz, vk_i, dm_ibz).real
+    assert abs(ek_ibz - ek_bz) < 4 * err * nao
