@@ -59,6 +59,7 @@ struct isdf_ctx {
   // the square fused into its epilogue (66-71 TF/s; kept as the library-free route and for A/B runs)
   int gemm_nn_own = 0;
   int attr_gemm_b = 0, attr_gemm_nn = 0;   // dynamic-LDS attributes raised on this handle's device
+  int conv_pipe = 1;         // plane passes of the convolution: 1 persistent workgroups with the next plane prefetched, 0 one workgroup per plane
   int conv_sub_rows = 0;     // rows per cache-resident sub-batch of the plane convolution (0: whole batch)
   int gram_pivot_tpb = 256;  // columns per workgroup of the Gram selection's pivot step (64, 128 or 256: measured 15.5 / 13.0 / 12.2 us per pivot)
   int block_apply_waves = 16;// grid of the register block apply: workgroups ~ this many times the CU count

@@ -520,19 +520,20 @@ __global__ __launch_bounds__(TPB) void strided_fft_fast_kernel(double2* __restri
 // chosen = 1 mod 16 (the real-plane load and the separation walk z fastest: a stride of 4 banks), y stage P[y][kz] with pitch
 // n2/2+1 = the global layout of the half spectrum.
 constexpr int TPBP = 1024;
-constexpr int PLANE_ENTRIES = 10240;             // complex numbers: the most a plane buffer may hold (160 KB of LDS)
+constexpr int PLANE_ENTRIES = 10240;
+constexpr int PIPE_NT = 768;                     // threads of the pipelined plane passes (12 waves: 170 VGPRs each)             // complex numbers: the most a plane buffer may hold (160 KB of LDS)
 
-template <int SIGN, int R>
+template <int SIGN, int R, int NT, int KM = 0>
 __device__ inline void stage_plane(double2* __restrict__ buf, int N, int n_cur, int s, int Ls, int M,
-                                   const double2* __restrict__ tw) {
-  constexpr int KMAX = (PLANE_ENTRIES / TPBP + R - 1) / R;
+                                   const double2* __restrict__ tw, const int tid) {
+  constexpr int KMAX = KM > 0 ? KM : ((PLANE_ENTRIES + NT - 1) / NT + R - 1) / R;
   const int mm = n_cur / R;
   const int total = (N / R) * M;
   const float inv_s = 1.0f / (float)s, inv_M = 1.0f / (float)M;
   double2 out[KMAX][R];
 #pragma unroll
   for (int u = 0; u < KMAX; ++u) {
-    const int i = threadIdx.x + u * TPBP;
+    const int i = tid + u * NT;
     if (i < total) {
       const int bf = (int)(((float)i + 0.5f) * inv_M), m = i - bf * M;
       const int p = (int)(((float)bf + 0.5f) * inv_s), q = bf - p * s;
@@ -555,7 +556,7 @@ __device__ inline void stage_plane(double2* __restrict__ buf, int N, int n_cur, 
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < KMAX; ++u) {
-    const int i = threadIdx.x + u * TPBP;
+    const int i = tid + u * NT;
     if (i < total) {
       const int bf = (int)(((float)i + 0.5f) * inv_M), m = i - bf * M;
       const int p = (int)(((float)bf + 0.5f) * inv_s), q = bf - p * s;
@@ -568,23 +569,23 @@ __device__ inline void stage_plane(double2* __restrict__ buf, int N, int n_cur, 
   __syncthreads();
 }
 
-template <int SIGN>
+template <int SIGN, int NT = 1024>
 __device__ inline void fft_plane(double2* buf, const Axis& ax, int Ls, int M, const double2* tw) {
   int n_cur = ax.n, s = 1;
   for (int st = 0; st < ax.nstage; ++st) {
     const int r = ax.radix[st];
     switch (r) {
-      case 16: stage_plane<SIGN, 16>(buf, ax.n, n_cur, s, Ls, M, tw); break;
-      case 15: stage_plane<SIGN, 15>(buf, ax.n, n_cur, s, Ls, M, tw); break;
-      case 12: stage_plane<SIGN, 12>(buf, ax.n, n_cur, s, Ls, M, tw); break;
-      case 10: stage_plane<SIGN, 10>(buf, ax.n, n_cur, s, Ls, M, tw); break;
-      case 9: stage_plane<SIGN, 9>(buf, ax.n, n_cur, s, Ls, M, tw); break;
-      case 8: stage_plane<SIGN, 8>(buf, ax.n, n_cur, s, Ls, M, tw); break;
-      case 6: stage_plane<SIGN, 6>(buf, ax.n, n_cur, s, Ls, M, tw); break;
-      case 5: stage_plane<SIGN, 5>(buf, ax.n, n_cur, s, Ls, M, tw); break;
-      case 4: stage_plane<SIGN, 4>(buf, ax.n, n_cur, s, Ls, M, tw); break;
-      case 3: stage_plane<SIGN, 3>(buf, ax.n, n_cur, s, Ls, M, tw); break;
-      default: stage_plane<SIGN, 2>(buf, ax.n, n_cur, s, Ls, M, tw); break;
+      case 16: stage_plane<SIGN, 16, NT>(buf, ax.n, n_cur, s, Ls, M, tw, (int)threadIdx.x); break;
+      case 15: stage_plane<SIGN, 15, NT>(buf, ax.n, n_cur, s, Ls, M, tw, (int)threadIdx.x); break;
+      case 12: stage_plane<SIGN, 12, NT>(buf, ax.n, n_cur, s, Ls, M, tw, (int)threadIdx.x); break;
+      case 10: stage_plane<SIGN, 10, NT>(buf, ax.n, n_cur, s, Ls, M, tw, (int)threadIdx.x); break;
+      case 9: stage_plane<SIGN, 9, NT>(buf, ax.n, n_cur, s, Ls, M, tw, (int)threadIdx.x); break;
+      case 8: stage_plane<SIGN, 8, NT>(buf, ax.n, n_cur, s, Ls, M, tw, (int)threadIdx.x); break;
+      case 6: stage_plane<SIGN, 6, NT>(buf, ax.n, n_cur, s, Ls, M, tw, (int)threadIdx.x); break;
+      case 5: stage_plane<SIGN, 5, NT>(buf, ax.n, n_cur, s, Ls, M, tw, (int)threadIdx.x); break;
+      case 4: stage_plane<SIGN, 4, NT>(buf, ax.n, n_cur, s, Ls, M, tw, (int)threadIdx.x); break;
+      case 3: stage_plane<SIGN, 3, NT>(buf, ax.n, n_cur, s, Ls, M, tw, (int)threadIdx.x); break;
+      default: stage_plane<SIGN, 2, NT>(buf, ax.n, n_cur, s, Ls, M, tw, (int)threadIdx.x); break;
     }
     n_cur /= r;
     s *= r;
@@ -684,6 +685,201 @@ __global__ __launch_bounds__(TPBP) void plane_inv_kernel(const double2* __restri
   for (int c = threadIdx.x; c < n1 * n2; c += TPBP) {
     const int l = (int)(((float)c + 0.5f) * inv_n2), e = c - l * n2;
     dst[c] = ((const double*)(x + e * Lz + (l >> 1)))[l & 1];
+  }
+}
+
+// ---- pipelined plane passes: ONE resident workgroup per CU walks over planes, the NEXT plane's global loads in flight (in
+// registers) while the current plane goes through its stages in LDS.  A plane needs 115-117 KB of the CU's 160 KB, so a second
+// workgroup cannot overlap its loads with the first one's arithmetic; a plane pass is then load + stages + store in sequence
+// (26 us per 120^2 plane: about 12 us of memory time at the CU's share of the achievable bandwidth, the rest LDS round trips and
+// butterflies).  768 threads (12 waves, 170 VGPRs each) hold the prefetched plane (NPRE values per thread) next to the stage
+// registers without spilling - 1024 threads have 128 VGPRs and sit at 113-115 already.
+// Everything about the plane is a compile-time constant (N x N points, two stages of radix RA and RB on both axes), so every
+// per-thread array has exactly the size the plane needs.
+template <int SIGN, int NT, int N, int RA, int RB>
+__device__ inline void fft_plane_fixed(double2* buf, int Ls, int M, const double2* tw, const int tid) {
+  static_assert(RA * RB == N, "two stages");
+  constexpr int MMAX = N / 2 + 1;
+  stage_plane<SIGN, RA, NT, ((N / RA) * MMAX + NT - 1) / NT>(buf, N, N, 1, Ls, M, tw, tid);
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));
+  stage_plane<SIGN, RB, NT, ((N / RB) * MMAX + NT - 1) / NT>(buf, N, N / RA, RA, Ls, M, tw, tid2);
+}
+
+template <int NT, int N, int RA, int RB>
+__global__ __launch_bounds__(NT) void plane_fwd_pipe_kernel(const double* __restrict__ in, double2* __restrict__ out, Axis az, Axis ay,
+                                                            int Lz, int bufsz, int nplanes) {
+  extern __shared__ double2 lds[];
+  constexpr int n2 = N, n1 = N, n2h = N / 2 + 1, npair = (N + 1) / 2;
+  constexpr int NPRE = (N * N + NT - 1) / NT;
+  double2* x = lds;
+  double2* twz = lds + bufsz;
+  double2* twy = twz + n2;
+  for (int k = threadIdx.x; k < n2; k += NT) twz[k] = az.tw[k];
+  for (int k = threadIdx.x; k < n1; k += NT) twy[k] = ay.tw[k];
+  constexpr int nreal = n1 * n2;
+  const float inv_n2 = 1.0f / (float)n2, inv_nh = 1.0f / (float)n2h;
+  double pre[NPRE];
+  int pl = blockIdx.x;
+  if (pl < nplanes) {
+    const double* src = in + (int64_t)pl * nreal;
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = threadIdx.x + u * NT;
+      pre[u] = c < nreal ? src[c] : 0.0;
+    }
+  }
+  for (; pl < nplanes; pl += gridDim.x) {
+    // an opaque copy of the thread index per round: index arithmetic that depends on it cannot be hoisted out of the plane loop
+    // (hoisted, its per-element offsets were what the compiler spilled)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    if (n1 & 1)                                           // the last line has no partner: its imaginary slot is zero
+      for (int e = tid; e < n2; e += NT) x[e * Lz + npair - 1].y = 0.0;
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = tid + u * NT;
+      if (c < nreal) {
+        const int l = (int)(((float)c + 0.5f) * inv_n2), e = c - l * n2;
+        ((double*)(x + e * Lz + (l >> 1)))[l & 1] = pre[u];
+      }
+    }
+    __syncthreads();
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // fresh opaque copy: this phase's index arithmetic stays in this phase
+    const int nxt = pl + (int)gridDim.x;
+    if (nxt < nplanes) {                                  // requested now, consumed at the top of the next round
+      const double* src = in + (int64_t)nxt * nreal;
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        const int c = tid + u * NT;
+        pre[u] = c < nreal ? src[c] : 0.0;
+      }
+    }
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // fresh opaque copy: this phase's index arithmetic stays in this phase
+    fft_plane_fixed<-1, NT, N, RA, RB>(x, Lz, npair, twz, tid);
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // fresh opaque copy: this phase's index arithmetic stays in this phase
+    constexpr int KS = (n1 * n2h + NT - 1) / NT;
+    double2 r[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const int c = tid + u * NT;
+      if (c < n1 * n2h) {
+        const int l = (int)(((float)c + 0.5f) * inv_nh), k = c - l * n2h;
+        const int m = l >> 1;
+        const double2 zk = x[k * Lz + m];
+        const double2 zn = x[(k == 0 ? 0 : n2 - k) * Lz + m];
+        if ((l & 1) == 0) r[u] = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
+        else r[u] = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const int c = tid + u * NT;
+      if (c < n1 * n2h) x[c] = r[u];
+    }
+    __syncthreads();
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // fresh opaque copy: this phase's index arithmetic stays in this phase
+    fft_plane_fixed<-1, NT, N, RA, RB>(x, n2h, n2h, twy, tid);
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // fresh opaque copy: this phase's index arithmetic stays in this phase
+    double2* dst = out + (int64_t)pl * n1 * n2h;
+    for (int c = tid; c < n1 * n2h; c += NT) dst[c] = x[c];
+    __syncthreads();                                      // the next round overwrites the buffer
+  }
+}
+
+template <int NT, int N, int RA, int RB>
+__global__ __launch_bounds__(NT) void plane_inv_pipe_kernel(const double2* __restrict__ in, double* __restrict__ out, Axis az, Axis ay,
+                                                            int Lz, int bufsz, int nplanes) {
+  extern __shared__ double2 lds[];
+  constexpr int n2 = N, n1 = N, n2h = N / 2 + 1, npair = (N + 1) / 2;
+  constexpr int NPRE = (N * (N / 2 + 1) + NT - 1) / NT;
+  double2* x = lds;
+  double2* twz = lds + bufsz;
+  double2* twy = twz + n2;
+  for (int k = threadIdx.x; k < n2; k += NT) twz[k] = az.tw[k];
+  for (int k = threadIdx.x; k < n1; k += NT) twy[k] = ay.tw[k];
+  constexpr int ncplx = n1 * n2h;
+  const float inv_nh = 1.0f / (float)n2h, inv_n2 = 1.0f / (float)n2;
+  double2 pre[NPRE];
+  int pl = blockIdx.x;
+  if (pl < nplanes) {
+    const double2* src = in + (int64_t)pl * ncplx;
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = threadIdx.x + u * NT;
+      pre[u] = c < ncplx ? src[c] : make_double2(0.0, 0.0);
+    }
+  }
+  for (; pl < nplanes; pl += gridDim.x) {
+    // an opaque copy of the thread index per round: index arithmetic that depends on it cannot be hoisted out of the plane loop
+    // (hoisted, its per-element offsets were what the compiler spilled)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = tid + u * NT;
+      if (c < ncplx) x[c] = pre[u];
+    }
+    __syncthreads();
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // fresh opaque copy: this phase's index arithmetic stays in this phase
+    const int nxt = pl + (int)gridDim.x;
+    if (nxt < nplanes) {
+      const double2* src = in + (int64_t)nxt * ncplx;
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        const int c = tid + u * NT;
+        pre[u] = c < ncplx ? src[c] : make_double2(0.0, 0.0);
+      }
+    }
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // fresh opaque copy: this phase's index arithmetic stays in this phase
+    fft_plane_fixed<1, NT, N, RA, RB>(x, n2h, n2h, twy, tid);
+    // pairs of lines back into one complex line each: Z_k = A_k + i B_k, Z_{n-k} = conj(A_k) + i conj(B_k)
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // fresh opaque copy: this phase's index arithmetic stays in this phase
+    constexpr int KS = (npair * n2h + NT - 1) / NT;
+    double2 za[KS], zb[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const int c = tid + u * NT;
+      if (c < npair * n2h) {
+        const int m = (int)(((float)c + 0.5f) * inv_nh), k = c - m * n2h;
+        double2 a = x[(2 * m) * n2h + k];
+        double2 b = (2 * m + 1 < n1) ? x[(2 * m + 1) * n2h + k] : make_double2(0.0, 0.0);
+        if (k == 0 || 2 * k == n2) { a.y = 0.0; b.y = 0.0; }
+        za[u] = make_double2(a.x - b.y, a.y + b.x);
+        zb[u] = make_double2(a.x + b.y, -a.y + b.x);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const int c = tid + u * NT;
+      if (c < npair * n2h) {
+        const int m = (int)(((float)c + 0.5f) * inv_nh), k = c - m * n2h;
+        x[k * Lz + m] = za[u];
+        if (!(k == 0 || 2 * k == n2)) x[(n2 - k) * Lz + m] = zb[u];
+      }
+    }
+    __syncthreads();
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // fresh opaque copy: this phase's index arithmetic stays in this phase
+    fft_plane_fixed<1, NT, N, RA, RB>(x, Lz, npair, twz, tid);
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // fresh opaque copy: this phase's index arithmetic stays in this phase
+    double* dst = out + (int64_t)pl * n1 * n2;
+    for (int c = tid; c < n1 * n2; c += NT) {
+      const int l = (int)(((float)c + 0.5f) * inv_n2), e = c - l * n2;
+      dst[c] = ((const double*)(x + e * Lz + (l >> 1)))[l & 1];
+    }
+    __syncthreads();
   }
 }
 
@@ -923,6 +1119,20 @@ int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, cons
     // (set on every call: the attribute is per device, a process-wide flag would skip a second device)
     HIP_TRY(h, hipFuncSetAttribute((const void*)plane_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute((const void*)plane_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define ISDF_PIPE_ATTR(NN, RA, RB)                                                                                              \
+  HIP_TRY(h, hipFuncSetAttribute((const void*)plane_fwd_pipe_kernel<PIPE_NT, NN, RA, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+  HIP_TRY(h, hipFuncSetAttribute((const void*)plane_inv_pipe_kernel<PIPE_NT, NN, RA, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (n1 == n2) switch (n1) {
+        case 64: ISDF_PIPE_ATTR(64, 8, 8) break;
+        case 72: ISDF_PIPE_ATTR(72, 9, 8) break;
+        case 80: ISDF_PIPE_ATTR(80, 10, 8) break;
+        case 96: ISDF_PIPE_ATTR(96, 12, 8) break;
+        case 100: ISDF_PIPE_ATTR(100, 10, 10) break;
+        case 108: ISDF_PIPE_ATTR(108, 12, 9) break;
+        case 120: ISDF_PIPE_ATTR(120, 12, 10) break;
+        default: break;
+      }
+#undef ISDF_PIPE_ATTR
     const size_t ldsx = sizeof(double2) * ((size_t)n0 * FX + n0);
     const int ntx = (int)cdiv((int64_t)n1 * n2h, FX);
     hipStream_t st = h->stream;
@@ -935,11 +1145,35 @@ int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, cons
       const int nr = std::min(sub, nb - r0);
       const dim3 gp((unsigned)((int64_t)nr * n0)), gx((unsigned)((int64_t)nr * ntx));
       double2* zb = zbuf + (int64_t)r0 * gc;
-      plane_fwd_kernel<<<gp, dim3(TPBP), plane_lds, st>>>(d_in + (int64_t)r0 * G, zb, ax[2], ax[1], Lz, bufsz);
+      const int nplanes = (int)((int64_t)nr * n0);
+      const dim3 gpipe((unsigned)std::min<int64_t>(nplanes, h->num_cu));
+      const double* src = d_in + (int64_t)r0 * G;
+      double* dst = d_out + (int64_t)r0 * G;
+      bool piped = false;
+      // the pipelined passes exist for square planes of the sizes below (radices = what factorise() picks for them)
+#define ISDF_PIPE_CASE(NN, RA, RB, FWD)                                                                                        \
+  case NN:                                                                                                                      \
+    if (ax[1].nstage == 2 && ax[1].radix[0] == RA && ax[1].radix[1] == RB) {                                                    \
+      if (FWD) plane_fwd_pipe_kernel<PIPE_NT, NN, RA, RB><<<gpipe, dim3(PIPE_NT), plane_lds, st>>>(src, zb, ax[2], ax[1], Lz, bufsz, nplanes); \
+      else plane_inv_pipe_kernel<PIPE_NT, NN, RA, RB><<<gpipe, dim3(PIPE_NT), plane_lds, st>>>(zb, dst, ax[2], ax[1], Lz, bufsz, nplanes);     \
+      piped = true;                                                                                                             \
+    }                                                                                                                           \
+    break;
+#define ISDF_PIPE_SWITCH(FWD)                                                                                                  \
+  if (h->conv_pipe != 0 && n1 == n2) switch (n1) {                                                                              \
+      ISDF_PIPE_CASE(64, 8, 8, FWD) ISDF_PIPE_CASE(72, 9, 8, FWD) ISDF_PIPE_CASE(80, 10, 8, FWD) ISDF_PIPE_CASE(96, 12, 8, FWD)  \
+      ISDF_PIPE_CASE(100, 10, 10, FWD) ISDF_PIPE_CASE(108, 12, 9, FWD) ISDF_PIPE_CASE(120, 12, 10, FWD) default: break;          \
+    }
+      ISDF_PIPE_SWITCH(true)
+      if (!piped) plane_fwd_kernel<<<gp, dim3(TPBP), plane_lds, st>>>(src, zb, ax[2], ax[1], Lz, bufsz);
       with_lines(FX, [&](auto z) {
         strided_fft_fast_kernel<2, decltype(z)::value><<<gx, dim3(TPB), ldsx, st>>>(zb, gc, (int64_t)n1 * n2h, n1 * n2h, ax[0], ntx, cg);
       });
-      plane_inv_kernel<<<gp, dim3(TPBP), plane_lds, st>>>(zb, d_out + (int64_t)r0 * G, ax[2], ax[1], Lz, bufsz);
+      piped = false;
+      ISDF_PIPE_SWITCH(false)
+      if (!piped) plane_inv_kernel<<<gp, dim3(TPBP), plane_lds, st>>>(zb, dst, ax[2], ax[1], Lz, bufsz);
+#undef ISDF_PIPE_SWITCH
+#undef ISDF_PIPE_CASE
     }
     KERNEL_CHECK(h);
     return ISDF_OK;
