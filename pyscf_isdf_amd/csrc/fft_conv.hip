@@ -281,11 +281,54 @@ __device__ inline void butterfly_r(const double2* a, double2* b) {
   }
 }
 
+// exp(-2 pi i k / R) for the composite radices, as literals: the constant twiddles inside a composite butterfly then cost no
+// LDS read (they were 6 of the 29 reads of a radix-12 butterfly) and the trivial ones (1, -i, ...) fold away.  k is a compile-time
+// constant wherever this is called (fully unrolled loops).
+template <int SIGN, int R>
+__device__ inline double2 const_twid(int k) {
+  if constexpr (R == 6) {
+    constexpr double c[6] = {1.0, 0.5000000000000001, -0.4999999999999998, -1.0, -0.5000000000000004, 0.5000000000000001};
+    constexpr double sn[6] = {-0.0, -0.8660254037844386, -0.8660254037844387, -1.2246467991473532e-16, 0.8660254037844384, 0.8660254037844386};
+    return make_double2(c[k], SIGN > 0 ? -sn[k] : sn[k]);
+  }
+  else if constexpr (R == 8) {
+    constexpr double c[8] = {1.0, 0.7071067811865476, 6.123233995736766e-17, -0.7071067811865475, -1.0, -0.7071067811865477, -1.8369701987210297e-16, 0.7071067811865474};
+    constexpr double sn[8] = {-0.0, -0.7071067811865475, -1.0, -0.7071067811865476, -1.2246467991473532e-16, 0.7071067811865475, 1.0, 0.7071067811865477};
+    return make_double2(c[k], SIGN > 0 ? -sn[k] : sn[k]);
+  }
+  else if constexpr (R == 9) {
+    constexpr double c[9] = {1.0, 0.766044443118978, 0.17364817766693041, -0.4999999999999998, -0.9396926207859083, -0.9396926207859084, -0.5000000000000004, 0.17364817766692997, 0.7660444431189778};
+    constexpr double sn[9] = {-0.0, -0.6427876096865393, -0.984807753012208, -0.8660254037844387, -0.3420201433256689, 0.34202014332566866, 0.8660254037844384, 0.9848077530122081, 0.6427876096865396};
+    return make_double2(c[k], SIGN > 0 ? -sn[k] : sn[k]);
+  }
+  else if constexpr (R == 10) {
+    constexpr double c[10] = {1.0, 0.8090169943749475, 0.30901699437494745, -0.30901699437494734, -0.8090169943749473, -1.0, -0.8090169943749476, -0.30901699437494756, 0.30901699437494723, 0.8090169943749473};
+    constexpr double sn[10] = {-0.0, -0.5877852522924731, -0.9510565162951535, -0.9510565162951536, -0.5877852522924732, -1.2246467991473532e-16, 0.587785252292473, 0.9510565162951535, 0.9510565162951536, 0.5877852522924734};
+    return make_double2(c[k], SIGN > 0 ? -sn[k] : sn[k]);
+  }
+  else if constexpr (R == 12) {
+    constexpr double c[12] = {1.0, 0.8660254037844387, 0.5000000000000001, 6.123233995736766e-17, -0.4999999999999998, -0.8660254037844387, -1.0, -0.8660254037844388, -0.5000000000000004, -1.8369701987210297e-16, 0.5000000000000001, 0.8660254037844384};
+    constexpr double sn[12] = {-0.0, -0.49999999999999994, -0.8660254037844386, -1.0, -0.8660254037844387, -0.49999999999999994, -1.2246467991473532e-16, 0.4999999999999997, 0.8660254037844384, 1.0, 0.8660254037844386, 0.5000000000000004};
+    return make_double2(c[k], SIGN > 0 ? -sn[k] : sn[k]);
+  }
+  else if constexpr (R == 15) {
+    constexpr double c[15] = {1.0, 0.9135454576426009, 0.6691306063588582, 0.30901699437494745, -0.10452846326765333, -0.4999999999999998, -0.8090169943749473, -0.9781476007338057, -0.9781476007338057, -0.8090169943749476, -0.5000000000000004, -0.10452846326765423, 0.30901699437494723, 0.6691306063588585, 0.913545457642601};
+    constexpr double sn[15] = {-0.0, -0.40673664307580015, -0.7431448254773941, -0.9510565162951535, -0.9945218953682734, -0.8660254037844387, -0.5877852522924732, -0.20791169081775931, 0.20791169081775907, 0.587785252292473, 0.8660254037844384, 0.9945218953682733, 0.9510565162951536, 0.743144825477394, 0.40673664307580015};
+    return make_double2(c[k], SIGN > 0 ? -sn[k] : sn[k]);
+  }
+  else if constexpr (R == 16) {
+    constexpr double c[16] = {1.0, 0.9238795325112867, 0.7071067811865476, 0.38268343236508984, 6.123233995736766e-17, -0.3826834323650897, -0.7071067811865475, -0.9238795325112867, -1.0, -0.9238795325112868, -0.7071067811865477, -0.38268343236509034, -1.8369701987210297e-16, 0.38268343236509, 0.7071067811865474, 0.9238795325112865};
+    constexpr double sn[16] = {-0.0, -0.3826834323650898, -0.7071067811865475, -0.9238795325112867, -1.0, -0.9238795325112867, -0.7071067811865476, -0.3826834323650899, -1.2246467991473532e-16, 0.38268343236508967, 0.7071067811865475, 0.9238795325112865, 1.0, 0.9238795325112866, 0.7071067811865477, 0.3826834323650904};
+    return make_double2(c[k], SIGN > 0 ? -sn[k] : sn[k]);
+  }
+  else return make_double2(1.0, 0.0);
+}
+
 // Composite radices in registers: R = R1 R2 point DFT as R2 DFTs of length R1 (inputs R2 apart), the constant twiddles
 // W_R^(n2 k1) = tw[n2 k1 N / R] (R divides N, so the axis table holds them), then R1 DFTs of length R2; output index k1 + R1 k2.
 // A 120-point line is then two stages (15 x 8) instead of four (4 x 2 x 3 x 5): half the LDS round trips and barriers, which is
 // what bounds these passes.
-template <int SIGN, int R1, int R2>
+template <int SIGN, int R1, int R2, bool CT>
 __device__ inline void butterfly_comp(const double2* a, double2* b, const double2* __restrict__ tw, int N) {
   constexpr int R = R1 * R2;
   double2 t[R2][R1];
@@ -296,11 +339,14 @@ __device__ inline void butterfly_comp(const double2* a, double2* b, const double
     for (int n1 = 0; n1 < R1; ++n1) u[n1] = a[R2 * n1 + n2];
     butterfly_r<SIGN, R1>(u, t[n2]);
   }
+  // CT: literals (no LDS read; needs a few more registers for the constants - the 1024-thread plane kernels, at 113-115 of their
+  // 128 VGPRs, keep the table)
   const int step = N / R;
 #pragma unroll
   for (int n2 = 1; n2 < R2; ++n2)
 #pragma unroll
-    for (int k1 = 1; k1 < R1; ++k1) t[n2][k1] = cmul(t[n2][k1], twid<SIGN>(tw, n2 * k1 * step));
+    for (int k1 = 1; k1 < R1; ++k1)
+      t[n2][k1] = cmul(t[n2][k1], CT ? const_twid<SIGN, R>(n2 * k1) : twid<SIGN>(tw, n2 * k1 * step));
 #pragma unroll
   for (int k1 = 0; k1 < R1; ++k1) {
     double2 v[R2], w[R2];
@@ -312,16 +358,16 @@ __device__ inline void butterfly_comp(const double2* a, double2* b, const double
   }
 }
 
-template <int SIGN, int R>
+template <int SIGN, int R, bool CT = true>
 __device__ inline void butterfly_any(const double2* a, double2* b, const double2* __restrict__ tw, int N) {
   if (R <= 5) butterfly_r<SIGN, (R <= 5 ? R : 2)>(a, b);
-  else if (R == 6) butterfly_comp<SIGN, 3, 2>(a, b, tw, N);
-  else if (R == 8) butterfly_comp<SIGN, 4, 2>(a, b, tw, N);
-  else if (R == 9) butterfly_comp<SIGN, 3, 3>(a, b, tw, N);
-  else if (R == 10) butterfly_comp<SIGN, 5, 2>(a, b, tw, N);
-  else if (R == 12) butterfly_comp<SIGN, 4, 3>(a, b, tw, N);
-  else if (R == 15) butterfly_comp<SIGN, 5, 3>(a, b, tw, N);
-  else butterfly_comp<SIGN, 4, 4>(a, b, tw, N);        // 16
+  else if (R == 6) butterfly_comp<SIGN, 3, 2, CT>(a, b, tw, N);
+  else if (R == 8) butterfly_comp<SIGN, 4, 2, CT>(a, b, tw, N);
+  else if (R == 9) butterfly_comp<SIGN, 3, 3, CT>(a, b, tw, N);
+  else if (R == 10) butterfly_comp<SIGN, 5, 2, CT>(a, b, tw, N);
+  else if (R == 12) butterfly_comp<SIGN, 4, 3, CT>(a, b, tw, N);
+  else if (R == 15) butterfly_comp<SIGN, 5, 3, CT>(a, b, tw, N);
+  else butterfly_comp<SIGN, 4, 4, CT>(a, b, tw, N);        // 16
 }
 
 template <int SIGN, int R, int ZCT>
@@ -344,13 +390,15 @@ __device__ inline void stage_inplace(double2* __restrict__ buf, int N, int n_cur
 #pragma unroll
       for (int k = 0; k < R; ++k) a[k] = xi[k * sin_];
       butterfly_any<SIGN, R>(a, out[u], tw, N);
-      const int tstep = p * s;           // < N
-      int t = tstep;
+      if (mm > 1) {                      // (the last stage has p = 0: every output twiddle is 1)
+        const int tstep = p * s;         // < N
+        int t = tstep;
 #pragma unroll
-      for (int j = 1; j < R; ++j) {
-        out[u][j] = cmul(out[u][j], twid<SIGN>(tw, t));
-        t += tstep;
-        if (t >= N) t -= N;
+        for (int j = 1; j < R; ++j) {
+          out[u][j] = cmul(out[u][j], twid<SIGN>(tw, t));
+          t += tstep;
+          if (t >= N) t -= N;
+        }
       }
     }
   }
@@ -542,14 +590,16 @@ __device__ inline void stage_plane(double2* __restrict__ buf, int N, int n_cur, 
       double2 a[R];
 #pragma unroll
       for (int k = 0; k < R; ++k) a[k] = xi[k * sin_];
-      butterfly_any<SIGN, R>(a, out[u], tw, N);
-      const int tstep = p * s;
-      int t = tstep;
+      butterfly_any<SIGN, R, (KM > 0)>(a, out[u], tw, N);
+      if (KM == 0 || mm > 1) {           // (the last stage has p = 0: every output twiddle is 1; skipped in the sized kernels)
+        const int tstep = p * s;
+        int t = tstep;
 #pragma unroll
-      for (int j = 1; j < R; ++j) {
-        out[u][j] = cmul(out[u][j], twid<SIGN>(tw, t));
-        t += tstep;
-        if (t >= N) t -= N;
+        for (int j = 1; j < R; ++j) {
+          out[u][j] = cmul(out[u][j], twid<SIGN>(tw, t));
+          t += tstep;
+          if (t >= N) t -= N;
+        }
       }
     }
   }
@@ -696,10 +746,9 @@ __global__ __launch_bounds__(TPBP) void plane_inv_kernel(const double2* __restri
 // registers without spilling - 1024 threads have 128 VGPRs and sit at 113-115 already.
 // Everything about the plane is a compile-time constant (N x N points, two stages of radix RA and RB on both axes), so every
 // per-thread array has exactly the size the plane needs.
-template <int SIGN, int NT, int N, int RA, int RB>
+template <int SIGN, int NT, int N, int RA, int RB, int MMAX = N / 2 + 1>
 __device__ inline void fft_plane_fixed(double2* buf, int Ls, int M, const double2* tw, const int tid) {
   static_assert(RA * RB == N, "two stages");
-  constexpr int MMAX = N / 2 + 1;
   stage_plane<SIGN, RA, NT, ((N / RA) * MMAX + NT - 1) / NT>(buf, N, N, 1, Ls, M, tw, tid);
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));
@@ -929,7 +978,8 @@ __global__ __launch_bounds__(TPBP) void plane_c2c_inv_kernel(const double2* __re
 #pragma unroll
   for (int u = 0; u < KS; ++u) {
     const int c = threadIdx.x + u * TPBP;
-    if (c < n1 * n2) r[u] = x[c];
+    const double2 v = x[c < n1 * n2 ? c : 0];
+    r[u] = make_double2(v.x, v.y);                      // (component-wise: the struct copy kept the whole array in scratch)
   }
   __syncthreads();
 #pragma unroll
@@ -947,6 +997,88 @@ __global__ __launch_bounds__(TPBP) void plane_c2c_inv_kernel(const double2* __re
     const double2 v = x[z * Lz + y];
     out_re[off + c] = v.x;
     out_im[off + c] = v.y;
+  }
+}
+
+// the same pass as a persistent workgroup with the next plane's loads in flight (see plane_fwd_pipe_kernel)
+template <int NT, int N, int RA, int RB>
+__global__ __launch_bounds__(NT) void plane_c2c_inv_pipe_kernel(const double2* __restrict__ in, double* __restrict__ out_re,
+                                                                double* __restrict__ out_im, Axis az, Axis ay, int Lz, int bufsz,
+                                                                int nplanes) {
+  extern __shared__ double2 lds[];
+  constexpr int n2 = N, n1 = N, nent = N * N;
+  constexpr int NPRE = (nent + NT - 1) / NT;
+  double2* x = lds;
+  double2* twz = lds + bufsz;
+  double2* twy = twz + n2;
+  for (int k = threadIdx.x; k < n2; k += NT) twz[k] = az.tw[k];
+  for (int k = threadIdx.x; k < n1; k += NT) twy[k] = ay.tw[k];
+  const float inv_n2 = 1.0f / (float)n2;
+  double2 pre[NPRE];
+  int pl = blockIdx.x;
+  if (pl < nplanes) {
+    const double2* src = in + (int64_t)pl * nent;
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = threadIdx.x + u * NT;
+      pre[u] = c < nent ? src[c] : make_double2(0.0, 0.0);
+    }
+  }
+  for (; pl < nplanes; pl += gridDim.x) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = tid + u * NT;
+      if (c < nent) x[c] = pre[u];                                               // P[y][z], pitch n2
+    }
+    __syncthreads();
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int nxt = pl + (int)gridDim.x;
+    if (nxt < nplanes) {
+      const double2* src = in + (int64_t)nxt * nent;
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        const int c = tid + u * NT;
+        pre[u] = c < nent ? src[c] : make_double2(0.0, 0.0);
+      }
+    }
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    fft_plane_fixed<1, NT, N, RA, RB, N>(x, n2, n2, twy, tid);                    // along y: element y, line z
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    double2 r[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = tid + u * NT;
+      const double2 v = x[c < nent ? c : 0];
+      r[u] = make_double2(v.x, v.y);                    // (component-wise: the struct copy kept the whole array in scratch)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = tid + u * NT;
+      if (c < nent) {
+        const int y = (int)(((float)c + 0.5f) * inv_n2), z = c - y * n2;
+        x[z * Lz + y] = r[u];
+      }
+    }
+    __syncthreads();
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    fft_plane_fixed<1, NT, N, RA, RB, N>(x, Lz, n1, twz, tid);                    // along z: element z, line y
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int64_t off = (int64_t)pl * nent;
+    for (int c = tid; c < nent; c += NT) {
+      const int y = (int)(((float)c + 0.5f) * inv_n2), z = c - y * n2;
+      const double2 v = x[z * Lz + y];
+      out_re[off + c] = v.x;
+      out_im[off + c] = v.y;
+    }
+    __syncthreads();
   }
 }
 
@@ -1284,7 +1416,33 @@ int conv_rows_q_own(isdf_handle h, const double* d_in, double* d_re, double* d_i
   hipStream_t st = h->stream;
   const size_t ldsx = sizeof(double2) * ((size_t)n0 * FX + n0);
   const dim3 gp((unsigned)((int64_t)nb * n0));
-  plane_fwd_kernel<<<gp, dim3(TPBP), lds_r, st>>>(d_in, zhalf, ax[2], ax[1], Lz, bufsz);
+  const int nplanes = (int)((int64_t)nb * n0);
+  const dim3 gpipe((unsigned)std::min<int64_t>(nplanes, h->num_cu));
+  int piped = 0;          // 1: forward plane pass piped, 2: inverse too
+#define ISDF_PIPEQ_CASE(NN, RA, RB)                                                                                                \
+  case NN:                                                                                                                          \
+    if (ax[1].nstage == 2 && ax[1].radix[0] == RA && ax[1].radix[1] == RB) {                                                        \
+      HIP_TRY(h, hipFuncSetAttribute((const void*)plane_fwd_pipe_kernel<PIPE_NT, NN, RA, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      HIP_TRY(h, hipFuncSetAttribute((const void*)plane_c2c_inv_pipe_kernel<PIPE_NT, NN, RA, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      if (!inverse) plane_fwd_pipe_kernel<PIPE_NT, NN, RA, RB><<<gpipe, dim3(PIPE_NT), lds_r, st>>>(d_in, zhalf, ax[2], ax[1], Lz, bufsz, nplanes); \
+      else plane_c2c_inv_pipe_kernel<PIPE_NT, NN, RA, RB><<<gpipe, dim3(PIPE_NT), lds_c, st>>>(zfull, d_re, d_im, ax[2], ax[1], Lc, bufc, nplanes); \
+      piped = 1;                                                                                                                    \
+    }                                                                                                                               \
+    break;
+  auto plane_pass = [&](bool inverse) -> int {
+    piped = 0;
+    if (h->conv_pipe != 0 && n1 == n2) switch (n1) {
+        ISDF_PIPEQ_CASE(64, 8, 8) ISDF_PIPEQ_CASE(72, 9, 8) ISDF_PIPEQ_CASE(80, 10, 8) ISDF_PIPEQ_CASE(96, 12, 8)
+        default: break;                 // (100^2: the complex plane's prefetch does not fit the registers)
+      }
+    if (!piped) {
+      if (!inverse) plane_fwd_kernel<<<gp, dim3(TPBP), lds_r, st>>>(d_in, zhalf, ax[2], ax[1], Lz, bufsz);
+      else plane_c2c_inv_kernel<<<gp, dim3(TPBP), lds_c, st>>>(zfull, d_re, d_im, ax[2], ax[1], Lc, bufc);
+    }
+    return ISDF_OK;
+  };
+#undef ISDF_PIPEQ_CASE
+  { int rc = plane_pass(false); if (rc != ISDF_OK) return rc; }
   const int ntx = (int)cdiv((int64_t)n1 * n2h, FX), ntf = (int)cdiv((int64_t)n1 * n2, FX);
   with_lines(FX, [&](auto z) {
     strided_fft_fast_kernel<0, decltype(z)::value><<<dim3((unsigned)((int64_t)nb * ntx)), dim3(TPB), ldsx, st>>>(
@@ -1295,7 +1453,7 @@ int conv_rows_q_own(isdf_handle h, const double* d_in, double* d_re, double* d_i
     strided_fft_fast_kernel<1, decltype(z)::value><<<dim3((unsigned)((int64_t)nb * ntf)), dim3(TPB), ldsx, st>>>(
         zfull, G, (int64_t)n1 * n2, n1 * n2, ax[0], ntf, (const double*)nullptr);
   });
-  plane_c2c_inv_kernel<<<gp, dim3(TPBP), lds_c, st>>>(zfull, d_re, d_im, ax[2], ax[1], Lc, bufc);
+  { int rc = plane_pass(true); if (rc != ISDF_OK) return rc; }
   KERNEL_CHECK(h);
   return ISDF_OK;
 }
