@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument('--c-isdf', type=int, default=None,
                     help='interpolation points per AO; default: 12 for the headline workload (the accuracy scan of DESIGN.md section 2), else 10')
     ap.add_argument('--fit-route', default=None, choices=['auto', 'cholesky', 'blockjacobi'])
+    ap.add_argument('--w-form', default='spectral', choices=['spectral', 'classic'],
+                    help="spectral (default): W = X X^T from the half spectra inside the sphere; classic: w conv(rows) rows^T")
     ap.add_argument('--robust-k', action='store_true', help='time the build + get_jk with the robust exchange (not the headline)')
     ap.add_argument('--density', default='random', choices=['random', 'scf'],
                     help="'random': BASELINE.json's benchmark density (random orthogonal orbitals; the headline); 'scf': physical "
@@ -295,6 +297,7 @@ def main():
         df.fit_route = args.fit_route
     if args.robust_k:
         df.robust_k = True
+    df.w_spectral = args.w_form == 'spectral'
     be = df.backend
 
     def barrier():
@@ -453,6 +456,9 @@ def main():
         out['config']['refine_over'] = args.refine_over if args.select == 'refined' else None
         out['config']['cand_ao_cutoff'] = args.cand_ao_cutoff if args.select == 'refined' else None
         out['config']['fit_row_panels'] = int(getattr(df, 'n_panels', 1))
+        frac = getattr(df, 'w_spectral_fraction', None)
+        out['config']['w_form'] = ('spectral: X X^T over %.3f G half-spectrum terms (sphere inscribed in the reciprocal FFT box)' % frac) if frac else 'classic: w conv(rows) rows^T over G grid points'
+        out['config']['w_spectral_fraction'] = frac
         # accuracy of the timed configuration against the reference's exact exchange (fft_jk.py:177-302 on the GPU,
         # isdf_get_k_exact; outside the timed region).  J is the reference's own formula (fft_jk.py:33-109): no fit error.
         out['config']['dE_K_vs_exact'] = None

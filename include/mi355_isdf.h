@@ -324,6 +324,20 @@ int isdf_W_from_factor(isdf_handle h, const double* d_F, int P, int kind, double
 int isdf_coulomb_W(isdf_handle h, const double* d_theta, int P, int64_t ldt,
                    const int32_t mesh[3], const double a[9],
                    int row0, int nrows, int batch, int upper_only, double* d_W, int64_t ldw);
+/* Spectral form of W.  By Parseval  w sum_r Theta_P(r) conv(Theta_Q)(r) = (w / G) sum_G coulG(G)
+ * fft(Theta_P)(G) conj(fft(Theta_Q)(G)); the sum over the half spectrum with multiplicities (1 on the kz = 0 and Nyquist planes,
+ * 2 between) is X X^T for the packed real rows X[r][2j], X[r][2j+1] = scale_j (Re, Im) fft(rows[r])[idx_j].  Restricted to the
+ * points inside a sphere of the reciprocal FFT box the sum loses what the kernel table's corners carry (1e-9 Eh in E_K at BASELINE
+ * configs[2], profiles/r03_sphere_check.log) and about half of its terms.
+ *   isdf_coulG_half:         d_out (n0 n1 (n2/2+1)) = the symmetrised half-spectrum table the Gamma-point convolution multiplies with
+ *                            (1/G inside; honours omega / cutoff / Wigner-Seitz state and the option "coul_sphere")
+ *   isdf_spectral_supported: *ok = 1 when isdf_spectral_rows covers this mesh (2-3-5 smooth, (y, z) plane fits LDS)
+ *   isdf_spectral_rows:      d_out (nrows, ldx; ldx even, >= 2 npts; padding zeroed) from nrows real rows (ld == G): forward
+ *                            plane pass + forward x pass of the own FFT, then the gather; batch rows per pass */
+int isdf_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9], double* d_out);
+int isdf_spectral_supported(isdf_handle h, const int32_t mesh[3], int batch, int* ok);
+int isdf_spectral_rows(isdf_handle h, const double* d_in, int nrows, int64_t ld, const int32_t mesh[3], const int32_t* d_idx,
+                       const double* d_scale, int npts, int batch, double* d_out, int64_t ldx);
 /* S4 alone: d_out rows = ifft(coulG * fft(d_in rows)).real (no weight), rows of length G contiguous
  * (ld == ldo == G); in place allowed.  Used by the grid-sharded multi-GPU path, where the rows are
  * assembled by an all-to-all before and scattered by another one after this call. */

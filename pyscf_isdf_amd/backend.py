@@ -393,6 +393,30 @@ class HipBackend:
         self.handle.call('isdf_coulomb_rows', self._p(rows), rows.shape[0], rows.stride(0), _np_ptr(mesh), _np_ptr(a),
                          int(batch), self._p(out), out.stride(0))
 
+    # ---- spectral form of W: W = X X^T with X the scaled half spectra of the fit rows inside a sphere ----
+    def spectral_supported(self, mesh, batch=512):
+        ok = ctypes.c_int(0)
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        self.handle.call('isdf_spectral_supported', _np_ptr(mesh), int(batch), ctypes.byref(ok))
+        return bool(ok.value)
+
+    def coulG_half(self, mesh, a):
+        """Host copy (n0, n1, n2/2+1) of the symmetrised half-spectrum kernel table of the Gamma-point convolution (1/G inside)."""
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out = self.empty((int(mesh[0]) * int(mesh[1]) * (int(mesh[2]) // 2 + 1),))
+        self.handle.call('isdf_coulG_half', _np_ptr(mesh), _np_ptr(a), self._p(out))
+        return self.to_host(out).reshape(int(mesh[0]), int(mesh[1]), int(mesh[2]) // 2 + 1)
+
+    def spectral_rows(self, rows, mesh, idx, scale, out, batch=512):
+        """out (n, ldx) <- scale_j (Re, Im) fft(rows)[idx_j] packed as consecutive pairs; rows (n, G) contiguous, idx int32."""
+        self._stream()
+        mesh = np.ascontiguousarray(mesh, dtype=np.int32)
+        assert rows.is_contiguous() and out.stride(1) == 1 and idx.dtype == torch.int32 and out.stride(0) % 2 == 0
+        self.handle.call('isdf_spectral_rows', self._p(rows), rows.shape[0], rows.stride(0), _np_ptr(mesh), self._p(idx),
+                         self._p(scale), int(idx.numel()), int(batch), self._p(out), out.stride(0))
+
     def symmetrize_upper(self, W):
         self._stream()
         self.handle.call('isdf_symmetrize_upper', self._p(W), W.shape[0], W.stride(0))

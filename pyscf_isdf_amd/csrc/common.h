@@ -68,6 +68,7 @@ struct isdf_ctx {
   double coul_omega = 0.0;
   // spherical truncation radius of the Coulomb kernel (exxdiv='vcut_sph', pbc.py:312-317); 0 = none.  isdf_set_coulomb_cutoff
   double coul_rc = 0.0;
+  int coul_sphere = 0;       // > 0: the Gamma-point kernel table keeps |G| <= coul_sphere percent of the inscribed sphere's radius
   WsKernel wsk;
 };
 
@@ -82,6 +83,9 @@ bool conv_rows_own_supported(const int32_t mesh[3], int nb);
 // k-point form (fft_conv.hip): d_re + i d_im rows = ifft(tab * fft(d_in rows)) with a full real table; zhalf nb * n0 n1 (n2/2+1),
 // zfull nb * G complex scratch
 bool conv_rows_q_own_supported(isdf_handle h, const int32_t mesh[3], int nb);
+bool spectral_rows_own_supported(isdf_handle h, const int32_t mesh[3], int nb);
+int spectral_rows_own(isdf_handle h, const double* d_in, int nb, const int32_t mesh[3], const int32_t* d_idx, const double* d_scale,
+                      int npts, double* d_out, int64_t ldx, HIP_vector_type<double, 2u>* zbuf);
 int conv_rows_q_own(isdf_handle h, const double* d_in, double* d_re, double* d_im, int nb, const int32_t mesh[3], const double* tab,
                     double2* zhalf, double2* zfull);
 int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, const int32_t mesh[3], const double* cg,

@@ -43,7 +43,7 @@ __device__ inline double kernel_value(double g2, double omega, double rc) {
 }
 
 __global__ void coulG_half_kernel(double* __restrict__ out, int n0, int n1, int n2, Recip r,
-                                  double scale, double omega, double rc) {
+                                  double scale, double omega, double rc, double g2cut) {
   const int n2h = n2 / 2 + 1;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t tot = (int64_t)n0 * n1 * n2h;
@@ -54,6 +54,8 @@ __global__ void coulG_half_kernel(double* __restrict__ out, int n0, int n1, int 
   if (ix == 0 && iy == 0 && iz == 0) { out[idx] = scale * kernel_value(0.0, omega, rc); return; }
   const double g1 = g2_of(ix, iy, iz, n0, n1, n2, r);
   const double g2 = g2_of((n0 - ix) % n0, (n1 - iy) % n1, (n2 - iz) % n2, n0, n1, n2, r);
+  // g2cut > 0 (option "coul_sphere"): entries beyond the sphere |G|^2 <= g2cut are dropped
+  if (g2cut > 0.0 && (g1 > g2cut || g2 > g2cut)) { out[idx] = 0.0; return; }
   out[idx] = scale * 0.5 * (kernel_value(g1, omega, rc) + kernel_value(g2, omega, rc));
 }
 
@@ -169,8 +171,20 @@ int get_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9], doub
     *out = cg;
     return ISDF_OK;
   }
+  double g2cut = 0.0;
+  if (h->coul_sphere > 0) {
+    // radius of the sphere inscribed in the reciprocal FFT box (faces kappa_i = +-(n_i - 1) / 2, at distance 2 pi kappa_i / |a_i|),
+    // times coul_sphere percent
+    double rmin = 1e300;
+    for (int i = 0; i < 3; ++i) {
+      const double an = sqrt(a[3 * i] * a[3 * i] + a[3 * i + 1] * a[3 * i + 1] + a[3 * i + 2] * a[3 * i + 2]);
+      rmin = std::min(rmin, 2.0 * 3.14159265358979323846 * (double)((mesh[i] - 1) / 2) / an);
+    }
+    rmin *= 0.01 * (double)h->coul_sphere;
+    g2cut = rmin * rmin * (1.0 + 1e-12);
+  }
   hipLaunchKernelGGL(coulG_half_kernel, dim3((unsigned)cdiv(gc, 256)), dim3(256), 0, h->stream, cg, mesh[0],
-                     mesh[1], mesh[2], rr, extra_scale / (double)G, h->coul_omega, h->coul_rc);
+                     mesh[1], mesh[2], rr, extra_scale / (double)G, h->coul_omega, h->coul_rc, g2cut);
   KERNEL_CHECK(h);
   *out = cg;
   return ISDF_OK;
@@ -361,6 +375,46 @@ extern "C" int isdf_coulomb_rows(isdf_handle h, const double* d_in, int nrows, i
   for (int r = 0; r < nrows; r += batch) {
     const int nb = std::min(batch, nrows - r);
     rc = convolve_rows(h, d_in + (int64_t)r * ld, d_out + (int64_t)r * ldo, nb, mesh, cg, Z);
+    if (rc) return rc;
+  }
+  return ISDF_OK;
+}
+
+// ---- spectral form of W: the kernel table the Gamma-point convolution uses, and the packed spectra ------
+extern "C" int isdf_coulG_half(isdf_handle h, const int32_t mesh[3], const double a[9], double* d_out) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, mesh && a && d_out);
+  double* cg = nullptr;
+  int rc = get_coulG_half(h, mesh, a, 1.0, &cg);
+  if (rc) return rc;
+  const int64_t gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
+  HIP_TRY(h, hipMemcpyAsync(d_out, cg, sizeof(double) * gc, hipMemcpyDeviceToDevice, h->stream));
+  return ISDF_OK;
+}
+
+extern "C" int isdf_spectral_supported(isdf_handle h, const int32_t mesh[3], int batch, int* ok) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, mesh && ok && batch > 0);
+  *ok = spectral_rows_own_supported(h, mesh, batch) ? 1 : 0;
+  return ISDF_OK;
+}
+
+extern "C" int isdf_spectral_rows(isdf_handle h, const double* d_in, int nrows, int64_t ld, const int32_t mesh[3],
+                                  const int32_t* d_idx, const double* d_scale, int npts, int batch, double* d_out, int64_t ldx) {
+  if (!h) return ISDF_ERR_ARG;
+  ARG_CHECK(h, d_in && d_out && mesh && d_idx && d_scale && nrows >= 0 && batch > 0 && npts > 0);
+  const int64_t G = (int64_t)mesh[0] * mesh[1] * mesh[2];
+  const int64_t gc = (int64_t)mesh[0] * mesh[1] * (mesh[2] / 2 + 1);
+  ARG_CHECK(h, ld == G && npts <= gc);
+  if (nrows == 0) return ISDF_OK;
+  if (batch > nrows) batch = nrows;
+  if (!spectral_rows_own_supported(h, mesh, batch))
+    return isdf_fail(h, ISDF_ERR_ARG, "isdf_spectral_rows: mesh %d x %d x %d is not covered by the plane FFT", mesh[0], mesh[1], mesh[2]);
+  double2* Z = (double2*)isdf_ws(h, "coul_Z", sizeof(double2) * (size_t)batch * gc);
+  if (!Z) return ISDF_ERR_HIP;
+  for (int r = 0; r < nrows; r += batch) {
+    const int nb = std::min(batch, nrows - r);
+    int rc = spectral_rows_own(h, d_in + (int64_t)r * ld, nb, mesh, d_idx, d_scale, npts, d_out + (int64_t)r * ldx, ldx, Z);
     if (rc) return rc;
   }
   return ISDF_OK;

@@ -1369,6 +1369,95 @@ int conv_rows_own(isdf_handle h, const double* d_in, double* d_out, int nb, cons
   return ISDF_OK;
 }
 
+// ---- spectral rows: X[r][2j], X[r][2j+1] = scale[j] * (Re, Im) fft(rows[r])[idx[j]] over a list of half-spectrum points.
+// With scale^2 = multiplicity * w * coulG / G on the points inside a sphere, W = w conv(rows) rows^T = X X^T: the convolution's
+// inverse transform and half of the P^2 G product's K dimension are never computed ("spectral W").
+__global__ void spectral_pack_kernel(const double2* __restrict__ z, int64_t gc, const int32_t* __restrict__ idx,
+                                     const double* __restrict__ scale, int npts, double2* __restrict__ out, int64_t ldx2) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ldx2) return;
+  const int row = blockIdx.y;
+  double2 v = make_double2(0.0, 0.0);                    // padding up to the leading dimension is zero
+  if (j < npts) {
+    const double2 t = z[(int64_t)row * gc + idx[j]];
+    const double s = scale[j];
+    v = make_double2(t.x * s, t.y * s);
+  }
+  out[(int64_t)row * ldx2 + j] = v;
+}
+
+bool spectral_rows_own_supported(isdf_handle h, const int32_t mesh[3], int nb) {
+  if (h->own_fft != 2 || !conv_rows_own_supported(mesh, nb)) return false;
+  Axis ax[3];
+  for (int d = 0; d < 3; ++d)
+    if (!factorise(mesh[d], &ax[d]) || !smooth235(ax[d])) return false;
+  int a = 0, b = 0;
+  return fast_lines(mesh[0]) >= 1 && plane_lds_bytes(mesh[1], mesh[2], &a, &b) != 0;
+}
+
+// d_out (nb rows, leading dimension ldx doubles, ldx even and >= 2 npts) from nb real rows of G points; zbuf: nb * gc complex
+int spectral_rows_own(isdf_handle h, const double* d_in, int nb, const int32_t mesh[3], const int32_t* d_idx,
+                      const double* d_scale, int npts, double* d_out, int64_t ldx, double2* zbuf) {
+  const int n0 = mesh[0], n1 = mesh[1], n2 = mesh[2], n2h = n2 / 2 + 1;
+  Axis ax[3];
+  for (int d = 0; d < 3; ++d) {
+    if (!factorise(mesh[d], &ax[d])) return isdf_fail(h, ISDF_ERR_ARG, "spectral_rows_own: unsupported mesh dimension %d", mesh[d]);
+    char name[32];
+    snprintf(name, sizeof(name), "fft_tw_%d", mesh[d]);
+    const bool fresh = h->ws.find(name) == h->ws.end();
+    double2* tw = (double2*)isdf_ws(h, name, sizeof(double2) * (size_t)mesh[d]);
+    if (!tw) return ISDF_ERR_HIP;
+    if (fresh) {
+      std::vector<double2> host(mesh[d]);
+      for (int k = 0; k < mesh[d]; ++k) {
+        const double t = -2.0 * 3.14159265358979323846 * (double)k / (double)mesh[d];
+        host[k] = make_double2(cos(t), sin(t));
+      }
+      HIP_TRY(h, hipMemcpyAsync(tw, host.data(), sizeof(double2) * (size_t)mesh[d], hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    ax[d].tw = tw;
+  }
+  const int64_t gc = (int64_t)n0 * n1 * n2h;
+  int Lz = 0, bufsz = 0;
+  const size_t lds_r = plane_lds_bytes(n1, n2, &Lz, &bufsz);
+  const int FX = fast_lines(n0);
+  ARG_CHECK(h, lds_r && FX >= 1 && (int64_t)nb * n0 < 2147483647LL && nb <= 65535 && (ldx & 1) == 0 && ldx >= 2 * (int64_t)npts);
+  HIP_TRY(h, hipFuncSetAttribute((const void*)plane_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // algorithmic bytes: the real rows in, the packed rows out
+  ProfScope ps(h, "spectral_rows_own[byte]", (8.0 * (double)n0 * n1 * n2 + 8.0 * (double)ldx) * nb, 3);
+  hipStream_t st = h->stream;
+  const size_t ldsx = sizeof(double2) * ((size_t)n0 * FX + n0);
+  const dim3 gp((unsigned)((int64_t)nb * n0));
+  const int nplanes = (int)((int64_t)nb * n0);
+  const dim3 gpipe((unsigned)std::min<int64_t>(nplanes, h->num_cu));
+  bool piped = false;
+#define ISDF_PIPES_CASE(NN, RA, RB)                                                                                                \
+  case NN:                                                                                                                          \
+    if (ax[1].nstage == 2 && ax[1].radix[0] == RA && ax[1].radix[1] == RB) {                                                        \
+      HIP_TRY(h, hipFuncSetAttribute((const void*)plane_fwd_pipe_kernel<PIPE_NT, NN, RA, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      plane_fwd_pipe_kernel<PIPE_NT, NN, RA, RB><<<gpipe, dim3(PIPE_NT), lds_r, st>>>(d_in, zbuf, ax[2], ax[1], Lz, bufsz, nplanes); \
+      piped = true;                                                                                                                 \
+    }                                                                                                                               \
+    break;
+  if (h->conv_pipe != 0 && n1 == n2) switch (n1) {
+      ISDF_PIPES_CASE(64, 8, 8) ISDF_PIPES_CASE(72, 9, 8) ISDF_PIPES_CASE(80, 10, 8) ISDF_PIPES_CASE(96, 12, 8)
+      ISDF_PIPES_CASE(100, 10, 10) ISDF_PIPES_CASE(108, 12, 9) ISDF_PIPES_CASE(120, 12, 10) default: break;
+    }
+#undef ISDF_PIPES_CASE
+  if (!piped) plane_fwd_kernel<<<gp, dim3(TPBP), lds_r, st>>>(d_in, zbuf, ax[2], ax[1], Lz, bufsz);
+  const int ntx = (int)cdiv((int64_t)n1 * n2h, FX);
+  with_lines(FX, [&](auto z) {
+    strided_fft_fast_kernel<0, decltype(z)::value><<<dim3((unsigned)((int64_t)nb * ntx)), dim3(TPB), ldsx, st>>>(
+        zbuf, gc, (int64_t)n1 * n2h, n1 * n2h, ax[0], ntx, (const double*)nullptr);
+  });
+  const int64_t ldx2 = ldx / 2;
+  spectral_pack_kernel<<<dim3((unsigned)cdiv(ldx2, 256), (unsigned)nb), dim3(256), 0, st>>>(zbuf, gc, d_idx, d_scale, npts,
+                                                                                           (double2*)d_out, ldx2);
+  KERNEL_CHECK(h);
+  return ISDF_OK;
+}
+
 // k-point convolution of real rows with a FULL real kernel table (n0, n1, n2; no 1/G inside): Vre + i Vim = ifft(tab fft(rows)).
 // zhalf: nb * n0 n1 (n2/2+1) complex scratch, zfull: nb * G complex scratch.  Supported: 2-3-5 smooth meshes whose real and
 // complex (y, z) planes fit LDS (up to ~100^2 per plane: the k-point configs of BASELINE.json); the caller falls back to hipFFT.

@@ -63,7 +63,7 @@ int isdf_get_plan(isdf_handle h, const int32_t mesh[3], int batch, FftPlan** out
 
 extern "C" {
 
-int isdf_abi_version(void) { return 18; }
+int isdf_abi_version(void) { return 19; }
 
 int isdf_set_coulomb_omega(isdf_handle h, double omega) {
   if (!h) return ISDF_ERR_ARG;
@@ -96,6 +96,7 @@ int isdf_set_option(isdf_handle h, const char* key, int value) {
   if (std::string(key) == "trsm_substitution") { h->trsm_substitution = value ? 1 : 0; return ISDF_OK; }
   if (std::string(key) == "own_fft") { h->own_fft = value < 0 ? 0 : (value > 2 ? 2 : value); return ISDF_OK; }
   if (std::string(key) == "gemm_nn_own") { h->gemm_nn_own = value ? 1 : 0; return ISDF_OK; }
+  if (std::string(key) == "coul_sphere") { h->coul_sphere = value < 0 ? 0 : value; return ISDF_OK; }
   if (std::string(key) == "conv_pipe") { h->conv_pipe = value != 0; return ISDF_OK; }
   if (std::string(key) == "conv_sub_rows") { h->conv_sub_rows = value < 0 ? 0 : value; return ISDF_OK; }
   if (std::string(key) == "gram_pivot_tpb") {

@@ -192,6 +192,145 @@ class FitRouteMixin:
         be.symmetrize_upper(W)
         self._bj_finish(st['Afac'], st['Dblk'], st['ip_off'], W)
 
+    # ---- spectral W: W = X X^T from the scaled half spectra of the fit rows inside a sphere --------------------------------
+    def _spectral_plan(self):
+        """dict(idx, scale, npts, ldx, fraction) for the kernel the backend is set to, or None when the spectral form does not
+        apply (switched off; a mesh the plane FFT does not cover; a kernel table with negative entries, e.g. exxdiv='vcut_ws').
+        By Parseval  w sum_r Theta_P conv(Theta_Q) = (w / G) sum_G coulG(G) fft(Theta_P)(G) conj(fft(Theta_Q)(G));  over the half
+        spectrum (multiplicity 1 on the kz = 0 and Nyquist planes, 2 between) that is X X^T with
+        X[P][2j], X[P][2j+1] = sqrt(mult_j w coulG_j / G) (Re, Im) fft(Theta_P)(G_j).  ``w_sphere`` percent of the radius of the
+        sphere inscribed in the reciprocal FFT box bounds the points kept (0: the whole box, no truncation): the fitted pair
+        densities are as band-limited as the AO products they are combinations of, and what the corners of the box carry is the
+        square of the fit error times a small kernel value - 1e-9 Eh in E_K at BASELINE configs[2]."""
+        be = self.backend
+        if not getattr(self, 'w_spectral', False) or not hasattr(be, 'spectral_rows'):
+            return None
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        if not be.spectral_supported(mesh, int(self.fft_batch or 512)):
+            return None
+        a = np.asarray(self.cell.lattice_vectors(), dtype=float)
+        G = int(np.prod(mesh))
+        cg = be.coulG_half(mesh, a)                                  # (n0, n1, n2/2+1), 1/G inside
+        if (cg < 0).any():
+            return None
+        n0, n1, n2 = (int(x) for x in mesh)
+        n2h = n2 // 2 + 1
+        keep = cg > 0
+        pct = getattr(self, 'w_sphere', 'auto')
+        auto = isinstance(pct, str)
+        pct = 100.0 if auto else float(pct or 0.0)
+        box = keep.copy()
+        if pct > 0:
+            b = 2 * np.pi * np.linalg.inv(a).T                       # rows b_i
+            f0, f1, f2 = np.fft.fftfreq(n0, 1.0 / n0), np.fft.fftfreq(n1, 1.0 / n1), np.arange(n2h, dtype=float)
+            Gv = f0[:, None, None, None] * b[0] + f1[None, :, None, None] * b[1] + f2[None, None, :, None] * b[2]
+            g2 = np.einsum('xyzc,xyzc->xyz', Gv, Gv)
+            # inscribed sphere: the faces of the box sit at the frequencies +-(n_i - 1) // 2 (the Nyquist planes of even meshes,
+            # whose frequencies are ambiguous, lie outside), at distance 2 pi f / |a_i| from the origin
+            rmin = min(2 * np.pi * ((int(n) - 1) // 2) / np.linalg.norm(a[i]) for i, n in enumerate(mesh)) * pct / 100.0
+            keep &= g2 <= rmin * rmin * (1 + 1e-12)
+        mult = np.full((n0, n1, n2h), 2.0)
+        mult[:, :, 0] = 1.0
+        if n2 % 2 == 0:
+            mult[:, :, n2 // 2] = 1.0
+        w = self.cell.vol / G
+        if auto:
+            # 'auto': the truncation is taken only when this mesh resolves the AO pair products - measured once per mesh on a few
+            # random products (phi^T c)(phi^T d): the share of their Coulomb energy that sits outside the sphere (coarse test
+            # meshes fail this by orders of magnitude; the production meshes of BASELINE.json read 1e-14 and less)
+            key = (tuple(int(x) for x in mesh), round(float(pct), 6))
+            if getattr(self, '_sphere_share', (None,))[0] != key:
+                self._sphere_share = (key, self._sphere_energy_share(mesh, cg, mult, box, keep, w))
+            if not (self._sphere_share[1] <= float(getattr(self, 'w_sphere_tol', 1e-11))):
+                return None
+        idx = np.flatnonzero(keep.ravel()).astype(np.int32)
+        if len(idx) == 0:
+            return None
+        scale = np.sqrt(mult.ravel()[idx] * w * cg.ravel()[idx])
+        npts = len(idx)
+        ldx = -(-2 * npts // 128) * 128
+        return dict(idx=be.to_device(idx), scale=be.to_device(scale), npts=npts, ldx=ldx, fraction=2.0 * npts / G)
+
+    def _sphere_energy_share(self, mesh, cg, mult, box, keep, w, ntest=8):
+        """max over ntest random AO pair products t = (phi^T c)(phi^T d) of  E_outside / E_total,  E = (t | v | t) summed over the
+        kernel table's points outside the sphere / over all of them (one batch of forward transforms)."""
+        import torch
+        be = self.backend
+        ao = getattr(self, 'ao', None)
+        if ao is None:
+            return np.inf
+        nao, G = ao.shape
+        rng = np.random.default_rng(7)
+        cd = be.to_device(rng.standard_normal((2 * ntest, nao)) / np.sqrt(nao))
+        rows = be.empty((2 * ntest, G))
+        be.gemm_nn(cd, ao, rows)
+        t = rows[:ntest].contiguous()
+        be.hadamard_rows(t, rows[ntest:].contiguous())
+        idx = np.flatnonzero(box.ravel()).astype(np.int32)
+        scale = np.sqrt(mult.ravel()[idx] * w * cg.ravel()[idx])
+        ldx = -(-2 * len(idx) // 128) * 128
+        X = be.empty((ntest, ldx))
+        be.spectral_rows(t, mesh, be.to_device(idx), be.to_device(scale), X, batch=ntest)
+        x = be.to_host(X)[:, :2 * len(idx)]
+        e = x[:, 0::2] ** 2 + x[:, 1::2] ** 2
+        outside = ~keep.ravel()[idx]
+        tot = e.sum(axis=1)
+        return float((e[:, outside].sum(axis=1) / np.where(tot > 0, tot, 1.0)).max())
+
+    def _finish_W_spectral(self, W, probe=None):
+        """S3c + S4 + S5 of the block-Jacobi route in the spectral form: the fit rows Y' = D^-1 (pair rows) are produced in
+        FFT-batch-sized pieces (whole preconditioner blocks at a time), transformed forward only and packed into X (P, ldx) -
+        about half the size of the rows themselves, so configs[2] needs no panels; M' = X X^T (upper half, 512-row strips through
+        isdf_gemm_nt) and the route's P x P finishing.  probe as in _finish_W_paneled."""
+        be, st = self.backend, self._fit_state
+        plan = self._spectral_plan()
+        ip_off = np.asarray(st['ip_off'], dtype=np.int64)
+        P = W.shape[0]
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        if plan is None:
+            # a kernel the spectral form cannot take (negative table entries): the paneled build on the same factors
+            rows_avail = int(self._bufs['theta'].numel() // G)
+            st2 = dict(st, kind='blockjacobi-paneled', rows=self._buffer('theta', (rows_avail, G)),
+                       panels=self._panel_plan(ip_off, rows_avail))
+            self._fit_state = st2
+            try:
+                return self._finish_W_paneled(W, probe=probe)
+            finally:
+                self._fit_state = st
+        nbat = int(self.fft_batch or 512)
+        big = int(np.diff(ip_off).max())
+        self._last_fft_batch = nbat
+        ldx = plan['ldx']
+        X = self._buffer('theta', (P, ldx))
+        scratch = self._buffer('rows_scratch', (nbat + big, G))
+        self.w_spectral_fraction = plan['fraction']
+        nxt, fill, g0 = 0, 0, 0
+        while nxt < P or fill > 0:
+            while fill < nbat and nxt < P:
+                i = int(np.searchsorted(ip_off, nxt))
+                j = i + 1
+                while j + 1 < len(ip_off) and fill + (ip_off[j + 1] - nxt) <= nbat + big:
+                    j += 1
+                b1 = int(ip_off[j])
+                self._bj_rows_range(nxt, b1, scratch[fill:fill + (b1 - nxt)])
+                fill += b1 - nxt
+                nxt = b1
+            take = min(nbat, fill)
+            rows = scratch[:take]
+            if probe is not None:
+                be.rows_combine(probe[0][:, g0:g0 + take], rows, probe[1], accumulate=g0 > 0)
+            be.spectral_rows(rows, mesh, plan['idx'], plan['scale'], X[g0:g0 + take], batch=take)
+            if fill > take:
+                scratch[:fill - take].copy_(scratch[take:fill].clone() if fill - take > take else scratch[take:fill])
+            g0 += take
+            fill -= take
+        for b0 in range(0, P, nbat):
+            b1 = min(P, b0 + nbat)
+            be.gemm_nt(X[b0:b1], X[b0:], W[b0:b1, b0:], alpha=1.0)
+        be.symmetrize_upper(W)
+        self._bj_finish(st['Afac'], st['Dblk'], st['ip_off'], W)
+
     def _bj_finish(self, Afac, Dblk, ip_off, W, antisymmetric=False):
         """W <- D^-T [A'^-1 W A'^-1] D^-1 (W holds M' on entry)."""
         be = self.backend

@@ -59,6 +59,12 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
                                           # final pick, the fit and W are made in get_jk (Gamma point, select 'local'/'refined')
         self.occ_refit = 'always'         # pair_space='occ': 'always' = refit whenever get_jk sees another occupied space;
                                           # 'once' = keep the first fit until the next build()
+        self.w_spectral = True            # block-Jacobi route on one GPU: W = X X^T from the half spectra of the fit rows inside a sphere of the
+                                          # reciprocal FFT box (fit_route._spectral_plan): no inverse transform, about half the P^2 G product
+        self.w_sphere = 'auto'            # percent of the inscribed sphere's radius kept (0: the whole box = the reference's sum to rounding);
+                                          # 'auto': 100 when the mesh resolves the AO pair products (share of their Coulomb energy outside the
+                                          # sphere <= w_sphere_tol, measured once per mesh), the classic build otherwise
+        self.w_sphere_tol = 1e-11
         self.cand_skip_zero_rows = True   # the per-atom selections skip the AO rows that are identically zero on the atom's block of
                                           # grid points (the collocation truncates every shell at its rcut): same pivots, less traffic
         self.cand_ao_cutoff = None        # 'refined', Bohr: the CANDIDATE stage of an atom's block sees only the AOs of atoms
@@ -381,6 +387,17 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         rows_single, rows_panel = self._rows_plan[1:]
         paneled = Pmax > rows_single and not self._want_theta and self.fit_route != 'cholesky'
         rows_buf = max(min(Pmax, rows_panel) if paneled else Pmax, 2 * nao + kmax)
+        # spectral form of W (block-Jacobi route): X (P, ldx) takes the place of the rows - about half their size
+        spectral = None
+        routes = self._fit_routes()                       # (also validates fit_route)
+        # (max_resident_rows is the tests' and experiments' handle on the paneled build: it keeps the classic form)
+        if self.w_spectral and not self._want_theta and (routes[0] == 'blockjacobi' or (paneled and 'cholesky' != self.fit_route)) \
+                and not self._sharded and not self.max_resident_rows:
+            plan = self._spectral_plan()
+            if plan is not None and -(-Pmax * plan['ldx'] // G) <= rows_panel:
+                spectral = dict(ldx=plan['ldx'], fraction=plan['fraction'])
+                paneled = False
+                rows_buf = max(-(-Pmax * plan['ldx'] // G), 2 * nao + kmax)
         scratch = self._buffer('theta', (rows_buf, G))
         ao_sel = scratch[:nao]
         L = scratch[nao:nao + kmax]
@@ -395,7 +412,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         piv_h = be.to_host(piv)
         self._tick('S2_select_candidates' if self.select == 'refined' else 'S2_select_ip', t0)
         self._sel = dict(owner=owner, perm=perm, blk_off=blk_off, nip_final=nip_final, piv_h=piv_h, rank=rank, paneled=paneled,
-                         rows_buf=rows_buf, rows_panel=rows_panel)
+                         rows_buf=rows_buf, rows_panel=rows_panel, spectral=spectral, rows_single=rows_single)
 
     def _pick_and_fit(self, orbitals=None):
         """S2 second stage + S3 + S4 + S5 from the candidates of _select_candidates: the final points ('refined': one pivoted
@@ -432,6 +449,16 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             self._psiP = self._buffer('psiP', (P, self._psi.shape[0]))
             be.gather_aoP(self._psi, d_ip, self._psiP)
         self.W = self._buffer('W', (P, P))
+        self.w_spectral_fraction = None
+        if sel.get('spectral') is not None:
+            if self._build_spectral(rank, clusters, d_ip, t0):
+                self._built = True
+                return self
+            # the probe check failed: the classic build below has the Cholesky route to fall back to
+            t0 = time.perf_counter()
+            rows_single, rows_panel = sel['rows_single'], sel['rows_panel']
+            paneled = P > rows_single
+            rows_buf = max(min(P, rows_panel) if paneled else P, 1)
         if paneled:
             self._build_paneled(rank, clusters, d_ip, rows_buf, rows_panel, t0)
             self._built = True
@@ -550,6 +577,38 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         else:
             self._pick_and_fit(orb)
         self._fit_pending = False
+
+    def _build_spectral(self, rank, clusters, d_ip, t0):
+        """S3c + S4 + S5 in the spectral form (fit_route.FitRouteMixin._finish_W_spectral): block-Jacobi route, the probe check
+        alongside.  Returns False when the check fails (the caller then runs the classic build, which can fall back to the
+        Cholesky route)."""
+        be = self.backend
+        P = len(self.ip)
+        nao, G = self.ao.shape
+        ip_off = self._bj_blocks(rank, clusters)
+        Afac, Dblk = self._bj_prepare(self.ao, 0, d_ip, ip_off, self.aoP, scratch=self.W)
+        self._fit_state = dict(kind='blockjacobi-spectral', Afac=Afac, Dblk=Dblk, ip_off=ip_off)
+        t0 = self._tick('S3_fit', t0)
+        probe = None
+        if self.fit_route == 'auto':
+            aoT = be.empty((nao, P))
+            be.gather_cols(self.ao, d_ip, aoT)
+            T0, E = self._bj_probe_vectors(aoT, Afac, Dblk, ip_off)
+            del aoT
+            probe = (E, be.empty((E.shape[0], G)))
+        self._finish_W_spectral(self.W, probe=probe)
+        t0 = self._tick('S4S5_coulomb_W', t0)
+        self.fit_route_used = 'blockjacobi'
+        self.n_panels = 1
+        if probe is None:
+            return True
+        self.bj_check = self._bj_probe_energies(T0, probe[1], self.W, None)
+        self._tick('S5_route_check', t0)
+        if self.bj_check <= self.bj_check_tol:
+            return True
+        warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e) in the spectral build; '
+                      'rebuilding W the classic way' % (self.bj_check, self.bj_check_tol))
+        return False
 
     def _build_paneled(self, rank, clusters, d_ip, rows_buf, rows_panel, t0):
         """S3c + S4 + S5 with the fit rows produced panel by panel (more points than HBM holds rows for): block-Jacobi
@@ -776,6 +835,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         be, st = self.backend, self._fit_state
         if st['kind'] == 'blockjacobi-paneled':
             return self._finish_W_paneled(W)
+        if st['kind'] == 'blockjacobi-spectral':
+            return self._finish_W_spectral(W)
         theta = st['theta']
         P, G = theta.shape
         mesh = np.asarray(self.mesh, dtype=np.int32)

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmi355_isdf.so')
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _lib = None
 
@@ -79,6 +79,9 @@ SIGNATURES = {
     'isdf_finish_Wq': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_vp]),
     'isdf_get_k_pair': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_dbl, c_vp]),
     'isdf_get_k_exact_kpt': (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_dbl, c_int, c_int, c_int, c_vp, c_vp]),
+    'isdf_coulG_half': (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    'isdf_spectral_supported': (c_int, [c_vp, c_vp, c_int, ctypes.POINTER(c_int)]),
+    'isdf_spectral_rows': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_i64]),
     'isdf_coulomb_rows_q': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'isdf_nyquist_spectra': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_vp]),
     'isdf_zhadamard_planes': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_i64]),

@@ -362,6 +362,26 @@ class OracleBackend:
         V = oisdf.coulomb_V(th[row0:row0 + nrows], a, mesh, self.omega, self.rc, self.ws)
         W[row0:row0 + nrows, :th.shape[0]] = torch.from_numpy(w * V.dot(th.T))
 
+    # spectral form of W (fit_route.FitRouteMixin._spectral_plan / _finish_W_spectral): numpy counterparts
+    def spectral_supported(self, mesh, batch=512):
+        return True
+
+    def coulG_half(self, mesh, a):
+        mesh = [int(x) for x in mesh]
+        G = int(np.prod(mesh))
+        c = tools.get_coulG(a, mesh, omega=self.omega, rc=self.rc, ws=self.ws).reshape(mesh)
+        flip = c[np.ix_(*[(-np.arange(n)) % n for n in mesh])]
+        return (0.5 * (c + flip) / G)[:, :, :mesh[2] // 2 + 1].copy()
+
+    def spectral_rows(self, rows, mesh, idx, scale, out, batch=512):
+        mesh = [int(x) for x in mesh]
+        z = np.fft.rfftn(rows.numpy().reshape(-1, *mesh), axes=(1, 2, 3)).reshape(rows.shape[0], -1)
+        v = z[:, idx.numpy()] * scale.numpy()
+        o = out.numpy()
+        o[:] = 0.0
+        o[:, 0:2 * v.shape[1]:2] = v.real
+        o[:, 1:2 * v.shape[1]:2] = v.imag
+
     def symmetrize_upper(self, W):
         w = W.numpy()
         iu = np.triu_indices(len(w), 1)

@@ -1215,12 +1215,17 @@ def test_max_device_memory_forces_panels_without_changing_the_result():
     G = int(np.prod(cell.mesh))
     df = ISDF(cell, c_isdf=8, select='refined')
     df.fit_route, df.fft_batch = 'blockjacobi', 32
+    df.w_spectral = False                      # the classic form: rows in panels (the spectral form, below, fits under the same cap)
     P = 8 * nao
     # room for about half of the rows next to the fixed allowances of FitRouteMixin._resident_rows
     df.max_device_memory = 8 * nao * G + 4 * 8 * P * P + (3 << 30) + 40 * 32 * G + 8 * G * (P // 2 + 24)
     k1 = df.get_jk(dm, with_j=False)[1]
     assert df.n_panels >= 2 and np.array_equal(df.ip, ref.ip)
     assert abs(k1 - k0).max() < 1e-9 * abs(k0).max()
+    sp = ISDF(cell, c_isdf=8, select='refined')
+    sp.fit_route, sp.fft_batch, sp.w_sphere, sp.max_device_memory = 'blockjacobi', 32, 0, df.max_device_memory
+    k2 = sp.get_jk(dm, with_j=False)[1]
+    assert sp.n_panels == 1 and sp.w_spectral_fraction > 1.0 and abs(k2 - k0).max() < 1e-8 * abs(k0).max()
 
 
 def test_candidate_stage_skips_rows_that_vanish_on_a_block_without_changing_the_points(be):
@@ -1249,3 +1254,55 @@ def test_candidate_stage_skips_rows_that_vanish_on_a_block_without_changing_the_
     got = be.block_row_absmax(be.to_device(src), off)
     ref = np.stack([abs(src[:, a:b]).max(axis=1) if b > a else np.zeros(37) for a, b in zip(off[:-1], off[1:])], axis=1)
     assert got.shape == (37, 5) and np.array_equal(got, ref)
+
+
+def test_spectral_W_matches_the_classic_product(be):
+    """W = X X^T from the packed half spectra (isdf_spectral_rows + isdf_gemm_nt) against w conv(rows) rows^T (isdf_coulomb_W) on the
+    same rows: the whole box to rounding, the sphere against the classic product made with the sphere-truncated kernel table
+    (option coul_sphere) to rounding; then the object end to end - whole box = classic K to the route's noise, 'auto' declines
+    the sphere on a mesh that does not resolve the pair products."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_diamond_prim('gth-dzvp', (24, 24, 24))
+    mesh = np.asarray(cell.mesh, dtype=np.int32)
+    a = np.asarray(cell.lattice_vectors())
+    G = int(np.prod(mesh))
+    rng = np.random.default_rng(8)
+    rows = be.to_device(rng.standard_normal((70, G)))
+    Wc = be.empty((70, 70))
+    be.coulomb_W(rows, mesh, a, 0, 70, 32, Wc)
+    holder = ISDF(cell, c_isdf=4, select='local', backend=be)
+    for pct, ksphere in ((0, 0), (100.0, 100), (70.0, 70)):
+        holder.w_sphere = pct
+        plan = holder._spectral_plan()
+        X = be.empty((70, plan['ldx']))
+        be.spectral_rows(rows, mesh, plan['idx'], plan['scale'], X, batch=32)
+        Ws = be.empty((70, 70))
+        be.gemm_nt(X, X, Ws)
+        be.set_option('coul_sphere', ksphere)
+        try:
+            Wk = be.empty((70, 70))
+            be.coulomb_W(rows, mesh, a, 0, 70, 32, Wk)
+        finally:
+            be.set_option('coul_sphere', 0)
+        ws, wk = be.to_host(Ws), be.to_host(Wk)
+        assert abs(ws - wk).max() < 1e-11 * abs(wk).max()
+        if pct == 0:
+            assert plan['npts'] == 24 * 24 * 13 - 1 and abs(wk - be.to_host(Wc)).max() == 0.0
+        else:
+            assert plan['fraction'] < 0.35 and abs(wk - be.to_host(Wc)).max() > 1e-9 * abs(wk).max()      # white noise is not band limited
+        # against numpy on the half spectrum
+        z = np.fft.rfftn(be.to_host(rows).reshape(70, *mesh), axes=(1, 2, 3)).reshape(70, -1)
+        v = z[:, be.to_host(plan['idx'])] * be.to_host(plan['scale'])
+        x = be.to_host(X)
+        assert abs(x[:, 0:2 * plan['npts']:2] - v.real).max() < 1e-10 * abs(v).max() and abs(x[:, 2 * plan['npts']:]).max() == 0.0
+    nao = cell.nao_nr()
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    ref = ISDF(cell, c_isdf=8, select='refined'); ref.w_spectral = False
+    k0 = ref.get_jk(dm, with_j=False)[1]
+    box = ISDF(cell, c_isdf=8, select='refined'); box.w_sphere = 0
+    k1 = box.get_jk(dm, with_j=False)[1]
+    assert box._fit_state['kind'] == 'blockjacobi-spectral' and box.w_spectral_fraction > 1.0
+    assert np.array_equal(box.ip, ref.ip) and abs(k1 - k0).max() < 1e-8 * abs(k0).max()
+    auto = ISDF(cell, c_isdf=8, select='refined')
+    k2 = auto.get_jk(dm, with_j=False)[1]
+    assert auto.w_spectral_fraction is None and auto._sphere_share[1] > 1e-9 and abs(k2 - k0).max() < 1e-12 * abs(k0).max()

@@ -495,3 +495,55 @@ def test_occ_pair_space_switches_back_to_ao_pairs_when_needed():
     assert abs(df.get_jk(d1, with_j=False)[1] - k_ao).max() < 1e-9 * abs(k_ao).max()
     vk_again = df.get_jk(tdm, with_j=False)[1]
     assert df._fit_dm is not None and abs(vk_again - vk_occ).max() < 1e-10 * abs(vk_occ).max()
+
+
+def test_spectral_W_host_logic_with_checker_backend():
+    """W = X X^T from the half spectra of the fit rows (fit_route.FitRouteMixin._spectral_plan / _finish_W_spectral): with the
+    whole box kept it is the classic W to the (amplified) rounding of the route; the sphere is taken by 'auto' only when the
+    mesh resolves the AO pair products, and a forced sphere on a mesh that does not is caught by the probe check."""
+    import warnings
+    import cells
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_diamond_prim('gth-szv', (24, 24, 24))
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(1)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+
+    def run(**kw):
+        df = ISDF(cell, c_isdf=6, select='local', backend=OracleBackend())
+        for k, v in kw.items():
+            setattr(df, k, v)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            vk = df.get_jk(dm, with_j=False)[1]
+        return df, vk, [str(w.message) for w in rec]
+    ref, k_ref, _ = run(w_spectral=False)
+    assert ref.w_spectral_fraction is None and ref.fit_route_used == 'blockjacobi'
+    box, k_box, _ = run(w_sphere=0)
+    assert box.w_spectral_fraction > 1.0 and box._fit_state['kind'] == 'blockjacobi-spectral'
+    assert abs(k_box - k_ref).max() < 1e-7 * abs(k_ref).max() and box.bj_check <= box.bj_check_tol
+    # the plan: every point of the half spectrum with a positive kernel value, multiplicity 1 on the kz = 0 and Nyquist planes
+    plan = box._spectral_plan()
+    n2h = 24 // 2 + 1
+    assert plan['npts'] == 24 * 24 * n2h - 1 and plan['ldx'] % 128 == 0 and plan['ldx'] >= 2 * plan['npts']
+    # range separation rebuilds W through the same spectral state (long range + short range = full)
+    kl = box.get_jk(dm, with_j=False, omega=0.4)[1]
+    ks = box.get_jk(dm, with_j=False, omega=-0.4)[1]
+    assert abs(kl + ks - k_box).max() < 1e-7 * abs(k_box).max()
+    # 'auto' on this 24^3 mesh: 7e-8 of the products' Coulomb energy sits outside the sphere -> the classic build
+    auto, k_auto, _ = run()
+    assert auto.w_spectral_fraction is None and 1e-9 < auto._sphere_share[1] < 1e-6 and np.array_equal(k_auto, k_ref)
+    # a forced sphere is about 0.3 of the box for the fcc cell; K moves by what the corners carried
+    sph, k_sph, _ = run(w_sphere=100.0, bj_check_tol=1e-6)
+    assert 0.25 < sph.w_spectral_fraction < 0.35 and 1e-10 < abs(k_sph - k_ref).max() < 1e-6
+    # on a coarse mesh the probe check rejects it and the classic build takes over
+    cell12 = cells.cell_diamond_prim('gth-szv', (12, 12, 12))
+    df = ISDF(cell12, c_isdf=6, select='local', backend=OracleBackend())
+    df.w_sphere = 100.0
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        k12 = df.get_jk(dm, with_j=False)[1]
+    assert any('spectral build' in str(w.message) for w in rec) and df.w_spectral_fraction is None or df._fit_state['kind'] != 'blockjacobi-spectral'
+    ref12 = ISDF(cell12, c_isdf=6, select='local', backend=OracleBackend()); ref12.w_spectral = False
+    assert abs(k12 - ref12.get_jk(dm, with_j=False)[1]).max() < 1e-12
