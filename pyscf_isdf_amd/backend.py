@@ -53,14 +53,19 @@ class HipBackend:
     def to_host(self, t):
         return t.detach().cpu().numpy()
 
+    kernel_epoch = 0          # bumped whenever the Coulomb kernel state of the handle changes (plans derived from the table key on it)
+
     def set_coulomb_omega(self, omega):
+        self.kernel_epoch += 1
         self.handle.call('isdf_set_coulomb_omega', float(omega or 0.0))
 
     def set_coulomb_cutoff(self, rc):
+        self.kernel_epoch += 1
         self.handle.call('isdf_set_coulomb_cutoff', float(rc or 0.0))
 
     def set_coulomb_ws(self, ws):
         """ws: dict(alpha, a, mesh, maxq, vq) from pbc_tools.wigner_seitz_kernel, or None to switch the kernel off."""
+        self.kernel_epoch += 1
         if ws is None:
             self.handle.call('isdf_set_coulomb_ws', 0.0, None, None, None, None)
             self._ws_table = None
@@ -73,6 +78,7 @@ class HipBackend:
                          self._p(self._ws_table))
 
     def set_option(self, key, value):
+        self.kernel_epoch += 1
         self.handle.call('isdf_set_option', key.encode(), int(value))
 
     def free_bytes(self):

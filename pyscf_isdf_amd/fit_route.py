@@ -206,6 +206,19 @@ class FitRouteMixin:
         if not getattr(self, 'w_spectral', False) or not hasattr(be, 'spectral_rows'):
             return None
         mesh = np.asarray(self.mesh, dtype=np.int32)
+        # (one plan per kernel state of the backend: the table comes down to the host and the point list goes up again)
+        epoch = getattr(be, 'kernel_epoch', None)
+        ckey = (tuple(int(x) for x in mesh), epoch, str(getattr(self, 'w_sphere', 'auto')), float(getattr(self, 'w_sphere_tol', 0.0)),
+                int(self.fft_batch or 512))
+        cached = getattr(self, '_spectral_plan_cache', None)
+        if epoch is not None and cached is not None and cached[0] == ckey:
+            return cached[1]
+        plan = self._spectral_plan_make(mesh)
+        self._spectral_plan_cache = (ckey, plan)
+        return plan
+
+    def _spectral_plan_make(self, mesh):
+        be = self.backend
         if not be.spectral_supported(mesh, int(self.fft_batch or 512)):
             return None
         a = np.asarray(self.cell.lattice_vectors(), dtype=float)

@@ -65,6 +65,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
                                           # 'auto': 100 when the mesh resolves the AO pair products (share of their Coulomb energy outside the
                                           # sphere <= w_sphere_tol, measured once per mesh), the classic build otherwise
         self.w_sphere_tol = 1e-11
+        self.w_spectral_max_c = 14        # the spectral form carries a few times the classic product's rounding (both operands come out of a
+                                          # transform), amplified like it by cond(A')^2: above this c_isdf the probe check would reject it
         self.cand_skip_zero_rows = True   # the per-atom selections skip the AO rows that are identically zero on the atom's block of
                                           # grid points (the collocation truncates every shell at its rcut): same pivots, less traffic
         self.cand_ao_cutoff = None        # 'refined', Bohr: the CANDIDATE stage of an atom's block sees only the AOs of atoms
@@ -392,7 +394,7 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
         routes = self._fit_routes()                       # (also validates fit_route)
         # (max_resident_rows is the tests' and experiments' handle on the paneled build: it keeps the classic form)
         if self.w_spectral and not self._want_theta and (routes[0] == 'blockjacobi' or (paneled and 'cholesky' != self.fit_route)) \
-                and not self._sharded and not self.max_resident_rows:
+                and not self._sharded and not self.max_resident_rows and self.c_isdf <= self.w_spectral_max_c:
             plan = self._spectral_plan()
             if plan is not None and -(-Pmax * plan['ldx'] // G) <= rows_panel:
                 spectral = dict(ldx=plan['ldx'], fraction=plan['fraction'])

@@ -1225,7 +1225,13 @@ def test_max_device_memory_forces_panels_without_changing_the_result():
     sp = ISDF(cell, c_isdf=8, select='refined')
     sp.fit_route, sp.fft_batch, sp.w_sphere, sp.max_device_memory = 'blockjacobi', 32, 0, df.max_device_memory
     k2 = sp.get_jk(dm, with_j=False)[1]
-    assert sp.n_panels == 1 and sp.w_spectral_fraction > 1.0 and abs(k2 - k0).max() < 1e-8 * abs(k0).max()
+    # the whole box in spectral form is LARGER than the rows (2 (n2/2 + 1) / n2 of them): under this cap it stays classic, in panels
+    assert sp.n_panels >= 2 and sp.w_spectral_fraction is None and abs(k2 - k0).max() < 1e-9 * abs(k0).max()
+    sp.w_sphere, sp.bj_check_tol = 100.0, 1e-5           # the sphere (0.3 of the box) fits in one piece
+    k3 = sp.get_jk(dm, with_j=False)[1]
+    sp.build()
+    k3 = sp.get_jk(dm, with_j=False)[1]
+    assert sp.n_panels == 1 and 0.2 < sp.w_spectral_fraction < 0.4 and abs(k3 - k0).max() < 1e-4 * abs(k0).max()
 
 
 def test_candidate_stage_skips_rows_that_vanish_on_a_block_without_changing_the_points(be):

@@ -44,10 +44,16 @@ for sel in selects:
             df.cand_ao_cutoff = float(os.environ['ISDF_CAND_CUTOFF'])
         if os.environ.get('ISDF_FIT_ROUTE'):
             df.fit_route = os.environ['ISDF_FIT_ROUTE']
+        if os.environ.get('ISDF_BJ_MAX_C'):
+            df.bj_max_c = int(os.environ['ISDF_BJ_MAX_C'])
+        if os.environ.get('ISDF_BJ_GROUP'):
+            df.bj_group = int(os.environ['ISDF_BJ_GROUP'])
+        if os.environ.get('ISDF_W_FORM'):
+            df.w_spectral = os.environ['ISDF_W_FORM'] == 'spectral'
         t0 = time.perf_counter()
         vk = df.get_jk(tdm if space == 'occ' else dm, with_j=False)[1]
         t1 = time.perf_counter()
-        nip, route_used = len(df.ip), '%s, %d panel(s), probe %s' % (df.fit_route_used, df.n_panels, ('%.1e' % df.bj_check) if df.bj_check is not None else '-')
+        nip, route_used = len(df.ip), '%s, %d panel(s), probe %s, W %s' % (df.fit_route_used, df.n_panels, ('%.1e' % df.bj_check) if df.bj_check is not None else '-', ('spectral %.3f' % df.w_spectral_fraction) if df.w_spectral_fraction else 'classic')
         if ref is None:
             df.release_fit_buffers()            # the fit's buffers fill HBM at large c; the exact exchange needs phi only
             ref = df.get_k_exact(mo_coeff=c, mo_occ=occ)
