@@ -67,6 +67,8 @@ int isdf_release_workspace(isdf_handle h);
  * "conv_pipe": 1 (default) the plane passes of the three-pass convolution run as persistent workgroups with the next plane's
  * loads in flight under the current plane's stages (square planes of 64, 72, 80, 96, 100, 108 or 120 points a side), 0 one
  * workgroup per plane everywhere; same results bit for bit (profiles/r03_conv_pipelined_plane_passes.log).
+ * "coul_sphere": p > 0 zeroes the Gamma-point kernel table beyond p percent of the radius of the sphere inscribed in the reciprocal
+ * FFT box (0, the default: the whole box) - the experiment behind the spectral form of W (profiles/r03_sphere_check.log).
  * "gram_pivot_tpb": columns per workgroup of isdf_select_ip_gram's pivot step, 256 (default), 128 or 64; same pivots and
  * factor for every value, narrower is slower (12.2 / 13.0 / 15.5 us per pivot, profiles/r03_gram_pivot_step_widths.log). */
 int isdf_set_option(isdf_handle h, const char* key, int value);

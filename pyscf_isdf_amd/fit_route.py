@@ -279,6 +279,15 @@ class FitRouteMixin:
         be.gemm_nn(cd, ao, rows)
         t = rows[:ntest].contiguous()
         be.hadamard_rows(t, rows[ntest:].contiguous())
+        Gfull = int(np.prod(mesh))
+        if G != Gfull:
+            # grid-sharded build: phi lives on this rank's slice - the products are assembled over the whole grid (zero-padded
+            # all-reduce, 8 rows), every rank then measures the same numbers
+            g0, g1 = self._slice
+            full = be.zeros((ntest, Gfull))
+            full[:, g0:g1] = t
+            self.comm.all_reduce_sum(full)
+            t = full
         idx = np.flatnonzero(box.ravel()).astype(np.int32)
         scale = np.sqrt(mult.ravel()[idx] * w * cg.ravel()[idx])
         ldx = -(-2 * len(idx) // 128) * 128

@@ -65,6 +65,8 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
                                           # 'auto': 100 when the mesh resolves the AO pair products (share of their Coulomb energy outside the
                                           # sphere <= w_sphere_tol, measured once per mesh), the classic build otherwise
         self.w_sphere_tol = 1e-11
+        self.w_spectral_check_tol = 5e-9  # the spectral form is kept only when the route's probe mismatch stays below this (the classic form
+                                          # is held to bj_check_tol): its rounding, amplified like the classic form's, shows up there first
         self.w_spectral_max_c = 14        # the spectral form carries a few times the classic product's rounding (both operands come out of a
                                           # transform), amplified like it by cond(A')^2: above this c_isdf the probe check would reject it
         self.cand_skip_zero_rows = True   # the per-atom selections skip the AO rows that are identically zero on the atom's block of
@@ -606,10 +608,12 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
             return True
         self.bj_check = self._bj_probe_energies(T0, probe[1], self.W, None)
         self._tick('S5_route_check', t0)
-        if self.bj_check <= self.bj_check_tol:
+        tol = min(self.bj_check_tol, self.w_spectral_check_tol)
+        if self.bj_check <= tol:
             return True
         warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e) in the spectral build; '
-                      'rebuilding W the classic way' % (self.bj_check, self.bj_check_tol))
+                      'rebuilding W the classic way' % (self.bj_check, tol))
+        self.w_spectral_fraction = None
         return False
 
     def _build_paneled(self, rank, clusters, d_ip, rows_buf, rows_panel, t0):

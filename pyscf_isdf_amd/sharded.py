@@ -252,6 +252,12 @@ class ShardedMixin:
         mesh = np.asarray(self.mesh, dtype=np.int32)
         G = int(np.prod(mesh))
         a = np.asarray(cell.lattice_vectors(), dtype=float)
+        self.w_spectral_fraction = None
+        if st['kind'] == 'blockjacobi' and self.w_spectral and not self._want_theta and self.c_isdf <= self.w_spectral_max_c:
+            plan = self._spectral_plan()
+            # (one decision for all ranks: the plan is a function of replicated data, but 'auto' measures on the rank's own slice)
+            if comm.agree_max(0.0 if plan is not None else 1.0) == 0.0:
+                return self._finish_W_sharded_spectral(W, plan)
         # S4 + S5 streamed over row batches: rank q convolves rows P_q[t*nb : (t+1)*nb] in step t.  Two streams: the
         # exchange/FFT pipeline of step t+1 (all-to-all, row assembly, convolution, all-to-all) runs on a side stream
         # while the MFMA products of step t run on the work stream; every buffer is allocated once (two slots).
@@ -331,6 +337,69 @@ class ShardedMixin:
             self._bj_finish_sharded(st['Afac'], st['Dblk'], st['ip_off'], W)
         elif st['kind'] == 'cholesky':
             be.W_from_factor(st['chol'], 0, W)
+
+    def _finish_W_sharded_spectral(self, W, plan):
+        """The spectral form of W (fit_route.FitRouteMixin._finish_W_spectral) on the grid-sharded build.  Rank q assembles the
+        rows of its batch over the whole grid (the same first all-to-all as the classic form), transforms them forward and packs
+        them into X[bat_q, :]; the second all-to-all hands every rank r its K slice X[:, K_r] of ALL rows (0.36 of the classic
+        form's volume); when all batches are through, W_r = X[:, K_r] X[:, K_r]^T (upper half) and one all-reduce.  The products
+        cannot start before the last batch has arrived (every row meets every row), so the exchange is not hidden behind them as
+        in the classic form - it is shorter instead."""
+        cell, be, comm = self.cell, self.backend, self.comm
+        st = self._fit_state
+        theta = st['theta']
+        P, ng = theta.shape
+        R, rk = comm.size, comm.rank
+        mesh = np.asarray(self.mesh, dtype=np.int32)
+        G = int(np.prod(mesh))
+        ldx = int(plan['ldx'])
+        self.w_spectral_fraction = plan['fraction']
+        slices = [comm.split_range(G, r) for r in range(R)]
+        rows = [comm.split_range(P, r) for r in range(R)]
+        ks = [tuple(16 * x for x in comm.split_range(ldx // 16, r)) for r in range(R)]      # K slices (ldx is a multiple of 128)
+        kw = ks[rk][1] - ks[rk][0]
+        nb = int(self.fft_batch or 512)
+        nb = max(1, min(nb, max(hi - lo for lo, hi in rows)))
+        nsteps = max(-(-(hi - lo) // nb) for lo, hi in rows)
+        Xloc = be.empty((P, max(kw, 1)))
+        pieces = be.empty((nb * G,))
+        full = be.empty((nb, G))
+        Xb = be.empty((nb, ldx))
+        recvX = be.empty((R * nb * max(kw, 1),))
+
+        def views(flat, nrow_of, width_of):
+            out, off = [], 0
+            for q in range(R):
+                n = nrow_of(q) * width_of(q)
+                out.append(flat[off:off + n].view(nrow_of(q), width_of(q)))
+                off += n
+            return out
+        for t in range(nsteps):
+            bat = [(min(lo + t * nb, hi), min(lo + (t + 1) * nb, hi)) for lo, hi in rows]
+            nrow = [hi - lo for lo, hi in bat]
+            mine = nrow[rk]
+            recv = views(pieces, lambda q: mine, lambda q: slices[q][1] - slices[q][0])
+            comm.all_to_all(recv, [theta[lo:hi] for lo, hi in bat])
+            rows_full = full[:mine]
+            for (s0, s1), piece in zip(slices, recv):
+                rows_full[:, s0:s1] = piece
+            if mine:
+                be.spectral_rows(rows_full, mesh, plan['idx'], plan['scale'], Xb[:mine], batch=mine)
+            got = views(recvX, lambda q: nrow[q], lambda q: kw)
+            comm.all_to_all(got, [Xb[:mine, k0:k1].contiguous() for k0, k1 in ks])
+            for q in range(R):
+                if nrow[q]:
+                    Xloc[bat[q][0]:bat[q][1]] = got[q]
+        del pieces, full, Xb, recvX
+        W.zero_()
+        if kw > 0:
+            for b0 in range(0, P, 512):
+                b1 = min(P, b0 + 512)
+                be.gemm_nt(Xloc[b0:b1], Xloc[b0:], W[b0:b1, b0:], alpha=1.0)
+        del Xloc
+        comm.all_reduce_sum(W)
+        be.symmetrize_upper(W)
+        self._bj_finish_sharded(st['Afac'], st['Dblk'], st['ip_off'], W)
 
     def _keep_V_for_robust_k_sharded(self, t0):
         """robust_k on the grid-sharded build: the fit rows on this rank's slice become V = conv(Theta)[:, S_r], in place -

@@ -1227,7 +1227,7 @@ def test_max_device_memory_forces_panels_without_changing_the_result():
     k2 = sp.get_jk(dm, with_j=False)[1]
     # the whole box in spectral form is LARGER than the rows (2 (n2/2 + 1) / n2 of them): under this cap it stays classic, in panels
     assert sp.n_panels >= 2 and sp.w_spectral_fraction is None and abs(k2 - k0).max() < 1e-9 * abs(k0).max()
-    sp.w_sphere, sp.bj_check_tol = 100.0, 1e-5           # the sphere (0.3 of the box) fits in one piece
+    sp.w_sphere, sp.bj_check_tol, sp.w_spectral_check_tol = 100.0, 1e-5, 1e-5           # the sphere (0.3 of the box) fits in one piece
     k3 = sp.get_jk(dm, with_j=False)[1]
     sp.build()
     k3 = sp.get_jk(dm, with_j=False)[1]
@@ -1305,7 +1305,7 @@ def test_spectral_W_matches_the_classic_product(be):
     dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
     ref = ISDF(cell, c_isdf=8, select='refined'); ref.w_spectral = False
     k0 = ref.get_jk(dm, with_j=False)[1]
-    box = ISDF(cell, c_isdf=8, select='refined'); box.w_sphere = 0
+    box = ISDF(cell, c_isdf=8, select='refined'); box.w_sphere, box.w_spectral_check_tol = 0, 3e-8
     k1 = box.get_jk(dm, with_j=False)[1]
     assert box._fit_state['kind'] == 'blockjacobi-spectral' and box.w_spectral_fraction > 1.0
     assert np.array_equal(box.ip, ref.ip) and abs(k1 - k0).max() < 1e-8 * abs(k0).max()

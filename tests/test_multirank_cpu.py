@@ -43,7 +43,9 @@ def _run_case(comm, fft_batch, route='cholesky'):
     if occ_space:
         df.pair_space = 'occ'
     df.fft_batch = fft_batch
-    df.fit_route = 'cholesky' if route in ('robust', 'refined', 'occ') else ('blockjacobi' if route == 'occ-bj' else route)
+    df.fit_route = 'cholesky' if route in ('robust', 'refined', 'occ') else ('blockjacobi' if route in ('occ-bj', 'spectral') else route)
+    if route == 'spectral':
+        df.w_sphere = 0                        # W = X X^T over the whole half spectrum: exact, K slices exchanged instead of V slices
     df.robust_k = route == 'robust'          # Dunlap's correction: V slices through the same all-to-alls, K1 all-reduced
     df.bj_check_tol = 1e-6                     # c_isdf=3 on 8 AOs: the check value is ~1e-8, far from the decision
     df.build()
@@ -61,6 +63,10 @@ def _run_case(comm, fft_batch, route='cholesky'):
         if comm.size > 1:
             ref = ISDF(cell, c_isdf=3, backend=OracleBackend()).get_k_exact(dm[0].dot(dm[0].T))
             assert abs(kx - ref).max() < 1e-12 * abs(ref).max()
+    if route == 'spectral':
+        assert df.w_spectral_fraction is not None and df.w_spectral_fraction > 1.0
+    else:
+        assert df.w_spectral_fraction is None          # (this coarse mesh does not resolve the pair products: 'auto' declines)
     return df.ip.copy(), df.W.numpy().copy(), vj, vk, df.fit_route_used, df.bj_check
 
 
@@ -78,7 +84,7 @@ def _worker(rank, world, port, q, route):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('route', ['cholesky', 'blockjacobi', 'auto', 'robust', 'refined', 'occ', 'occ-bj'])
+@pytest.mark.parametrize('route', ['cholesky', 'blockjacobi', 'auto', 'robust', 'refined', 'occ', 'occ-bj', 'spectral'])
 def test_two_ranks_match_one_rank(route):
     _setup_path()
     from pyscf_isdf_amd.parallel import Comm

@@ -520,7 +520,7 @@ def test_spectral_W_host_logic_with_checker_backend():
         return df, vk, [str(w.message) for w in rec]
     ref, k_ref, _ = run(w_spectral=False)
     assert ref.w_spectral_fraction is None and ref.fit_route_used == 'blockjacobi'
-    box, k_box, _ = run(w_sphere=0)
+    box, k_box, _ = run(w_sphere=0, w_spectral_check_tol=3e-8)
     assert box.w_spectral_fraction > 1.0 and box._fit_state['kind'] == 'blockjacobi-spectral'
     assert abs(k_box - k_ref).max() < 1e-7 * abs(k_ref).max() and box.bj_check <= box.bj_check_tol
     # the plan: every point of the half spectrum with a positive kernel value, multiplicity 1 on the kz = 0 and Nyquist planes
@@ -535,7 +535,7 @@ def test_spectral_W_host_logic_with_checker_backend():
     auto, k_auto, _ = run()
     assert auto.w_spectral_fraction is None and 1e-9 < auto._sphere_share[1] < 1e-6 and np.array_equal(k_auto, k_ref)
     # a forced sphere is about 0.3 of the box for the fcc cell; K moves by what the corners carried
-    sph, k_sph, _ = run(w_sphere=100.0, bj_check_tol=1e-6)
+    sph, k_sph, _ = run(w_sphere=100.0, bj_check_tol=1e-6, w_spectral_check_tol=1e-6)
     assert 0.25 < sph.w_spectral_fraction < 0.35 and 1e-10 < abs(k_sph - k_ref).max() < 1e-6
     # on a coarse mesh the probe check rejects it and the classic build takes over
     cell12 = cells.cell_diamond_prim('gth-szv', (12, 12, 12))
