@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet, MI355X FP64 matrix (the guide's table has no f64 row);
                                # best rocBLAS dgemm measured on the box: 73.8 (profiles/r01_probe_*.log)
-PMC_FILE = 'r03_pmc_bench_cfg3_fetch_write.json'
+PMC_FILE = 'r03_pmc_bench_cfg3_spectral_fetch_write.json'
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -392,6 +392,8 @@ def main():
             # algorithmic bytes of the launches that kernel handles: W batch r reads V (nb x G) and the rows r.. of Y' ((P - r) x G)
             # once and writes nb x (P - r); the 256x128 kernel takes every batch of more than 128 rows (gemm_f64.hip)
             Gn, Pn = int(np.prod(cell.mesh)), len(df.ip)
+            if getattr(df, 'w_spectral_fraction', None):
+                Gn = int(df._last_spectral_ldx)          # spectral form: strips of X (512 x ldx) against X ((P - r) x ldx)
             nbat = int(getattr(df, '_last_fft_batch', 0) or 512)
             algs = [8.0 * ((min(nbat, Pn - r) + (Pn - r)) * Gn + min(nbat, Pn - r) * (Pn - r))
                     for r in range(0, Pn, nbat) if min(nbat, Pn - r) > 128]

@@ -327,6 +327,7 @@ class FitRouteMixin:
         X = self._buffer('theta', (P, ldx))
         scratch = self._buffer('rows_scratch', (nbat + big, G))
         self.w_spectral_fraction = plan['fraction']
+        self._last_spectral_ldx = ldx
         nxt, fill, g0 = 0, 0, 0
         while nxt < P or fill > 0:
             while fill < nbat and nxt < P:
