@@ -53,3 +53,44 @@ print('spectral sphere (GPU) vs extended-precision Fourier sum: %.2e' % rel(ms2,
 print('classic vs spectral box (GPU):                         %.2e' % rel(mc, ms))
 print('extended real-space sum (numpy conv) vs Fourier sum:    %.2e' % rel(Mreal.astype(float), Mref.astype(float)))
 print('asymmetry classic %.2e  spectral %.2e' % (rel(mc, mc.T), rel(ms, ms.T)))
+
+# where does the spectral form's error come from?  (a) the product of the GPU's own X in extended precision on the host against
+# the GPU's gemm of the same X: the accumulation;  (b) that host product against the extended-precision sum over numpy's
+# spectra: the transform + packing
+x = be.to_host(X).astype(np.longdouble)
+Mx = x.dot(x.T)
+print('GPU gemm of X            vs extended-precision product of the same X: %.2e   (accumulation)' % rel(ms, Mx.astype(float)))
+print('extended product of GPU X vs extended-precision Fourier sum (numpy):   %.2e   (transform + packing)' % rel(Mx.astype(float), Mref.astype(float)))
+# the same split for the classic form: V from the GPU convolution, product on the host in extended precision
+V = sub.clone(); be.coulomb_rows(V, mesh, a, n)
+vh = be.to_host(V).astype(np.longdouble)
+Mv = w * vh.dot(y.astype(np.longdouble).T)
+print('GPU classic product      vs extended product of the GPU V and rows:   %.2e   (accumulation)' % rel(mc, Mv.astype(float)))
+print('extended product of GPU V vs extended-precision Fourier sum:           %.2e   (convolution)' % rel(Mv.astype(float), Mref.astype(float)))
+
+# does the ORDER of the packed points matter for the accumulation?  512-row strips (the production kernel variant); points as they
+# lie in the half spectrum / sorted by descending |G| (small terms first, the large low-G terms at the end of the chain) / ascending
+import numpy as _np
+sub512 = Y[:512].contiguous()
+pick = _np.array([0, 1, 5, 40, 41, 100, 200, 300, 400, 511])
+b = 2 * _np.pi * _np.linalg.inv(a).T
+n0, n1, n2 = (int(v) for v in mesh)
+f0, f1, f2 = _np.fft.fftfreq(n0, 1.0 / n0), _np.fft.fftfreq(n1, 1.0 / n1), _np.arange(n2 // 2 + 1, dtype=float)
+Gv = f0[:, None, None, None] * b[0] + f1[None, :, None, None] * b[1] + f2[None, None, :, None] * b[2]
+g2 = _np.einsum('xyzc,xyzc->xyz', Gv, Gv).ravel()
+idx0, sc0 = be.to_host(plan2['idx']), be.to_host(plan2['scale'])
+for tag, order in (('as stored', _np.arange(len(idx0))), ('descending |G|', _np.argsort(-g2[idx0], kind='stable')), ('ascending |G|', _np.argsort(g2[idx0], kind='stable'))):
+    Xo = be.empty((512, plan2['ldx']))
+    be.spectral_rows(sub512, mesh, be.to_device(idx0[order].astype(_np.int32)), be.to_device(sc0[order]), Xo, batch=512)
+    Mo = be.empty((512, 512)); be.gemm_nt(Xo, Xo, Mo)
+    xo = be.to_host(Xo)[pick].astype(_np.longdouble)
+    ref = xo.dot(xo.T).astype(float)
+    got = be.to_host(Mo)[_np.ix_(pick, pick)]
+    scl = _np.sqrt(_np.outer(_np.diag(ref), _np.diag(ref)))
+    print('512-row strip, sphere, points %-16s: gemm vs extended product of the same X  %.2e' % (tag, float(_np.max(_np.abs((got - ref) / scl)))))
+Vc = sub512.clone(); be.coulomb_rows(Vc, mesh, a, 512)
+Mc5 = be.empty((512, 512)); be.gemm_nt(Vc, sub512, Mc5, alpha=w)
+vh = be.to_host(Vc)[pick].astype(_np.longdouble); yh = be.to_host(sub512)[pick].astype(_np.longdouble)
+ref = (w * vh.dot(yh.T)).astype(float)
+scl = _np.sqrt(_np.outer(_np.diag(ref), _np.diag(ref)))
+print('512-row strip, classic product: gemm vs extended product of the same V, rows           %.2e' % float(_np.max(_np.abs((be.to_host(Mc5)[_np.ix_(pick, pick)] - ref) / scl))))
