@@ -244,7 +244,10 @@ def spawn_ranks(n):
 def main():
     args = parse_args()
     if args.c_isdf is None:
-        args.c_isdf = 12 if args.workload == 'diamond-444-dzvp-120' else 10
+        # configs[2]: c = 18 is where the measured |dE_K| falls under the north star's 1e-6 Eh (3.8e-7; c = 17 / 19 read +1.6e-6 /
+        # -2.0e-6: DESIGN.md section 2) - inside the 30 s budget since the spectral form of W; c = 12 (--c-isdf 12) is the fast
+        # variant (9.3 s, -3.6e-5 Eh).  With more than one rank the points per rank decide what fits: c = 12 there.
+        args.c_isdf = (18 if args.gpus == 1 else 12) if args.workload == 'diamond-444-dzvp-120' else 10
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     import torch

@@ -65,10 +65,11 @@ class ISDF(FitRouteMixin, ShardedMixin, KPointMixin, HcoreMixin, EriSurfaceMixin
                                           # 'auto': 100 when the mesh resolves the AO pair products (share of their Coulomb energy outside the
                                           # sphere <= w_sphere_tol, measured once per mesh), the classic build otherwise
         self.w_sphere_tol = 1e-11
+        self.w_sort_bins = 256            # packed points sorted into this many shells of |G|^2, outermost first (0: as they lie in the half spectrum)
         self.w_spectral_check_tol = 5e-9  # the spectral form is kept only when the route's probe mismatch stays below this (the classic form
                                           # is held to bj_check_tol): its rounding, amplified like the classic form's, shows up there first
-        self.w_spectral_max_c = 14        # the spectral form carries a few times the classic product's rounding (both operands come out of a
-                                          # transform), amplified like it by cond(A')^2: above this c_isdf the probe check would reject it
+        self.w_spectral_max_c = 18        # the spectral form carries a few times the classic product's rounding (both operands come out of a
+                                          # transform), amplified like it by cond(A')^2: above this c_isdf the probe check rejects it at configs[2]
         self.cand_skip_zero_rows = True   # the per-atom selections skip the AO rows that are identically zero on the atom's block of
                                           # grid points (the collocation truncates every shell at its rcut): same pivots, less traffic
         self.cand_ao_cutoff = None        # 'refined', Bohr: the CANDIDATE stage of an atom's block sees only the AOs of atoms

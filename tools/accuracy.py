@@ -46,6 +46,10 @@ for sel in selects:
             df.fit_route = os.environ['ISDF_FIT_ROUTE']
         if os.environ.get('ISDF_BJ_MAX_C'):
             df.bj_max_c = int(os.environ['ISDF_BJ_MAX_C'])
+        if os.environ.get('ISDF_W_MAX_C'):
+            df.w_spectral_max_c = int(os.environ['ISDF_W_MAX_C'])
+        if os.environ.get('ISDF_W_CHECK_TOL'):
+            df.w_spectral_check_tol = float(os.environ['ISDF_W_CHECK_TOL'])
         if os.environ.get('ISDF_BJ_GROUP'):
             df.bj_group = int(os.environ['ISDF_BJ_GROUP'])
         if os.environ.get('ISDF_W_FORM'):
