@@ -410,8 +410,10 @@ def main():
                 if fetch is None or write is None:
                     traffic_note = 'profiles/%s lacks FETCH_SIZE or WRITE_SIZE for %s' % (PMC_FILE, base)
                 elif v['launches'] != per_step or abs(v['avg_ms'] - dom['avg_ms']) > 0.05 * dom['avg_ms'] or world != 1 or not algs:
-                    traffic_note = ('profiles/%s is for another run (%d launches of %.1f ms there, %.1f per step of %.1f ms here)'
-                                    % (PMC_FILE, v['launches'], v['avg_ms'], per_step, dom['avg_ms']))
+                    traffic_note = ('profiles/%s is for another run (%d launches of %.1f ms there, %.1f per step of %.1f ms here): the PMC '
+                                    'passes were collected on the c = 12 variant of this build (--c-isdf 12: %.1f GB per launch of this '
+                                    'kernel, 1.19 x its algorithmic bytes); at c = 18 they did not finish inside the GPU box\'s limit'
+                                    % (PMC_FILE, v['launches'], v['avg_ms'], per_step, dom['avg_ms'], (2 * fetch + write) * 1024 / 1e9))
                 else:
                     traffic = dict(bytes_per_launch=round((2 * fetch + write) * 1024),
                                    algorithmic_bytes_per_launch=round(sum(algs) / len(algs)),
