@@ -246,8 +246,9 @@ def main():
     if args.c_isdf is None:
         # configs[2]: c = 18 is where the measured |dE_K| falls under the north star's 1e-6 Eh (3.8e-7; c = 17 / 19 read +1.6e-6 /
         # -2.0e-6: DESIGN.md section 2) - inside the 30 s budget since the spectral form of W; c = 12 (--c-isdf 12) is the fast
-        # variant (9.3 s, -3.6e-5 Eh).  With more than one rank the points per rank decide what fits: c = 12 there.
-        args.c_isdf = (18 if args.gpus == 1 else 12) if args.workload == 'diamond-444-dzvp-120' else 10
+        # variant (9.3 s, -3.6e-5 Eh).  The same c at every rank count (strong scaling): the sharded spectral build holds a K slice of
+        # X per rank (74 GB at 2 ranks), not the fit rows.
+        args.c_isdf = 18 if args.workload == 'diamond-444-dzvp-120' else 10
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     import torch
@@ -396,7 +397,7 @@ def main():
             # once and writes nb x (P - r); the 256x128 kernel takes every batch of more than 128 rows (gemm_f64.hip)
             Gn, Pn = int(np.prod(cell.mesh)), len(df.ip)
             if getattr(df, 'w_spectral_fraction', None):
-                Gn = int(df._last_spectral_ldx)          # spectral form: strips of X (512 x ldx) against X ((P - r) x ldx)
+                Gn = int(getattr(df, '_last_spectral_ldx', Gn))          # spectral form: strips of X (512 x ldx) against X ((P - r) x ldx)
             nbat = int(getattr(df, '_last_fft_batch', 0) or 512)
             algs = [8.0 * ((min(nbat, Pn - r) + (Pn - r)) * Gn + min(nbat, Pn - r) * (Pn - r))
                     for r in range(0, Pn, nbat) if min(nbat, Pn - r) > 128]

@@ -107,10 +107,12 @@ class ShardedMixin:
         Pmax = int(nip_final.sum())
         need = 8 * Pmax * ng + 4 * 8 * Pmax * Pmax
         have = be.free_bytes() + sum(int(b.numel()) * 8 for k, b in self._bufs.items() if k in ('theta', 'W', 'factor', 'Dblk', 'Dinv'))
-        if need > have:
+        rows_do_not_fit = comm.agree_max(1.0 if need > have else 0.0) > 0.0
+        spectral_may = self.w_spectral and not self._want_theta and self.c_isdf <= self.w_spectral_max_c and self.fit_route != 'cholesky'
+        if rows_do_not_fit and not spectral_may:
             raise MemoryError('ISDF: %d fit rows of %d grid columns (%.0f GB with the P x P matrices) do not fit on rank %d '
                               '(%.0f GB obtainable); use more ranks or fewer points' % (Pmax, ng, need / 1e9, rk, have / 1e9))
-        self._sel = dict(sharded=True, owner=owner, merged=merged, nip_final=nip_final)
+        self._sel = dict(sharded=True, owner=owner, merged=merged, nip_final=nip_final, rows_do_not_fit=rows_do_not_fit)
         if self.pair_space == 'occ':
             self._fit_pending = True
             self._built = True
@@ -159,10 +161,61 @@ class ShardedMixin:
         if self._psi is not None:
             self._psiP = self._buffer('psiP', (P, self._psi.shape[0]))
             self._psiP.copy_(self._slice_columns(self.ip, g0, g1, src=self._psi).T)
-        theta = self._buffer('theta', (P, ng))
         ar = be.to_device(np.arange(P, dtype=np.int64))
         ip_off = self._bj_blocks([len(merged.get(b, none)) for b in range(cell.natm)], clusters)
-        for route in self._fit_routes():
+        routes = self._fit_routes()
+        # spectral form of W (block-Jacobi route): the fit rows are produced batch by batch inside _finish_W_sharded_spectral and
+        # never held as a whole - a rank keeps its K slice of X (P x ldx / R) instead of P x G / R rows
+        self.w_spectral_fraction = None
+        plan = None
+        if self.w_spectral and not self._want_theta and self.c_isdf <= self.w_spectral_max_c and \
+                (routes[0] == 'blockjacobi' or sel.get('rows_do_not_fit')):
+            plan = self._spectral_plan()
+            if comm.agree_max(0.0 if plan is not None else 1.0) != 0.0:
+                plan = None
+        if plan is not None:
+            Afac = self._buffer('factor', (P, P))
+            Dblk = self._buffer('Dblk', (P, P))
+
+            def root_factorise():
+                self._bj_prepare(aoP_T, 0, ar, ip_off, self.aoP, scratch=self._buffer('W', (P, P)))
+                return self.reg_used
+            reg = comm.run_on_root(root_factorise)
+            if comm.rank != 0:
+                be.gather_aoP(aoP_T, ar, self.aoP)
+                self._Dinv_key = None
+            comm.broadcast(Afac)
+            comm.broadcast(Dblk)
+            self.reg_used = comm.agree_max(reg or 0.0)
+            t0 = self._tick('S3_fit', t0)
+            self._fit_state = dict(kind='blockjacobi-spectral', theta=None, sharded=True, Afac=Afac, Dblk=Dblk, ip_off=ip_off, chol=None)
+            probe = None
+            if self.fit_route == 'auto':
+                T0, E = self._bj_probe_vectors(aoP_T, Afac, Dblk, ip_off)
+                probe = (E, be.empty((E.shape[0], ng)))
+            self.W = self._buffer('W', (P, P))
+            self._finish_W_sharded_spectral(self.W, plan, probe=probe)
+            t0 = self._tick('S4S5_coulomb_W', t0)
+            self.fit_route_used = 'blockjacobi'
+            ok = True
+            if probe is not None:
+                self.bj_check = comm.agree_max(self._bj_probe_energies(T0, probe[1], self.W, (g0, g1)))
+                t0 = self._tick('S5_route_check', t0)
+                tol = min(self.bj_check_tol, self.w_spectral_check_tol)
+                ok = self.bj_check <= tol
+                if not ok:
+                    warnings.warn('ISDF: block-Jacobi fit route failed its probe check (mismatch %.2e > %.2e) in the spectral build; '
+                                  'rebuilding W the classic way' % (self.bj_check, tol))
+                    self.w_spectral_fraction = None
+            if ok:
+                del aoP_T
+                self._built = True
+                return self
+            if sel.get('rows_do_not_fit'):
+                raise MemoryError('ISDF: the spectral form failed its probe check and the classic form\'s %d fit rows of %d grid '
+                                  'columns do not fit on rank %d; use more ranks or fewer points' % (P, ng, comm.rank))
+        theta = self._buffer('theta', (P, ng))
+        for route in routes:
             # the P x P factorisations run on rank 0 and are broadcast (2 x 8 P^2 bytes): every rank then holds the
             # same bits, and the shift ladders' decisions cannot diverge between ranks
             if route == 'blockjacobi':
@@ -246,18 +299,19 @@ class ShardedMixin:
         Uses the Coulomb kernel the backend is set to (plain, or range-separated for get_jk(omega=...))."""
         cell, be, comm = self.cell, self.backend, self.comm
         st = self._fit_state
+        if st['kind'] == 'blockjacobi-spectral':
+            # a rebuild of W from the same fit with another kernel (range separation): the rows are recomputed as in the first build
+            plan = self._spectral_plan()
+            if comm.agree_max(0.0 if plan is not None else 1.0) != 0.0:
+                raise NotImplementedError('this Coulomb kernel has no spectral form (negative table entries) and the fit was built '
+                                          'without resident rows; set w_spectral = False for this kernel')
+            return self._finish_W_sharded_spectral(W, plan)
         theta = st['theta']
         P, ng = theta.shape
         R, rk = comm.size, comm.rank
         mesh = np.asarray(self.mesh, dtype=np.int32)
         G = int(np.prod(mesh))
         a = np.asarray(cell.lattice_vectors(), dtype=float)
-        self.w_spectral_fraction = None
-        if st['kind'] == 'blockjacobi' and self.w_spectral and not self._want_theta and self.c_isdf <= self.w_spectral_max_c:
-            plan = self._spectral_plan()
-            # (one decision for all ranks: the plan is a function of replicated data, but 'auto' measures on the rank's own slice)
-            if comm.agree_max(0.0 if plan is not None else 1.0) == 0.0:
-                return self._finish_W_sharded_spectral(W, plan)
         # S4 + S5 streamed over row batches: rank q convolves rows P_q[t*nb : (t+1)*nb] in step t.  Two streams: the
         # exchange/FFT pipeline of step t+1 (all-to-all, row assembly, convolution, all-to-all) runs on a side stream
         # while the MFMA products of step t run on the work stream; every buffer is allocated once (two slots).
@@ -338,34 +392,56 @@ class ShardedMixin:
         elif st['kind'] == 'cholesky':
             be.W_from_factor(st['chol'], 0, W)
 
-    def _finish_W_sharded_spectral(self, W, plan):
-        """The spectral form of W (fit_route.FitRouteMixin._finish_W_spectral) on the grid-sharded build.  Rank q assembles the
-        rows of its batch over the whole grid (the same first all-to-all as the classic form), transforms them forward and packs
-        them into X[bat_q, :]; the second all-to-all hands every rank r its K slice X[:, K_r] of ALL rows (0.36 of the classic
-        form's volume); when all batches are through, W_r = X[:, K_r] X[:, K_r]^T (upper half) and one all-reduce.  The products
-        cannot start before the last batch has arrived (every row meets every row), so the exchange is not hidden behind them as
-        in the classic form - it is shorter instead."""
+    def _finish_W_sharded_spectral(self, W, plan, probe=None):
+        """The spectral form of W (fit_route.FitRouteMixin._finish_W_spectral) on the grid-sharded build.  The points are dealt to
+        the ranks in whole preconditioner blocks; in every step each rank computes, ON ITS GRID SLICE, the fit rows of every
+        rank's current batch of blocks (pair rows + block solves: nothing is held beyond the step), the first all-to-all assembles
+        rank q's batch over the whole grid on rank q, which transforms it forward and packs it into X[bat_q, :]; the second
+        all-to-all hands every rank r its K slice X[:, K_r] of ALL rows (0.36 of the classic form's volume); when all batches are
+        through, W_r = X[:, K_r] X[:, K_r]^T (upper half) and one all-reduce.  The products cannot start before the last batch has
+        arrived (every row meets every row), so the exchange is not hidden behind them as in the classic form - it is shorter
+        instead, and a rank holds P x ldx / R doubles of X where the classic form holds P x G / R of rows.
+        probe: (E (n, P), F (n, ng)) - the route check's combination rows; F <- E Y' on this rank's slice is accumulated on the way."""
         cell, be, comm = self.cell, self.backend, self.comm
         st = self._fit_state
-        theta = st['theta']
-        P, ng = theta.shape
+        ip_off = np.asarray(st['ip_off'], dtype=np.int64)
+        P = int(ip_off[-1])
+        ng = self.ao.shape[1]
         R, rk = comm.size, comm.rank
         mesh = np.asarray(self.mesh, dtype=np.int32)
         G = int(np.prod(mesh))
         ldx = int(plan['ldx'])
         self.w_spectral_fraction = plan['fraction']
+        self._last_spectral_ldx = ldx
+        self._last_fft_batch = int(self.fft_batch or 512)
         slices = [comm.split_range(G, r) for r in range(R)]
-        rows = [comm.split_range(P, r) for r in range(R)]
         ks = [tuple(16 * x for x in comm.split_range(ldx // 16, r)) for r in range(R)]      # K slices (ldx is a multiple of 128)
         kw = ks[rk][1] - ks[rk][0]
-        nb = int(self.fft_batch or 512)
-        nb = max(1, min(nb, max(hi - lo for lo, hi in rows)))
-        nsteps = max(-(-(hi - lo) // nb) for lo, hi in rows)
+        nbat = int(self.fft_batch or 512)
+        big = int(np.diff(ip_off).max())
+        # block-aligned shares of the points, and inside a share batches of whole blocks of at most max(nbat, big) rows
+        nblk = len(ip_off) - 1
+        cuts = [int(np.searchsorted(ip_off, P * r / R, side='left')) for r in range(R)] + [nblk]
+        cuts = [min(max(c, 0), nblk) for c in cuts]
+        plans = []
+        for q in range(R):
+            b0, b1 = cuts[q], max(cuts[q + 1], cuts[q])
+            steps, i = [], b0
+            while i < b1:
+                j = i + 1
+                while j < b1 and ip_off[j + 1] - ip_off[i] <= max(nbat, big):
+                    j += 1
+                steps.append((int(ip_off[i]), int(ip_off[j])))
+                i = j
+            plans.append(steps)
+        nsteps = max(len(p) for p in plans)
+        cap = max([hi - lo for p in plans for lo, hi in p] + [1])
         Xloc = be.empty((P, max(kw, 1)))
-        pieces = be.empty((nb * G,))
-        full = be.empty((nb, G))
-        Xb = be.empty((nb, ldx))
-        recvX = be.empty((R * nb * max(kw, 1),))
+        rows_loc = be.empty((R * cap, ng))           # this step's rows of every rank's batch, on this rank's slice
+        pieces = be.empty((cap * G,))
+        full = be.empty((cap, G))
+        Xb = be.empty((cap, ldx))
+        recvX = be.empty((R * cap * max(kw, 1),))
 
         def views(flat, nrow_of, width_of):
             out, off = [], 0
@@ -374,12 +450,22 @@ class ShardedMixin:
                 out.append(flat[off:off + n].view(nrow_of(q), width_of(q)))
                 off += n
             return out
+        first = True
         for t in range(nsteps):
-            bat = [(min(lo + t * nb, hi), min(lo + (t + 1) * nb, hi)) for lo, hi in rows]
+            bat = [p[t] if t < len(p) else (0, 0) for p in plans]
             nrow = [hi - lo for lo, hi in bat]
+            send = []
+            for q, (lo, hi) in enumerate(bat):
+                blockrows = rows_loc[q * cap:q * cap + (hi - lo)]
+                if hi > lo:
+                    self._bj_rows_range(lo, hi, blockrows)
+                    if probe is not None:
+                        be.rows_combine(probe[0][:, lo:hi], blockrows, probe[1], accumulate=not first)
+                        first = False
+                send.append(blockrows)
             mine = nrow[rk]
             recv = views(pieces, lambda q: mine, lambda q: slices[q][1] - slices[q][0])
-            comm.all_to_all(recv, [theta[lo:hi] for lo, hi in bat])
+            comm.all_to_all(recv, send)
             rows_full = full[:mine]
             for (s0, s1), piece in zip(slices, recv):
                 rows_full[:, s0:s1] = piece
@@ -390,7 +476,7 @@ class ShardedMixin:
             for q in range(R):
                 if nrow[q]:
                     Xloc[bat[q][0]:bat[q][1]] = got[q]
-        del pieces, full, Xb, recvX
+        del pieces, full, Xb, recvX, rows_loc
         W.zero_()
         if kw > 0:
             for b0 in range(0, P, 512):

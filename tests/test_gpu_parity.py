@@ -602,6 +602,34 @@ def test_sharded_code_path_on_one_gpu(route):
     assert abs(wj0 - wj1).max() < 1e-10 and abs(wk0 - wk1).max() < tol * abs(wk0).max()
 
 
+def test_sharded_spectral_form_on_one_gpu():
+    """The grid-sharded build's spectral form of W (points dealt in whole blocks, rows made on the fly, K slices of X exchanged,
+    probe check alongside, no resident rows) executed on ONE rank with the real kernels: same points, K equal to the single-GPU
+    spectral build to the route's noise; the range-separated rebuild goes through the same state."""
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_diamond_prim('gth-dzvp', (24, 24, 24))
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(9)
+    dm = rng.standard_normal((2, nao, nao)); dm = dm + dm.transpose(0, 2, 1)
+
+    def make(sharded):
+        df = ISDF(cell, c_isdf=6, select='refined')
+        df.w_sphere, df.w_spectral_check_tol, df.fft_batch = 0, 3e-8, 40
+        df.force_sharded = sharded
+        return df
+    ref, df = make(False), make(True)
+    vj0, vk0 = ref.get_jk(dm)
+    vj1, vk1 = df.get_jk(dm)
+    assert np.array_equal(ref.ip, df.ip) and ref.fit_route_used == df.fit_route_used == 'blockjacobi'
+    assert ref.w_spectral_fraction == df.w_spectral_fraction > 1.0
+    assert df._fit_state['kind'] == 'blockjacobi-spectral' and df._fit_state['theta'] is None
+    assert ref.bj_check is not None and df.bj_check is not None and df.bj_check <= 3e-8
+    assert abs(vj0 - vj1).max() < 1e-10 and abs(vk0 - vk1).max() < 1e-7 * abs(vk0).max()
+    wj0, wk0 = ref.get_jk(dm, omega=0.3)
+    wj1, wk1 = df.get_jk(dm, omega=0.3)
+    assert abs(wj0 - wj1).max() < 1e-10 and abs(wk0 - wk1).max() < 1e-7 * abs(wk0).max()
+
+
 @pytest.mark.parametrize('omega', [0.4, -0.4, 0.11])
 def test_range_separated_get_jk(omega):
     """get_jk(omega=...) (FFTDF.get_jk with range_coulomb, pyscf/pbc/df/fft.py:298-303): the device kernel table carries the

@@ -43,8 +43,9 @@ def _run_case(comm, fft_batch, route='cholesky'):
     if occ_space:
         df.pair_space = 'occ'
     df.fft_batch = fft_batch
-    df.fit_route = 'cholesky' if route in ('robust', 'refined', 'occ') else ('blockjacobi' if route in ('occ-bj', 'spectral') else route)
-    if route == 'spectral':
+    df.fit_route = 'cholesky' if route in ('robust', 'refined', 'occ') else ('blockjacobi' if route in ('occ-bj', 'spectral') else ('auto' if route == 'spectral-auto' else route))
+    if route in ('spectral', 'spectral-auto'):
+        df.w_spectral_check_tol = 1e-6
         df.w_sphere = 0                        # W = X X^T over the whole half spectrum: exact, K slices exchanged instead of V slices
     df.robust_k = route == 'robust'          # Dunlap's correction: V slices through the same all-to-alls, K1 all-reduced
     df.bj_check_tol = 1e-6                     # c_isdf=3 on 8 AOs: the check value is ~1e-8, far from the decision
@@ -63,8 +64,10 @@ def _run_case(comm, fft_batch, route='cholesky'):
         if comm.size > 1:
             ref = ISDF(cell, c_isdf=3, backend=OracleBackend()).get_k_exact(dm[0].dot(dm[0].T))
             assert abs(kx - ref).max() < 1e-12 * abs(ref).max()
-    if route == 'spectral':
+    if route in ('spectral', 'spectral-auto'):
         assert df.w_spectral_fraction is not None and df.w_spectral_fraction > 1.0
+        if comm.size > 1:
+            assert df._fit_state['kind'] == 'blockjacobi-spectral' and df._fit_state['theta'] is None      # no resident rows
     else:
         assert df.w_spectral_fraction is None          # (this coarse mesh does not resolve the pair products: 'auto' declines)
     return df.ip.copy(), df.W.numpy().copy(), vj, vk, df.fit_route_used, df.bj_check
@@ -84,7 +87,7 @@ def _worker(rank, world, port, q, route):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('route', ['cholesky', 'blockjacobi', 'auto', 'robust', 'refined', 'occ', 'occ-bj', 'spectral'])
+@pytest.mark.parametrize('route', ['cholesky', 'blockjacobi', 'auto', 'robust', 'refined', 'occ', 'occ-bj', 'spectral', 'spectral-auto'])
 def test_two_ranks_match_one_rank(route):
     _setup_path()
     from pyscf_isdf_amd.parallel import Comm
@@ -101,7 +104,7 @@ def test_two_ranks_match_one_rank(route):
         assert p.exitcode == 0
     assert np.array_equal(ip1, ip2)
     assert used1 == used2 == ('cholesky' if route in ('cholesky', 'robust', 'refined', 'occ') else 'blockjacobi')
-    if route == 'auto':
+    if route in ('auto', 'spectral-auto'):
         # the probe energies are all-reduced over the grid slices: both layouts measure the same mismatch
         assert chk1 is not None and abs(chk1 - chk2) <= 0.5 * chk1 + 1e-13
     assert abs(W1 - W2).max() < (1e-9 if route in ('cholesky', 'robust', 'refined') else 1e-6) * abs(W1).max() or route in ('occ', 'occ-bj')
@@ -128,6 +131,30 @@ def test_three_ranks_ragged_shares_match_one_rank():
         assert p.exitcode == 0
     assert np.array_equal(ip1, ip3) and used1 == used3
     assert abs(W1 - W3).max() < 1e-9 * abs(W1).max()
+    assert abs(vj1 - vj3).max() < 1e-10 and abs(vk1 - vk3).max() < 1e-8 * abs(vk1).max()
+
+
+@pytest.mark.timeout(300)
+def test_three_ranks_spectral_form_block_aligned_shares():
+    """The spectral form of W on three ranks: the points are dealt in whole preconditioner blocks (2 atoms -> one rank gets no
+    block at all), the rows of every rank's batch are made on the fly on each grid slice, K slices of X are exchanged; with the
+    probe check alongside.  Same points, same K as one rank."""
+    _setup_path()
+    from pyscf_isdf_amd.parallel import Comm
+    ip1, W1, vj1, vk1, used1, chk1 = _run_case(Comm(), None, 'spectral-auto')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q, 'spectral-auto')) for r in range(3)]
+    for p in procs:
+        p.start()
+    ip3, W3, vj3, vk3, used3, chk3 = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(ip1, ip3) and used1 == used3 == 'blockjacobi'
+    assert chk1 is not None and chk3 is not None
+    assert abs(W1 - W3).max() < 1e-6 * abs(W1).max()
     assert abs(vj1 - vj3).max() < 1e-10 and abs(vk1 - vk3).max() < 1e-8 * abs(vk1).max()
 
 
