@@ -132,6 +132,29 @@ def build_W(theta, a, mesh, omega=None, rc=None):
     return w * V.dot(theta.T)
 
 
+def build_W_spectral(theta, a, mesh, sphere_pct=0.0, omega=None, rc=None):
+    """build_W in its Parseval form: with the conventions of pbc/tools/pbc.py:149-211 (fft unscaled, ifft 1/N)
+    w sum_r Theta_P(r) conv(Theta_Q)(r) = (w / N) sum_G coulG(G) fft(Theta_P)(G) conj(fft(Theta_Q)(G)) = (X X^T)_PQ with
+    X_P = sqrt(w coulG / N) fft(Theta_P) (real and imaginary parts as separate columns).  sphere_pct > 0 keeps only the G inside
+    that percentage of the radius of the sphere inscribed in the reciprocal FFT box (faces at the frequencies +-(n_i - 1) // 2):
+    what include/mi355_isdf.h isdf_spectral_rows + isdf_gemm_nt compute (pyscf_isdf_amd/fit_route.py _spectral_plan)."""
+    mesh = [int(x) for x in mesh]
+    a = np.asarray(a, dtype=float)
+    N = int(np.prod(mesh))
+    w = abs(np.linalg.det(a)) / N
+    coulG = tools.get_coulG(a, mesh, omega=omega, rc=rc)
+    keep = coulG > 0
+    if sphere_pct > 0:
+        b = 2 * np.pi * np.linalg.inv(a).T
+        Gv = tools.get_Gv(b, mesh)
+        g2 = np.einsum('gi,gi->g', Gv, Gv)
+        rmin = min(2 * np.pi * ((n - 1) // 2) / np.linalg.norm(a[i]) for i, n in enumerate(mesh)) * sphere_pct / 100.0
+        keep &= g2 <= rmin * rmin * (1 + 1e-12)
+    z = tools.fft(theta, mesh)[:, keep] * np.sqrt(w * coulG[keep] / N)
+    X = np.concatenate([z.real, z.imag], axis=1)
+    return X.dot(X.T)
+
+
 def W_from_factor(S, Y, a, mesh):
     """W for Theta = S^-1 Y (S upper triangular) without forming Theta:
     W = S^-1 [w conv(Y) Y^T] S^-T  (include/mi355_isdf.h isdf_W_from_factor)."""

@@ -547,3 +547,38 @@ def test_spectral_W_host_logic_with_checker_backend():
     assert any('spectral build' in str(w.message) for w in rec) and df.w_spectral_fraction is None or df._fit_state['kind'] != 'blockjacobi-spectral'
     ref12 = ISDF(cell12, c_isdf=6, select='local', backend=OracleBackend()); ref12.w_spectral = False
     assert abs(k12 - ref12.get_jk(dm, with_j=False)[1]).max() < 1e-12
+
+
+def test_oracle_spectral_W_is_the_parseval_form_of_build_W(hec):
+    """oracle.isdf.build_W_spectral: whole box = build_W to rounding (plain, range-separated and spherically truncated kernels);
+    inside the sphere it is exact for band-limited rows and close for the smooth rows of a fit; and it is what the checker
+    backend's packed rows give through the object's plan (multiplicities of the half spectrum included)."""
+    import cells
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell, ao, aoT = hec
+    a, mesh = cell.lattice_vectors(), [int(x) for x in cell.mesh]
+    rng = np.random.default_rng(4)
+    rows = rng.standard_normal((7, aoT.shape[1]))
+    for kw in (dict(), dict(omega=0.5), dict(omega=-0.5), dict(rc=3.0)):
+        W0, W1 = oisdf.build_W(rows, a, mesh, **kw), oisdf.build_W_spectral(rows, a, mesh, **kw)
+        assert abs(W0 - W1).max() < 1e-12 * abs(W0).max()
+    # band-limited rows: nothing outside the sphere, so the truncated sum is the whole sum
+    G = aoT.shape[1]
+    z = np.fft.fftn(rows.reshape(7, *mesh), axes=(1, 2, 3))
+    f = [np.fft.fftfreq(n, 1.0 / n) for n in mesh]
+    low = (abs(f[0])[:, None, None] <= 3) & (abs(f[1])[None, :, None] <= 3) & (abs(f[2])[None, None, :] <= 3)
+    smooth = np.fft.ifftn(z * low, axes=(1, 2, 3)).real.reshape(7, G)
+    Ws, Wb = oisdf.build_W_spectral(smooth, a, mesh, sphere_pct=100.0), oisdf.build_W(smooth, a, mesh)
+    assert abs(Ws - Wb).max() < 1e-12 * abs(Wb).max()
+    assert abs(oisdf.build_W_spectral(rows, a, mesh, sphere_pct=100.0) - oisdf.build_W(rows, a, mesh)).max() > 1e-6 * abs(W0).max()
+    # the product path: plan of the object + packed rows of the checker backend
+    df = ISDF(cell, c_isdf=4, select='local', backend=OracleBackend())
+    for pct in (0, 100.0, 60.0):
+        df.w_sphere = pct
+        plan = df._spectral_plan()
+        X = df.backend.empty((7, plan['ldx']))
+        df.backend.spectral_rows(df.backend.to_device(smooth if pct else rows), np.asarray(mesh), plan['idx'], plan['scale'], X, batch=7)
+        Wx = X.numpy().dot(X.numpy().T)
+        ref = oisdf.build_W_spectral(smooth if pct else rows, a, mesh, sphere_pct=pct)
+        assert abs(Wx - ref).max() < 1e-12 * abs(ref).max()
