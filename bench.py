@@ -92,18 +92,20 @@ def cpu_baseline(cell, c_isdf, gpu_stage_sizes):
     t = time.perf_counter()
     oisdf.select_ip(ao_blk, k_b)
     est['S2_select_ip'] = (time.perf_counter() - t) * natm
-    # S3 fit: Cholesky of the full A_PP (exact size) + solves on a slice of grid columns
+    # S3 fit: Cholesky of A_PP (a leading block of at most 20480 points, extrapolated with its cube: the sample has to stay
+    # bounded at P = 30 000) + solves on a slice of grid columns (extrapolated with the square of the point count)
     aoP = rng.standard_normal((P, nao)) / np.sqrt(nao)
+    Pc = min(P, 20480)
     t = time.perf_counter()
-    A = aoP.dot(aoP.T) ** 2
-    A[np.diag_indices(P)] += 1e-3 * A.diagonal().max()
+    A = aoP[:Pc].dot(aoP[:Pc].T) ** 2
+    A[np.diag_indices(Pc)] += 1e-3 * A.diagonal().max()
     cf = scipy.linalg.cho_factor(A, overwrite_a=True)
-    t_chol = time.perf_counter() - t
+    t_chol = (time.perf_counter() - t) * (P / Pc) ** 3
     n3 = min(G, 16384)
     t = time.perf_counter()
-    B = aoP.dot(aoT_s[:, :n3]) ** 2
+    B = aoP[:Pc].dot(aoT_s[:, :n3]) ** 2
     scipy.linalg.cho_solve(cf, B)
-    est['S3_fit'] = t_chol + (time.perf_counter() - t) * G / n3
+    est['S3_fit'] = t_chol + (time.perf_counter() - t) * (P / Pc) ** 2 * G / n3
     del A, cf
     # S4 Coulomb convolution of a few full-grid rows; S5 W rows
     n4 = 4
@@ -135,9 +137,9 @@ def cpu_baseline(cell, c_isdf, gpu_stage_sizes):
     est['S7_get_k'] = (time.perf_counter() - t) * P / n7
     total = sum(est.values())
     sample = ('numpy/scipy oracle (Cholesky fit route), stage samples extrapolated linearly: S1 %d of %d grid points; S2 1 of %d atom blocks '
-              '(%d pts, %d pivots); S3 full %dx%d Cholesky + %d of %d grid columns; S4 %d of %d FFT rows; S5 %d rows x %d grid columns against all P rows; '
+              '(%d pts, %d pivots); S3 Cholesky of a %dx%d block of the %dx%d matrix (cubic extrapolation) + %d of %d grid columns; S4 %d of %d FFT rows; S5 %d rows x %d grid columns against all P rows; '
               'S6 %d grid points; S7 %d of %d rows; measured %.1f s of CPU work; per-stage estimate (s): %s'
-              % (n1, G, natm, m_b, k_b, P, P, n3, G, n4, P, r5, n5, n1, n7, P, time.perf_counter() - t_all,
+              % (n1, G, natm, m_b, k_b, Pc, Pc, P, P, n3, G, n4, P, r5, n5, n1, n7, P, time.perf_counter() - t_all,
                  {k: round(v, 1) for k, v in est.items()}))
     return total, sample
 
