@@ -582,3 +582,27 @@ def test_oracle_spectral_W_is_the_parseval_form_of_build_W(hec):
         Wx = X.numpy().dot(X.numpy().T)
         ref = oisdf.build_W_spectral(smooth if pct else rows, a, mesh, sphere_pct=pct)
         assert abs(Wx - ref).max() < 1e-12 * abs(ref).max()
+
+
+def test_spectral_state_falls_back_for_kernels_without_a_spectral_form():
+    """exxdiv='vcut_ws' (a kernel table with negative entries has no sqrt) and 'vcut_sph' (non-negative: spectral) requested from
+    an object whose fit was built in the spectral form: the truncated-kernel W is rebuilt from the same factors - through the
+    paneled classic product for vcut_ws, through X X^T for vcut_sph - and K equals the classic object's."""
+    import cells
+    from oracle_backend import OracleBackend
+    from pyscf_isdf_amd.isdf import ISDF
+    cell = cells.cell_diamond_prim('gth-szv', (12, 12, 12))
+    nao = cell.nao_nr()
+    rng = np.random.default_rng(3)
+    dm = rng.standard_normal((nao, nao)); dm = dm + dm.T
+    ref = ISDF(cell, c_isdf=5, select='local', backend=OracleBackend()); ref.w_spectral, ref.fit_route = False, 'blockjacobi'
+    sp = ISDF(cell, c_isdf=5, select='local', backend=OracleBackend()); sp.w_sphere, sp.fit_route = 0, 'blockjacobi'
+    k0 = ref.get_jk(dm, with_j=False)[1]
+    k1 = sp.get_jk(dm, with_j=False)[1]
+    assert sp._fit_state['kind'] == 'blockjacobi-spectral' and abs(k1 - k0).max() < 1e-7 * abs(k0).max()
+    for ex in ('vcut_sph', 'vcut_ws'):
+        a = ref.get_jk(dm, with_j=False, exxdiv=ex)[1]
+        b = sp.get_jk(dm, with_j=False, exxdiv=ex)[1]
+        assert abs(a - k0).max() > 1e-3 * abs(k0).max()                  # the truncation does change K
+        assert abs(a - b).max() < 1e-7 * abs(a).max()
+    assert sp._fit_state['kind'] == 'blockjacobi-spectral'               # the state survives the fallback
