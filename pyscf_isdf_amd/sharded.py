@@ -168,8 +168,10 @@ class ShardedMixin:
         # never held as a whole - a rank keeps its K slice of X (P x ldx / R) instead of P x G / R rows
         self.w_spectral_fraction = None
         plan = None
+        # (tried first also above bj_max_c when the route is left to 'auto' - as the single-GPU build does where the rows would need
+        # panels: the probe check decides, and the Cholesky route below is the fallback)
         if self.w_spectral and not self._want_theta and self.c_isdf <= self.w_spectral_max_c and \
-                (routes[0] == 'blockjacobi' or sel.get('rows_do_not_fit')):
+                (routes[0] == 'blockjacobi' or sel.get('rows_do_not_fit') or self.fit_route == 'auto'):
             plan = self._spectral_plan()
             if comm.agree_max(0.0 if plan is not None else 1.0) != 0.0:
                 plan = None

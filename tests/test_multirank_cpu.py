@@ -44,6 +44,8 @@ def _run_case(comm, fft_batch, route='cholesky'):
         df.pair_space = 'occ'
     df.fft_batch = fft_batch
     df.fit_route = 'cholesky' if route in ('robust', 'refined', 'occ') else ('blockjacobi' if route in ('occ-bj', 'spectral') else ('auto' if route == 'spectral-auto' else route))
+    if route == 'spectral-auto' and comm.size > 1:
+        df.bj_max_c = 2                        # above bj_max_c the sharded build still tries the spectral form first (route 'auto')
     if route in ('spectral', 'spectral-auto'):
         df.w_spectral_check_tol = 1e-6
         df.w_sphere = 0                        # W = X X^T over the whole half spectrum: exact, K slices exchanged instead of V slices
